@@ -1,0 +1,163 @@
+/*
+ * splitp_hip.h - C ABI of the MI355X (gfx950) implementation of SplitP's
+ * flattening / subflattening / split_score hot path.
+ *
+ * The reference (js51/SplitP v0.3.2) is pure Python and has NO FFI or plugin interface
+ * (SURVEY.md section 8b): the drop-in boundary is its Python call surface
+ *     splitp.flattening     (splitp/constructions.py:7)
+ *     splitp.subflattening  (splitp/constructions.py:108)
+ *     splitp.split_score    (splitp/phylogenetics.py:315)
+ * which splitp_amd/ mirrors.  This header is the C ABI underneath that surface: what a
+ * maintainer of the reference would bind with ctypes to replace the bodies of those three
+ * functions (INTEGRATION.md shows the stub).  Every entry point names the reference code
+ * it replaces.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = SP_OK, otherwise an SP_E* code; the message
+ *     is available from sp_last_error() (thread-local).
+ *   - plain pointers and sizes only; no C++ exceptions cross the ABI.
+ *   - "host" pointers are ordinary process memory (NumPy arrays); "dev" pointers are HIP
+ *     device pointers (e.g. torch tensor data_ptr()).  The library owns all other device
+ *     memory behind the opaque handles.
+ *   - a context is bound to one device and one HIP stream; it is not thread-safe.  All
+ *     kernels of a call are enqueued on the context's stream; calls that return host data
+ *     synchronise that stream before returning, calls that write only device memory do not.
+ *   - taxa are numbered 0..n-1 in the order of the pattern string (taxon 0 = first
+ *     character).  A pattern key is the base-4 value of the pattern string with
+ *     A,C,G,T = 0,1,2,3 (splitp/constants.py:7-8) and the FIRST character most significant
+ *     (splitp/constructions.py:166-171).
+ *   - a split is given as two ordered lists of taxon indices (the order in which the
+ *     reference iterates split[0] / split[1]: first listed = most significant base-4 digit of
+ *     the row / column index, constructions.py:39-40).  The two lists must be disjoint and
+ *     together cover all n taxa (the reference silently overwrites colliding cells otherwise,
+ *     constructions.py:43,:101 - rejected here with SP_EINVAL).
+ */
+#ifndef SPLITP_HIP_H
+#define SPLITP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_OK 0
+#define SP_EINVAL 1   /* bad argument */
+#define SP_EHIP 2     /* a HIP runtime call failed */
+#define SP_ENOMEM 3   /* device or host allocation failed */
+#define SP_ELIMIT 4   /* size outside what this build supports (see message) */
+#define SP_ENOCONV 5  /* eigen iteration did not converge (score still written, flagged) */
+
+#define SP_ABI_VERSION 1
+
+typedef struct sp_ctx sp_ctx;             /* device + stream + workspace arena */
+typedef struct sp_alignment sp_alignment; /* device-resident pattern table */
+
+/* ---------------------------------------------------------------- context ---------- */
+int sp_abi_version(void);
+const char* sp_last_error(void);
+/* number of visible HIP devices (0 when there is no GPU; never fails) */
+int sp_device_count(void);
+
+/* device: HIP ordinal.  stream: a hipStream_t to adopt (e.g. torch's current stream), or
+ * NULL to create a private non-blocking stream owned by the context. */
+int sp_ctx_create(int device, void* stream, sp_ctx** out);
+int sp_ctx_destroy(sp_ctx* ctx);
+int sp_ctx_set_stream(sp_ctx* ctx, void* stream);
+int sp_ctx_synchronize(sp_ctx* ctx);
+
+/* Per-phase device timing.  When enabled, every batched call brackets each phase with
+ * hipEvents on the context's stream; sp_ctx_phase_times() then synchronises and returns,
+ * for each phase, the accumulated milliseconds and number of launches since the last
+ * reset.  Phase ids: SP_PHASE_*. */
+#define SP_PHASE_REINDEX 0  /* per-split bit-gather + presence bitmaps + ranks            */
+#define SP_PHASE_SCATTER 1  /* zero-fill + scatter into the (compact) count matrix        */
+#define SP_PHASE_GRAM 2     /* fp64 MFMA Gram over the smaller side                       */
+#define SP_PHASE_EIGEN 3    /* top-4 eigenvalues + score                                  */
+#define SP_PHASE_MOMENT 4   /* signed second-moment matrix (subflattening path)           */
+#define SP_PHASE_SUBSCORE 5 /* gather + one-sided Jacobi SVD of the (3a+1)x(3b+1) blocks  */
+#define SP_PHASE_HIST 6     /* site-pattern histogram (alignment columns -> pattern table) */
+#define SP_PHASE_DENSE 7    /* full 4^a x 4^b dense scatter (sp_flatten_dense)             */
+#define SP_N_PHASES 8
+int sp_ctx_enable_timing(sp_ctx* ctx, int on);
+int sp_ctx_reset_timing(sp_ctx* ctx);
+int sp_ctx_phase_times(sp_ctx* ctx, double* ms /*[SP_N_PHASES]*/, int64_t* launches /*[SP_N_PHASES]*/);
+
+/* ---------------------------------------------------------------- alignment -------- */
+/* Upload a pattern table (the dict the reference passes as `pattern_probabilities`,
+ * e.g. from splitp/simulation.py:42-56 or splitp/parsers/fasta.py:66-80).
+ *   keys[D]     pattern keys (see above), all distinct
+ *   weights[D]  the table's float values (relative frequencies or exact probabilities)
+ *   counts[D]   optional (may be NULL): integer site counts with weights[i] == counts[i]/N
+ *               exactly; enables the exact-integer Gram / moment path
+ *   N           number of sites (sum of counts), ignored when counts == NULL */
+int sp_alignment_create(sp_ctx* ctx, const uint64_t* keys, const double* weights, const int64_t* counts,
+                        int64_t D, int n_taxa, int64_t N, sp_alignment** out);
+
+/* Build the pattern table on the device from alignment columns: the site-pattern histogram
+ * that precedes the path (splitp/parsers/fasta.py:48-63 get_pattern_counts; sites containing a
+ * character outside ACGT, either case, are skipped, :54-57).  seqs is n_taxa rows of L ASCII
+ * characters (row stride `stride` bytes, host memory). */
+int sp_alignment_from_sequences(sp_ctx* ctx, const uint8_t* seqs, int n_taxa, int64_t L, int64_t stride,
+                                sp_alignment** out);
+/* Same, from already packed site keys resident on the host (one key per site). */
+int sp_alignment_from_site_keys(sp_ctx* ctx, const uint64_t* site_keys, int64_t L, int n_taxa, sp_alignment** out);
+
+int sp_alignment_destroy(sp_alignment* al);
+/* D distinct patterns, n taxa, N sites (0 if unknown), exact = 1 when integer counts are held */
+int sp_alignment_info(const sp_alignment* al, int64_t* D, int* n_taxa, int64_t* N, int* exact);
+/* copy the table back (sorted by key when it was built on the device); any pointer may be NULL */
+int sp_alignment_fetch(sp_alignment* al, uint64_t* keys, double* weights, int64_t* counts);
+
+/* ---------------------------------------------------------------- flattening ------- */
+/* Row/column index of every pattern for one split - the body of the per-pattern loop of
+ * constructions.py:88-93 (sparse/dok format).  rows[D], cols[D] host, table order. */
+int sp_flatten_indices(sp_alignment* al, const int32_t* order_a, int a, const int32_t* order_b, int b,
+                       int64_t* rows, int64_t* cols);
+
+/* Reduced flattening (constructions.py:31-55): two calls.  _prepare computes the sorted sets
+ * of used row / column keys on the device and returns their sizes; _fetch writes the R x C
+ * float64 matrix (row-major, zeros elsewhere) and, if non-NULL, the used row/col keys. */
+int sp_flatten_reduced_prepare(sp_alignment* al, const int32_t* order_a, int a, const int32_t* order_b, int b,
+                               int64_t* R, int64_t* C);
+int sp_flatten_reduced_fetch(sp_alignment* al, double* matrix, int64_t* row_keys, int64_t* col_keys);
+
+/* Full 4^a x 4^b count matrix (uint32, row-major) of one split; requires integer counts and
+ * 4^(a+b) <= 2^32 cells.  The .todense() of constructions.py:86-102 times N. */
+int sp_flatten_dense_counts(sp_alignment* al, const int32_t* order_a, int a, const int32_t* order_b, int b,
+                            uint32_t* out_host);
+
+/* ---------------------------------------------------------------- subflattening ---- */
+/* (3a+1) x (3b+1) signed-sum matrix of constructions.py:108-163, row-major float64. */
+int sp_subflatten(sp_alignment* al, const int32_t* order_a, int a, const int32_t* order_b, int b, double* out_host);
+/* the (3n+1)x(3n+1) signed second-moment matrix all subflattenings are sub-blocks of
+ * (SURVEY.md appendix A.3); int64 when the alignment is exact (out_i64), else float64. */
+int sp_moment_matrix(sp_alignment* al, int64_t* out_i64, double* out_f64);
+
+/* ---------------------------------------------------------------- split score ------ */
+/* phylogenetics.py:280-300 for a host matrix (row-major, leading dimension ld):
+ * score = sqrt(max(0, 1 - (sum of the 4 largest sigma^2) / (sum of all sigma^2))).
+ * min(rows, cols) <= 4 gives exactly 0 (the reference's 1 - x/x).  An all-zero matrix gives NaN
+ * (the reference's 0/0). */
+int sp_score_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, int64_t cols, int64_t ld, double* score);
+/* phylogenetics.py:303-312 for a sparse matrix given as COO triplets (host). */
+int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* ci, const double* v, int64_t nnz,
+                     int64_t rows, int64_t cols, double* score);
+
+/* Batched: flattening + split_score for many splits of one alignment, everything on the
+ * device (the README loop, README.md:36-41, as one call).
+ *   split_taxa[n_splits * n]  for split s: order_a (a entries) then order_b (n - a entries)
+ *   split_a[n_splits]         a of each split
+ *   method                    SP_METHOD_FLATTENING or SP_METHOD_SUBFLATTENING
+ *   scores_host               may be NULL; if given, the stream is synchronised
+ *   scores_dev                may be NULL; device buffer of n_splits doubles
+ *   status_host               may be NULL; per-split flags (bit 0: eigen iteration hit its cap) */
+#define SP_METHOD_FLATTENING 0
+#define SP_METHOD_SUBFLATTENING 1
+int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
+                    int method, double* scores_host, void* scores_dev, int32_t* status_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLITP_HIP_H */

@@ -1,0 +1,22 @@
+"""splitp_amd - MI355X-native implementation of SplitP's flattening / subflattening /
+split_score hot path (reference: js51/SplitP v0.3.2, splitp/constructions.py,
+splitp/phylogenetics.py:280-328, splitp/matrix.py).
+
+Drop-in surface (same names / signatures as `import splitp`, reference splitp/__init__.py:15-17):
+    flattening, subflattening, split_score, FlatFormat, all_splits
+plus the device-resident batched form of the README loop:
+    DeviceAlignment, score_splits
+Host code is Python; all compute is hand-written HIP for gfx950 behind a ctypes C ABI
+(include/splitp_hip.h).  There is no CPU fallback."""
+from . import constants, constructions, enums, matrix, phylogenetics, splits  # noqa: F401
+from .batch import score_splits  # noqa: F401
+from .constructions import (flattening, sparse_flattening_with_banned_patterns,  # noqa: F401
+                            subflattening)
+from .device import DeviceAlignment, get_context  # noqa: F401
+from .enums import FlatFormat, Method  # noqa: F401
+from .matrix import frobenius_norm, is_sparse  # noqa: F401
+from .phylogenetics import split_score  # noqa: F401
+from .splits import all_splits  # noqa: F401
+from ._lib import SplitPDeviceError  # noqa: F401
+
+__version__ = "0.1.0"

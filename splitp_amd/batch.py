@@ -1,0 +1,146 @@
+"""Batched scoring: many candidate splits of one alignment in one device pass, sharded across
+GPUs with an all-gather of the scores.
+
+This is the device-resident form of the reference's README loop (README.md:36-41):
+    for split in splits: split_score(flattening(split, alignment, FlatFormat.reduced))
+and of one round of erickson_SVD (splitp/phylogenetics.py:126-140).  The candidate-split set is
+dealt to ranks by cost class; each rank scores its shard with libsplitp_hip.so; one
+all_gather (RCCL when the process group's backend is "nccl") returns every score to every rank."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .device import as_device_alignment, normalise_split, resolve_split
+from .enums import Method
+
+
+def encode_splits(splits, table, n_taxa):
+    """-> (split_taxa int32 [S, n], split_a int32 [S]) in the C ABI's layout."""
+    s_count = len(splits)
+    taxa_arr = np.empty((s_count, n_taxa), dtype=np.int32)
+    a_arr = np.empty(s_count, dtype=np.int32)
+    taxa = getattr(table, "taxa", None)
+    where = None
+    for i, sp in enumerate(splits):
+        sp = normalise_split(sp)
+        if where is None:
+            t = taxa if taxa is not None else sorted(set.union(*map(set, sp)))
+            where = {x: j for j, x in enumerate(t)}
+        if len(sp[0]) + len(sp[1]) != n_taxa:
+            raise ValueError(f"split {sp} does not cover all {n_taxa} taxa of the table")
+        a_arr[i] = len(sp[0])
+        taxa_arr[i, : len(sp[0])] = [where[x] for x in sp[0]]
+        taxa_arr[i, len(sp[0]):] = [where[x] for x in sp[1]]
+    return taxa_arr, a_arr
+
+
+def split_costs(split_a, n_taxa, method):
+    """Relative cost of a split (for balanced sharding): the Gram over the smaller side costs
+    ~ 4^k * D on the flattening route; the subflattening route's eigenproblem ~ (3k+1)^3."""
+    k = np.minimum(split_a, n_taxa - split_a).astype(np.int64)
+    if method == _lib.SP_METHOD_FLATTENING:
+        return (4.0 ** k)
+    return (3.0 * k + 1.0) ** 3
+
+
+def shard_indices(costs, world_size):
+    """Deal splits to ranks: sort by (cost class desc, original index) and deal round-robin, so
+    every rank receives an equal share of every cost class.  Returns a list of index arrays
+    (deterministic; identical on every rank)."""
+    order = np.lexsort((np.arange(len(costs)), -np.asarray(costs)))
+    return [order[r::world_size] for r in range(world_size)]
+
+
+def _method_code(method):
+    name = getattr(method, "name", method)
+    if name in ("flattening", Method.flattening):
+        return _lib.SP_METHOD_FLATTENING
+    if name in ("subflattening", Method.subflattening):
+        return _lib.SP_METHOD_SUBFLATTENING
+    raise ValueError(f"unsupported method {method!r} (flattening or subflattening)")
+
+
+def score_encoded(al, split_taxa, split_a, method_code, scores_dev_ptr=None, want_host=True):
+    """Score already-encoded splits on this process's GPU.  Returns (scores, status) host arrays
+    when want_host, else enqueues only (scores land in scores_dev_ptr)."""
+    n = len(split_a)
+    split_taxa = np.ascontiguousarray(split_taxa, dtype=np.int32)
+    split_a = np.ascontiguousarray(split_a, dtype=np.int32)
+    scores = np.empty(n, dtype=np.float64) if want_host else None
+    status = np.zeros(n, dtype=np.int32) if want_host else None
+    _lib.check(al.ctx._lib.sp_score_splits(
+        al.handle, _lib._ptr(split_taxa, C.c_int32), _lib._ptr(split_a, C.c_int32), n, method_code,
+        _lib._ptr(scores, C.c_double), C.c_void_p(scores_dev_ptr) if scores_dev_ptr else None,
+        _lib._ptr(status, C.c_int32)))
+    return scores, status
+
+
+def gather_scores(local_scores, shards, n_total, group=None, device_tensor=None):
+    """All-gather the per-rank score shards and un-permute them into split order.
+
+    local_scores: 1-D array / tensor of this rank's shard (len(shards[rank])).  With the "nccl"
+    backend (RCCL over xGMI) the exchange is one all_gather_into_tensor of ceil(S/P) doubles per
+    rank on the GPU; with "gloo" (CPU tests) the same call on host tensors."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per = max(len(s) for s in shards)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    if device_tensor is not None:
+        send = device_tensor
+    else:
+        send = torch.zeros(per, dtype=torch.float64, device=dev)
+        loc = torch.as_tensor(np.asarray(local_scores, dtype=np.float64))
+        send[: len(shards[rank])] = loc.to(dev)
+    recv = torch.empty(world * per, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    allv = recv.cpu().numpy().reshape(world, per)
+    out = np.empty(n_total, dtype=np.float64)
+    for r in range(world):
+        out[shards[r]] = allv[r, : len(shards[r])]
+    return out
+
+
+def score_splits(pattern_probabilities, splits, method=Method.flattening, distributed=None, group=None,
+                 return_status=False):
+    """Scores of `splits` (any iterable of the reference's split forms) for one alignment.
+
+    distributed=None: use torch.distributed if it is initialised with world_size > 1.
+    Every rank must call this with the same splits; every rank receives all scores."""
+    splits = list(splits)
+    al = as_device_alignment(pattern_probabilities)
+    code = _method_code(method)
+    taxa_arr, a_arr = encode_splits(splits, pattern_probabilities, al.n_taxa)
+    use_dist = distributed
+    if use_dist is None:
+        try:
+            import torch.distributed as dist
+
+            use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        except Exception:
+            use_dist = False
+    if not use_dist:
+        scores, status = score_encoded(al, taxa_arr, a_arr, code)
+        return (scores, status) if return_status else scores
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    shards = shard_indices(split_costs(a_arr, al.n_taxa, code), world)
+    mine = shards[rank]
+    per = max(len(s) for s in shards)
+    if dist.get_backend(group) == "nccl":
+        send = torch.zeros(per, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+        if len(mine):
+            score_encoded(al, taxa_arr[mine], a_arr[mine], code, scores_dev_ptr=send.data_ptr(), want_host=False)
+        out = gather_scores(None, shards, len(splits), group=group, device_tensor=send)
+    else:
+        loc, _ = score_encoded(al, taxa_arr[mine], a_arr[mine], code) if len(mine) else (np.zeros(0), None)
+        out = gather_scores(loc, shards, len(splits), group=group)
+    return out

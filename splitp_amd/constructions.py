@@ -1,0 +1,147 @@
+"""flattening / subflattening - drop-in for reference splitp/constructions.py, on MI355X.
+
+Same names, argument order, defaults and return types as the reference:
+    flattening(split, pattern_probabilities, flattening_format=FlatFormat.sparse)   constructions.py:7
+    subflattening(split, pattern_probabilities, data=None)                          constructions.py:108
+    sparse_flattening_with_banned_patterns(split, table, taxa, ban_row, ban_col)    constructions.py:105
+The per-pattern Python loops run as HIP kernels (splitp_amd/csrc/flatten.hip, subflat.hip)
+behind the C ABI of include/splitp_hip.h; results come back as the same host objects the
+reference returns (scipy dok_matrix / numpy ndarray, float64)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+from scipy.sparse import coo_matrix, dok_matrix
+
+from . import _lib
+from .constants import DNA_state_space_dict
+from .device import as_device_alignment, normalise_split, resolve_split
+from .enums import FlatFormat
+
+
+def _orders(split, table, al):
+    split = normalise_split(split)
+    oa, ob = resolve_split(split, table, al.n_taxa)
+    return oa, ob
+
+
+def _indices(al, oa, ob):
+    d = len(al)
+    rows = np.empty(d, dtype=np.int64)
+    cols = np.empty(d, dtype=np.int64)
+    _lib.check(al.ctx._lib.sp_flatten_indices(
+        al.handle, _lib._ptr(oa, C.c_int32), len(oa), _lib._ptr(ob, C.c_int32), len(ob),
+        _lib._ptr(rows, C.c_int64), _lib._ptr(cols, C.c_int64)))
+    return rows, cols
+
+
+def flattening(split, pattern_probabilities, flattening_format=FlatFormat.sparse):
+    """Compute the flattening of a split given a pattern probability dictionary.
+
+    reference: splitp/constructions.py:7-28.  `pattern_probabilities` may be the reference's
+    dict / Alignment or a splitp_amd.DeviceAlignment (already resident in HBM).  Any format other
+    than FlatFormat.sparse / FlatFormat.reduced returns None, like the reference."""
+    if flattening_format is not FlatFormat.sparse and flattening_format is not FlatFormat.reduced:
+        name = getattr(flattening_format, "name", None)
+        if name not in ("sparse", "reduced"):  # accept the reference's own enum members by name
+            return None
+        flattening_format = FlatFormat[name]
+    al = as_device_alignment(pattern_probabilities)
+    oa, ob = _orders(split, pattern_probabilities, al)
+    if flattening_format is FlatFormat.sparse:
+        return _sparse(al, oa, ob)
+    return _reduced(al, oa, ob)
+
+
+def _reduced(al, oa, ob):
+    # reference: constructions.py:31-55
+    r, c = C.c_int64(), C.c_int64()
+    lib = al.ctx._lib
+    _lib.check(lib.sp_flatten_reduced_prepare(al.handle, _lib._ptr(oa, C.c_int32), len(oa), _lib._ptr(ob, C.c_int32),
+                                              len(ob), C.byref(r), C.byref(c)))
+    out = np.zeros((r.value, c.value), dtype=np.float64)
+    _lib.check(lib.sp_flatten_reduced_fetch(al.handle, _lib._ptr(out, C.c_double), None, None))
+    return out
+
+
+def _sparse(al, oa, ob, ban_row_patterns=None, ban_col_patterns=None):
+    # reference: constructions.py:58-102 (dok branch)
+    rows, cols = _indices(al, oa, ob)
+    _, vals, _ = al.fetch()
+    shape = (4 ** len(oa), 4 ** len(ob))
+    if ban_row_patterns is not None or ban_col_patterns is not None:
+        vals = vals.copy()
+        if ban_row_patterns is not None:
+            vals[_digit_count(rows, len(oa), ban_row_patterns) > 1] = 0.0
+        if ban_col_patterns is not None:
+            vals[_digit_count(cols, len(ob), ban_col_patterns) > 1] = 0.0
+    keep = vals != 0  # a dok assignment of 0 stores nothing
+    out = coo_matrix((vals[keep], (rows[keep], cols[keep])), shape=shape, dtype=np.float64).todok()
+    if not isinstance(out, dok_matrix):
+        out = dok_matrix(out)
+    return out
+
+
+def _digit_count(index, length, letter):
+    """How many of the `length` base-4 digits of each index equal the digit of `letter`
+    (the reference's row_pattern.count(letter), constructions.py:94-99)."""
+    if len(str(letter)) != 1:
+        # str.count of a multi-character pattern: fall back to explicit strings (rare, host-side option)
+        out = np.zeros(len(index), dtype=np.int64)
+        for i, v in enumerate(index.tolist()):
+            s = "".join("ACGT"[(v >> (2 * (length - 1 - t))) & 3] for t in range(length))
+            out[i] = s.count(letter)
+        return out
+    d = DNA_state_space_dict[letter]
+    cnt = np.zeros(len(index), dtype=np.int64)
+    for t in range(length):
+        cnt += ((index >> (2 * t)) & 3) == d
+    return cnt
+
+
+def sparse_flattening_with_banned_patterns(split, pattern_probabilities, taxa, ban_row_patterns=None,
+                                           ban_col_patterns=None):
+    """reference: constructions.py:58-105 (alias of __sparse_flattening with an explicit taxa list)."""
+    al = as_device_alignment(pattern_probabilities)
+    split = normalise_split(split)
+    where = {t: i for i, t in enumerate(taxa)}
+    oa = np.array([where[s] for s in split[0]], dtype=np.int32)
+    ob = np.array([where[s] for s in split[1]], dtype=np.int32)
+    return _sparse(al, oa, ob, ban_row_patterns, ban_col_patterns)
+
+
+def subflattening_labels(length):
+    """Row / column labels of a subflattening (reference constructions.py:174-189)."""
+    out = []
+    for i in range(length):
+        for ch in "ACG":
+            out.append("T" * i + ch + "T" * (length - i - 1))
+    out.append("T" * length)
+    return out
+
+
+def subflattening(split, pattern_probabilities, data=None):
+    """Signed-sum subflattening, (3|A|+1) x (3|B|+1) float64 ndarray.
+
+    reference: splitp/constructions.py:108-163.  Computed as a sub-block of the alignment's
+    signed second-moment matrix (one device contraction per alignment, cached on the device
+    table).  `data`, if given, receives the reference's cache keys ("coeffs", "labels"); the
+    coefficient cache itself is not needed here and stays empty.
+
+    Deviation (documented): for a string split on a plain dict the reference counts '|' as a taxon
+    (constructions.py:114-117) and then raises KeyError; here the split is normalised first."""
+    al = as_device_alignment(pattern_probabilities)
+    split = normalise_split(split)
+    oa, ob = resolve_split(split, pattern_probabilities, al.n_taxa)
+    if data is not None:
+        data.setdefault("coeffs", {})
+        labels = data.setdefault("labels", {})
+        labels.setdefault(len(oa), subflattening_labels(len(oa)))
+        labels.setdefault(len(ob), subflattening_labels(len(ob)))
+    if len(oa) + len(ob) != al.n_taxa:
+        raise KeyError(len(oa) + len(ob))  # the reference's __reconstruct_pattern raises KeyError here (:198)
+    out = np.empty((3 * len(oa) + 1, 3 * len(ob) + 1), dtype=np.float64)
+    _lib.check(al.ctx._lib.sp_subflatten(al.handle, _lib._ptr(oa, C.c_int32), len(oa), _lib._ptr(ob, C.c_int32),
+                                         len(ob), _lib._ptr(out, C.c_double)))
+    return out

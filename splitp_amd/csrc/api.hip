@@ -1,0 +1,661 @@
+// Host side of libsplitp_hip.so: context / alignment handles, batch planning, the C ABI.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "common.h"
+
+// ------------------------------------------------------------------ errors ---------------------
+static thread_local char g_err[1024] = "";
+void sp_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* sp_last_error(void) { return g_err; }
+extern "C" int sp_abi_version(void) { return SP_ABI_VERSION; }
+extern "C" int sp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int DevBuf::ensure(size_t bytes) {
+    if (bytes <= cap) return SP_OK;
+    if (p) {
+        SP_HIP(hipDeviceSynchronize());
+        SP_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = std::max(bytes, (size_t)4096);
+    want += want / 8;  // slack so slowly growing shapes do not re-allocate every call
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        sp_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        return SP_ENOMEM;
+    }
+    cap = want;
+    return SP_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+// ------------------------------------------------------------------ timing ---------------------
+PhaseScope::PhaseScope(sp_ctx* ctx, int ph) : c(ctx), phase(ph) {
+    if (!c->timing) return;
+    auto get = [&]() {
+        hipEvent_t e = nullptr;
+        if (!c->timer.pool.empty()) {
+            e = c->timer.pool.back();
+            c->timer.pool.pop_back();
+        } else if (hipEventCreate(&e) != hipSuccess) {
+            e = nullptr;
+        }
+        return e;
+    };
+    e0 = get();
+    e1 = get();
+    if (e0) (void)hipEventRecord(e0, c->stream);
+}
+PhaseScope::~PhaseScope() {
+    if (!c->timing || !e0 || !e1) return;
+    (void)hipEventRecord(e1, c->stream);
+    c->timer.pending[phase].push_back({e0, e1});
+}
+
+static int drain_timers(sp_ctx* ctx) {
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    for (int ph = 0; ph < SP_N_PHASES; ++ph) {
+        for (auto& pr : ctx->timer.pending[ph]) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                ctx->timer.ms[ph] += ms;
+                ctx->timer.launches[ph] += 1;
+            }
+            ctx->timer.pool.push_back(pr.first);
+            ctx->timer.pool.push_back(pr.second);
+        }
+        ctx->timer.pending[ph].clear();
+    }
+    return SP_OK;
+}
+
+// ------------------------------------------------------------------ context --------------------
+extern "C" int sp_ctx_create(int device, void* stream, sp_ctx** out) {
+    SP_REQUIRE(out, SP_EINVAL, "sp_ctx_create: out is NULL");
+    int n = sp_device_count();
+    SP_REQUIRE(n > 0, SP_EHIP, "sp_ctx_create: no HIP device visible (this library has no CPU fallback)");
+    SP_REQUIRE(device >= 0 && device < n, SP_EINVAL, "sp_ctx_create: device %d out of range (have %d)", device, n);
+    SP_HIP(hipSetDevice(device));
+    sp_ctx* c = new sp_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = reinterpret_cast<hipStream_t>(stream);
+        c->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            sp_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return SP_EHIP;
+        }
+        c->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return SP_OK;
+}
+
+extern "C" int sp_ctx_destroy(sp_ctx* c) {
+    if (!c) return SP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int ph = 0; ph < SP_N_PHASES; ++ph)
+        for (auto& pr : c->timer.pending[ph]) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    for (auto e : c->timer.pool) (void)hipEventDestroy(e);
+    DevBuf* bufs[] = {&c->splits, &c->bitmaps, &c->coords, &c->dims,   &c->mats, &c->grams,
+                      &c->eigws,  &c->scores,  &c->status, &c->misc,   &c->misc2};
+    for (auto* b : bufs) b->release();
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SP_OK;
+}
+
+extern "C" int sp_ctx_set_stream(sp_ctx* c, void* stream) {
+    SP_REQUIRE(c, SP_EINVAL, "sp_ctx_set_stream: ctx is NULL");
+    SP_HIP(hipStreamSynchronize(c->stream));
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (stream) {
+        c->stream = reinterpret_cast<hipStream_t>(stream);
+        c->own_stream = false;
+    } else {
+        SP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return SP_OK;
+}
+
+extern "C" int sp_ctx_synchronize(sp_ctx* c) {
+    SP_REQUIRE(c, SP_EINVAL, "sp_ctx_synchronize: ctx is NULL");
+    SP_HIP(hipStreamSynchronize(c->stream));
+    return SP_OK;
+}
+
+extern "C" int sp_ctx_enable_timing(sp_ctx* c, int on) {
+    SP_REQUIRE(c, SP_EINVAL, "ctx is NULL");
+    c->timing = on != 0;
+    return SP_OK;
+}
+extern "C" int sp_ctx_reset_timing(sp_ctx* c) {
+    SP_REQUIRE(c, SP_EINVAL, "ctx is NULL");
+    SP_CHECK(drain_timers(c));
+    for (int i = 0; i < SP_N_PHASES; ++i) {
+        c->timer.ms[i] = 0;
+        c->timer.launches[i] = 0;
+    }
+    return SP_OK;
+}
+extern "C" int sp_ctx_phase_times(sp_ctx* c, double* ms, int64_t* launches) {
+    SP_REQUIRE(c, SP_EINVAL, "ctx is NULL");
+    SP_CHECK(drain_timers(c));
+    for (int i = 0; i < SP_N_PHASES; ++i) {
+        if (ms) ms[i] = c->timer.ms[i];
+        if (launches) launches[i] = c->timer.launches[i];
+    }
+    return SP_OK;
+}
+
+// ------------------------------------------------------------------ alignment ------------------
+extern "C" int sp_alignment_create(sp_ctx* ctx, const uint64_t* keys, const double* weights, const int64_t* counts,
+                                   int64_t D, int n_taxa, int64_t N, sp_alignment** out) {
+    SP_REQUIRE(ctx && out, SP_EINVAL, "sp_alignment_create: NULL ctx/out");
+    SP_REQUIRE(n_taxa >= 2 && n_taxa <= 32, SP_EINVAL, "n_taxa must be in [2, 32], got %d", n_taxa);
+    SP_REQUIRE(D >= 0, SP_EINVAL, "D < 0");
+    SP_REQUIRE(D == 0 || (keys && (weights || counts)), SP_EINVAL, "keys and weights/counts are required");
+    SP_HIP(hipSetDevice(ctx->device));
+    const u64 lim = n_taxa == 32 ? ~0ull : ((1ull << (2 * n_taxa)) - 1);
+    std::vector<u32> c32;
+    std::vector<double> w;
+    double sumsq = 0;
+    if (counts) {
+        c32.resize(D);
+        for (int64_t i = 0; i < D; ++i) {
+            SP_REQUIRE(counts[i] >= 0 && counts[i] <= 0xFFFFFFFFll, SP_EINVAL, "count %lld out of uint32 range",
+                       (long long)counts[i]);
+            c32[i] = (u32)counts[i];
+        }
+        SP_REQUIRE(N > 0, SP_EINVAL, "N must be positive when counts are given");
+    }
+    w.resize(D);
+    for (int64_t i = 0; i < D; ++i) {
+        SP_REQUIRE(keys[i] <= lim, SP_EINVAL, "pattern key %llu does not fit %d taxa", (unsigned long long)keys[i],
+                   n_taxa);
+        w[i] = weights ? weights[i] : (double)counts[i] / (double)N;
+        sumsq += w[i] * w[i];
+    }
+    sp_alignment* al = new sp_alignment();
+    al->ctx = ctx;
+    al->n_taxa = n_taxa;
+    al->D = D;
+    al->N = counts ? N : 0;
+    al->exact = counts != nullptr;
+    al->sumsq_w = sumsq;
+    int rc = SP_OK;
+    const size_t d1 = (size_t)std::max<int64_t>(D, 1);
+    if ((rc = al->keys.ensure(d1 * 8)) || (rc = al->weights.ensure(d1 * 8)) || (rc = al->counts.ensure(d1 * 4))) {
+        sp_alignment_destroy(al);
+        return rc;
+    }
+    if (D > 0) {
+        // synchronous copies: the host vectors above die at return
+        SP_HIP(hipMemcpy(al->keys.p, keys, D * 8, hipMemcpyHostToDevice));
+        SP_HIP(hipMemcpy(al->weights.p, w.data(), D * 8, hipMemcpyHostToDevice));
+        if (counts) SP_HIP(hipMemcpy(al->counts.p, c32.data(), D * 4, hipMemcpyHostToDevice));
+    }
+    *out = al;
+    return SP_OK;
+}
+
+extern "C" int sp_alignment_destroy(sp_alignment* al) {
+    if (!al) return SP_OK;
+    (void)hipSetDevice(al->ctx->device);
+    (void)hipStreamSynchronize(al->ctx->stream);
+    al->keys.release();
+    al->weights.release();
+    al->counts.release();
+    al->moments.release();
+    delete al;
+    return SP_OK;
+}
+
+extern "C" int sp_alignment_info(const sp_alignment* al, int64_t* D, int* n_taxa, int64_t* N, int* exact) {
+    SP_REQUIRE(al, SP_EINVAL, "alignment is NULL");
+    if (D) *D = al->D;
+    if (n_taxa) *n_taxa = al->n_taxa;
+    if (N) *N = al->N;
+    if (exact) *exact = al->exact ? 1 : 0;
+    return SP_OK;
+}
+
+extern "C" int sp_alignment_fetch(sp_alignment* al, uint64_t* keys, double* weights, int64_t* counts) {
+    SP_REQUIRE(al, SP_EINVAL, "alignment is NULL");
+    SP_HIP(hipSetDevice(al->ctx->device));
+    SP_HIP(hipStreamSynchronize(al->ctx->stream));
+    if (al->D == 0) return SP_OK;
+    if (keys) SP_HIP(hipMemcpy(keys, al->keys.p, al->D * 8, hipMemcpyDeviceToHost));
+    if (weights) SP_HIP(hipMemcpy(weights, al->weights.p, al->D * 8, hipMemcpyDeviceToHost));
+    if (counts) {
+        SP_REQUIRE(al->exact, SP_EINVAL, "alignment holds no integer counts");
+        std::vector<u32> c(al->D);
+        SP_HIP(hipMemcpy(c.data(), al->counts.p, al->D * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < al->D; ++i) counts[i] = c[i];
+    }
+    return SP_OK;
+}
+
+// ------------------------------------------------------------------ split validation / planning
+static int check_split(int n, const int32_t* oa, int a, const int32_t* ob, int b) {
+    SP_REQUIRE(oa && ob, SP_EINVAL, "split order arrays are NULL");
+    SP_REQUIRE(a >= 1 && b >= 1 && a + b == n, SP_EINVAL,
+               "a split must cover all %d taxa of the table (got %d + %d): the reference overwrites colliding "
+               "cells for partial splits (constructions.py:43,:101), which is rejected here",
+               n, a, b);
+    unsigned seen = 0;
+    for (int i = 0; i < a + b; ++i) {
+        const int t = i < a ? oa[i] : ob[i - a];
+        SP_REQUIRE(t >= 0 && t < n, SP_EINVAL, "taxon index %d out of range [0, %d)", t, n);
+        SP_REQUIRE(!(seen & (1u << t)), SP_EINVAL, "taxon %d appears twice in the split", t);
+        seen |= 1u << t;
+    }
+    return SP_OK;
+}
+
+struct Plan {
+    std::vector<SplitDev> splits;
+    size_t bm_words = 0, pf_words = 0, mat_elems = 0, g_elems = 0;
+};
+
+// rows_first_small: orient every split so that the smaller side indexes the rows (scoring).
+static int plan_splits(int n, int64_t D, const int32_t* split_taxa, const int32_t* split_a, int64_t S,
+                       bool small_rows, bool want_mats, bool want_gram, Plan& plan) {
+    plan.splits.resize(S);
+    for (int64_t s = 0; s < S; ++s) {
+        const int a = split_a[s], b = n - a;
+        const int32_t* oa = split_taxa + s * n;
+        const int32_t* ob = oa + a;
+        SP_CHECK(check_split(n, oa, a, ob, b));
+        SplitDev& sd = plan.splits[s];
+        memset(&sd, 0, sizeof(sd));
+        const bool swap = small_rows && a > b;
+        sd.nr = swap ? b : a;
+        sd.nc = swap ? a : b;
+        for (int i = 0; i < sd.nr; ++i) sd.taxa[i] = (int8_t)(swap ? ob[i] : oa[i]);
+        for (int i = 0; i < sd.nc; ++i) sd.taxa[sd.nr + i] = (int8_t)(swap ? oa[i] : ob[i]);
+        SP_REQUIRE(sd.nr <= 14 && sd.nc <= 14, SP_ELIMIT,
+                   "split side of %d taxa: the bitmap compaction of this build supports sides up to 14 taxa",
+                   std::max(sd.nr, sd.nc));
+        sd.rw = (int32_t)((pow4(sd.nr) + 63) / 64);
+        sd.cw = (int32_t)((pow4(sd.nc) + 63) / 64);
+        sd.bm_off = (int64_t)plan.bm_words;
+        sd.pfx_off = (int64_t)plan.pf_words;
+        plan.bm_words += (size_t)sd.rw + sd.cw;
+        plan.pf_words += (size_t)sd.rw + sd.cw;
+        const int64_t rmax = std::min<int64_t>(pow4(sd.nr), std::max<int64_t>(D, 1));
+        const int64_t cmax = std::min<int64_t>(pow4(sd.nc), std::max<int64_t>(D, 1));
+        sd.rcap = (int32_t)round_up(rmax, 64);
+        sd.pitch = (int32_t)round_up(cmax, 32);
+        if (want_mats) {
+            sd.mat_off = (int64_t)plan.mat_elems;
+            plan.mat_elems += (size_t)sd.rcap * sd.pitch;
+        }
+        if (want_gram) {
+            sd.g_pitch = sd.rcap;
+            sd.g_off = (int64_t)plan.g_elems;
+            plan.g_elems += (size_t)sd.rcap * sd.rcap;
+        }
+    }
+    return SP_OK;
+}
+
+static int upload_plan(sp_ctx* ctx, const Plan& plan, int64_t D) {
+    const size_t S = plan.splits.size();
+    SP_CHECK(ctx->splits.ensure(S * sizeof(SplitDev)));
+    SP_CHECK(ctx->bitmaps.ensure(plan.bm_words * 8 + plan.pf_words * 4 + 64));
+    SP_CHECK(ctx->coords.ensure(S * (size_t)std::max<int64_t>(D, 1) * 8));
+    SP_CHECK(ctx->dims.ensure(S * sizeof(int2)));
+    SP_HIP(hipMemcpyAsync(ctx->splits.p, plan.splits.data(), S * sizeof(SplitDev), hipMemcpyHostToDevice, ctx->stream));
+    return SP_OK;
+}
+
+static u64* bm_ptr(sp_ctx* ctx) { return ctx->bitmaps.as<u64>(); }
+static u32* pf_ptr(sp_ctx* ctx, const Plan& plan) { return reinterpret_cast<u32*>(ctx->bitmaps.as<u64>() + plan.bm_words); }
+static u32* rr_ptr(sp_ctx* ctx) { return ctx->coords.as<u32>(); }
+static u32* cc_ptr(sp_ctx* ctx, size_t S, int64_t D) { return ctx->coords.as<u32>() + S * (size_t)std::max<int64_t>(D, 1); }
+
+// ------------------------------------------------------------------ flattening API ------------
+extern "C" int sp_flatten_indices(sp_alignment* al, const int32_t* oa, int a, const int32_t* ob, int b, int64_t* rows,
+                                  int64_t* cols) {
+    SP_REQUIRE(al && rows && cols, SP_EINVAL, "NULL argument");
+    sp_ctx* ctx = al->ctx;
+    SP_HIP(hipSetDevice(ctx->device));
+    SP_CHECK(check_split(al->n_taxa, oa, a, ob, b));
+    if (al->D == 0) return SP_OK;
+    SplitDev sd;
+    memset(&sd, 0, sizeof(sd));
+    sd.nr = a;
+    sd.nc = b;
+    for (int i = 0; i < a; ++i) sd.taxa[i] = (int8_t)oa[i];
+    for (int i = 0; i < b; ++i) sd.taxa[a + i] = (int8_t)ob[i];
+    SP_CHECK(ctx->splits.ensure(sizeof(SplitDev)));
+    SP_CHECK(ctx->misc.ensure((size_t)al->D * 16));
+    SP_HIP(hipMemcpyAsync(ctx->splits.p, &sd, sizeof(sd), hipMemcpyHostToDevice, ctx->stream));
+    int64_t* drows = ctx->misc.as<int64_t>();
+    int64_t* dcols = drows + al->D;
+    SP_CHECK(launch_bit_indices(ctx, al->keys.as<u64>(), al->D, al->n_taxa, ctx->splits.as<SplitDev>(), drows, dcols));
+    SP_HIP(hipMemcpyAsync(rows, drows, al->D * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipMemcpyAsync(cols, dcols, al->D * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+extern "C" int sp_flatten_reduced_prepare(sp_alignment* al, const int32_t* oa, int a, const int32_t* ob, int b,
+                                          int64_t* R, int64_t* C) {
+    SP_REQUIRE(al && R && C, SP_EINVAL, "NULL argument");
+    sp_ctx* ctx = al->ctx;
+    SP_HIP(hipSetDevice(ctx->device));
+    al->red_ready = false;
+    std::vector<int32_t> taxa(al->n_taxa);
+    SP_CHECK(check_split(al->n_taxa, oa, a, ob, b));
+    for (int i = 0; i < a; ++i) taxa[i] = oa[i];
+    for (int i = 0; i < b; ++i) taxa[a + i] = ob[i];
+    if (al->D == 0) {
+        *R = *C = 0;
+        al->red_R = al->red_C = 0;
+        al->red_ready = true;
+        return SP_OK;
+    }
+    Plan plan;
+    int32_t aa = a;
+    SP_CHECK(plan_splits(al->n_taxa, al->D, taxa.data(), &aa, 1, false, false, false, plan));
+    SP_CHECK(upload_plan(ctx, plan, al->D));
+    SP_CHECK(launch_reindex(ctx, al->keys.as<u64>(), al->D, al->n_taxa, ctx->splits.as<SplitDev>(), plan.splits,
+                            bm_ptr(ctx), pf_ptr(ctx, plan), ctx->dims.as<int2>(), rr_ptr(ctx), cc_ptr(ctx, 1, al->D)));
+    int2 d;
+    SP_HIP(hipMemcpyAsync(&d, ctx->dims.p, sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    *R = al->red_R = d.x;
+    *C = al->red_C = d.y;
+    al->red_ready = true;
+    return SP_OK;
+}
+
+__global__ void k_scatter_exact_shape(int64_t D, const u32* __restrict__ rr, const u32* __restrict__ cc,
+                                      const double* __restrict__ vals, double* __restrict__ out, int64_t C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D) out[(int64_t)rr[i] * C + cc[i]] = vals[i];
+}
+
+extern "C" int sp_flatten_reduced_fetch(sp_alignment* al, double* matrix, int64_t* row_keys, int64_t* col_keys) {
+    SP_REQUIRE(al && al->red_ready, SP_EINVAL, "sp_flatten_reduced_fetch without a preceding _prepare");
+    sp_ctx* ctx = al->ctx;
+    SP_HIP(hipSetDevice(ctx->device));
+    const int64_t R = al->red_R, C = al->red_C, D = al->D;
+    al->red_ready = false;
+    if (D == 0 || R == 0 || C == 0) return SP_OK;
+    const size_t mbytes = (size_t)R * C * 8;
+    SP_CHECK(ctx->misc.ensure(mbytes + (size_t)(R + C) * 8));
+    double* dm = ctx->misc.as<double>();
+    int64_t* drk = reinterpret_cast<int64_t*>(dm + R * C);
+    int64_t* dck = drk + R;
+    if (matrix) {
+        SP_HIP(hipMemsetAsync(dm, 0, mbytes, ctx->stream));
+        hipLaunchKernelGGL(k_scatter_exact_shape, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, D,
+                           rr_ptr(ctx), cc_ptr(ctx, 1, D), al->weights.as<double>(), dm, C);
+        SP_HIP(hipGetLastError());
+        SP_HIP(hipMemcpyAsync(matrix, dm, mbytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (row_keys || col_keys) {
+        SP_CHECK(launch_used_keys(ctx, al->keys.as<u64>(), D, al->n_taxa, ctx->splits.as<SplitDev>(), rr_ptr(ctx),
+                                  cc_ptr(ctx, 1, D), drk, dck));
+        if (row_keys) SP_HIP(hipMemcpyAsync(row_keys, drk, R * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (col_keys) SP_HIP(hipMemcpyAsync(col_keys, dck, C * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+extern "C" int sp_flatten_dense_counts(sp_alignment* al, const int32_t* oa, int a, const int32_t* ob, int b,
+                                       uint32_t* out_host) {
+    SP_REQUIRE(al && out_host, SP_EINVAL, "NULL argument");
+    SP_REQUIRE(al->exact, SP_EINVAL, "sp_flatten_dense_counts needs an alignment with integer counts");
+    sp_ctx* ctx = al->ctx;
+    SP_HIP(hipSetDevice(ctx->device));
+    SP_CHECK(check_split(al->n_taxa, oa, a, ob, b));
+    SP_REQUIRE(al->n_taxa <= 14, SP_ELIMIT, "dense flattening of %d taxa would need 4^%d cells", al->n_taxa, al->n_taxa);
+    SplitDev sd;
+    memset(&sd, 0, sizeof(sd));
+    sd.nr = a;
+    sd.nc = b;
+    for (int i = 0; i < a; ++i) sd.taxa[i] = (int8_t)oa[i];
+    for (int i = 0; i < b; ++i) sd.taxa[a + i] = (int8_t)ob[i];
+    const int64_t cells = pow4(al->n_taxa);
+    SP_CHECK(ctx->splits.ensure(sizeof(SplitDev)));
+    SP_CHECK(ctx->mats.ensure((size_t)cells * 4));
+    SP_HIP(hipMemcpyAsync(ctx->splits.p, &sd, sizeof(sd), hipMemcpyHostToDevice, ctx->stream));
+    SP_CHECK(launch_dense_scatter(ctx, al->keys.as<u64>(), al->counts.as<u32>(), al->D, al->n_taxa,
+                                  ctx->splits.as<SplitDev>(), sd, ctx->mats.as<u32>()));
+    SP_HIP(hipMemcpyAsync(out_host, ctx->mats.p, (size_t)cells * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+// ------------------------------------------------------------------ scoring --------------------
+static int run_dense_route(sp_alignment* al, const Plan& plan) {
+    sp_ctx* ctx = al->ctx;
+    const size_t S = plan.splits.size();
+    const int64_t D = al->D;
+    SP_CHECK(upload_plan(ctx, plan, D));
+    SP_CHECK(ctx->grams.ensure(plan.g_elems * 8));
+    SP_CHECK(ctx->scores.ensure(S * 8));
+    SP_CHECK(ctx->status.ensure(S * 4));
+    const SplitDev* sdev = ctx->splits.as<SplitDev>();
+    int2* dims = ctx->dims.as<int2>();
+    SP_CHECK(launch_reindex(ctx, al->keys.as<u64>(), D, al->n_taxa, sdev, plan.splits, bm_ptr(ctx), pf_ptr(ctx, plan),
+                            dims, rr_ptr(ctx), cc_ptr(ctx, S, D)));
+    if (al->exact) {
+        SP_CHECK(ctx->mats.ensure(plan.mat_elems * 4));
+        SP_CHECK(launch_zero_scatter<u32>(ctx, sdev, plan.splits, D, dims, rr_ptr(ctx), cc_ptr(ctx, S, D),
+                                          al->counts.as<u32>(), ctx->mats.as<u32>()));
+        SP_CHECK(launch_gram<u32>(ctx, sdev, plan.splits, dims, ctx->mats.as<u32>(), ctx->grams.as<double>()));
+    } else {
+        SP_CHECK(ctx->mats.ensure(plan.mat_elems * 8));
+        SP_CHECK(launch_zero_scatter<double>(ctx, sdev, plan.splits, D, dims, rr_ptr(ctx), cc_ptr(ctx, S, D),
+                                             al->weights.as<double>(), ctx->mats.as<double>()));
+        SP_CHECK(launch_gram<double>(ctx, sdev, plan.splits, dims, ctx->mats.as<double>(), ctx->grams.as<double>()));
+    }
+    SP_CHECK(launch_eigen(ctx, sdev, plan.splits, dims, ctx->grams.as<double>(), nullptr, ctx->scores.as<double>(),
+                          ctx->status.as<int>()));
+    return SP_OK;
+}
+
+int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S);  // subflat.hip
+
+extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
+                               int method, double* scores_host, void* scores_dev, int32_t* status_host) {
+    SP_REQUIRE(al && split_taxa && split_a, SP_EINVAL, "NULL argument");
+    SP_REQUIRE(n_splits >= 0, SP_EINVAL, "n_splits < 0");
+    sp_ctx* ctx = al->ctx;
+    SP_HIP(hipSetDevice(ctx->device));
+    if (n_splits == 0) return SP_OK;
+    SP_REQUIRE(al->D > 0, SP_EINVAL, "empty pattern table");
+    if (method == SP_METHOD_FLATTENING) {
+        Plan plan;
+        SP_CHECK(plan_splits(al->n_taxa, al->D, split_taxa, split_a, n_splits, true, true, true, plan));
+        SP_CHECK(run_dense_route(al, plan));
+    } else if (method == SP_METHOD_SUBFLATTENING) {
+        SP_CHECK(run_subflat_route(al, split_taxa, split_a, n_splits));
+    } else {
+        sp_set_error("unknown method %d", method);
+        return SP_EINVAL;
+    }
+    if (scores_dev)
+        SP_HIP(hipMemcpyAsync(scores_dev, ctx->scores.p, n_splits * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (scores_host)
+        SP_HIP(hipMemcpyAsync(scores_host, ctx->scores.p, n_splits * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (status_host)
+        SP_HIP(hipMemcpyAsync(status_host, ctx->status.p, n_splits * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (scores_host || status_host) SP_HIP(hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+// Generic matrix: upload (transposed if needed so the smaller side indexes rows), Gram, eigen.
+extern "C" int sp_score_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, int64_t cols, int64_t ld,
+                                   double* score) {
+    SP_REQUIRE(ctx && m && score, SP_EINVAL, "NULL argument");
+    SP_REQUIRE(rows >= 1 && cols >= 1 && ld >= cols, SP_EINVAL, "bad matrix shape %lld x %lld (ld %lld)",
+               (long long)rows, (long long)cols, (long long)ld);
+    SP_HIP(hipSetDevice(ctx->device));
+    const bool tr = rows > cols;
+    const int64_t R = tr ? cols : rows, K = tr ? rows : cols;
+    if (R <= 4) {
+        // reference: 1 - x/x = 0 exactly (nan for the all-zero matrix)
+        bool any = false;
+        for (int64_t i = 0; i < rows && !any; ++i)
+            for (int64_t j = 0; j < cols; ++j)
+                if (m[i * ld + j] != 0) {
+                    any = true;
+                    break;
+                }
+        *score = any ? 0.0 : NAN;
+        return SP_OK;
+    }
+    Plan plan;
+    plan.splits.resize(1);
+    SplitDev& sd = plan.splits[0];
+    memset(&sd, 0, sizeof(sd));
+    sd.rcap = (int32_t)round_up(R, 64);
+    sd.pitch = (int32_t)round_up(K, 32);
+    sd.g_pitch = sd.rcap;
+    SP_CHECK(ctx->splits.ensure(sizeof(SplitDev)));
+    SP_CHECK(ctx->dims.ensure(sizeof(int2)));
+    SP_CHECK(ctx->mats.ensure((size_t)sd.rcap * sd.pitch * 8));
+    SP_CHECK(ctx->grams.ensure((size_t)sd.rcap * sd.rcap * 8));
+    SP_CHECK(ctx->scores.ensure(8));
+    SP_CHECK(ctx->status.ensure(4));
+    // pack on the host into the padded (R_pad x K_pad) layout, transposing if needed
+    std::vector<double> packed((size_t)sd.rcap * sd.pitch, 0.0);
+    if (!tr) {
+        for (int64_t i = 0; i < rows; ++i) memcpy(&packed[(size_t)i * sd.pitch], m + i * ld, cols * 8);
+    } else {
+        for (int64_t i = 0; i < rows; ++i)
+            for (int64_t j = 0; j < cols; ++j) packed[(size_t)j * sd.pitch + i] = m[i * ld + j];
+    }
+    const int2 d = make_int2((int)R, (int)K);
+    SP_HIP(hipMemcpyAsync(ctx->mats.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipMemcpyAsync(ctx->dims.p, &d, sizeof(d), hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipMemcpyAsync(ctx->splits.p, &sd, sizeof(sd), hipMemcpyHostToDevice, ctx->stream));
+    SP_CHECK(launch_gram<double>(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(),
+                                 ctx->mats.as<double>(), ctx->grams.as<double>()));
+    SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.as<double>(),
+                          nullptr, ctx->scores.as<double>(), ctx->status.as<int>()));
+    SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+// Sparse (COO) matrix: phylogenetics.py:303-312.  The reference asks ARPACK for the top-4 singular
+// values and divides by the Frobenius norm; here the non-empty rows / columns are compacted on the
+// device, the compact matrix is scattered densely and scored through the same Gram + eigen kernels
+// (removing all-zero rows / columns does not change singular values).
+extern "C" int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* ci, const double* v, int64_t nnz,
+                                int64_t rows, int64_t cols, double* score) {
+    SP_REQUIRE(ctx && score, SP_EINVAL, "NULL argument");
+    SP_REQUIRE(rows >= 1 && cols >= 1 && nnz >= 0, SP_EINVAL, "bad shape");
+    SP_REQUIRE(nnz == 0 || (ri && ci && v), SP_EINVAL, "NULL triplet arrays");
+    SP_HIP(hipSetDevice(ctx->device));
+    if (nnz == 0) {
+        *score = NAN;  // reference: 0/0
+        return SP_OK;
+    }
+    SP_REQUIRE(rows <= ((int64_t)1 << 32) && cols <= ((int64_t)1 << 32), SP_ELIMIT,
+               "sparse matrix side %lld exceeds the 2^32 supported by the bitmap compaction",
+               (long long)std::max(rows, cols));
+    bool any = false;
+    for (int64_t i = 0; i < nnz; ++i) {
+        SP_REQUIRE(ri[i] >= 0 && ri[i] < rows && ci[i] >= 0 && ci[i] < cols, SP_EINVAL, "triplet %lld out of range",
+                   (long long)i);
+        any |= v[i] != 0;
+    }
+    if (!any) {
+        *score = NAN;
+        return SP_OK;
+    }
+    // orient so that the side with fewer distinct indices can become the rows: unknown before
+    // compaction, so compact first with rows = given rows, then transpose logically if needed.
+    Plan plan;
+    plan.splits.resize(1);
+    SplitDev& sd = plan.splits[0];
+    memset(&sd, 0, sizeof(sd));
+    sd.rw = (int32_t)((rows + 63) / 64);
+    sd.cw = (int32_t)((cols + 63) / 64);
+    plan.bm_words = plan.pf_words = (size_t)sd.rw + sd.cw;
+    SP_CHECK(ctx->splits.ensure(sizeof(SplitDev)));
+    SP_CHECK(ctx->bitmaps.ensure(plan.bm_words * 12 + 64));
+    SP_CHECK(ctx->coords.ensure((size_t)nnz * 8));
+    SP_CHECK(ctx->dims.ensure(sizeof(int2)));
+    SP_CHECK(ctx->misc.ensure((size_t)nnz * 24));
+    int64_t* dri = ctx->misc.as<int64_t>();
+    int64_t* dci = dri + nnz;
+    double* dv = reinterpret_cast<double*>(dci + nnz);
+    SP_HIP(hipMemcpyAsync(dri, ri, nnz * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipMemcpyAsync(dci, ci, nnz * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipMemcpyAsync(dv, v, nnz * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipMemcpyAsync(ctx->splits.p, &sd, sizeof(sd), hipMemcpyHostToDevice, ctx->stream));
+    u32* rr = rr_ptr(ctx);
+    u32* cc = rr + nnz;
+    SP_CHECK(launch_reindex_coo(ctx, dri, dci, nnz, ctx->splits.as<SplitDev>(), bm_ptr(ctx), pf_ptr(ctx, plan),
+                                ctx->dims.as<int2>(), rr, cc));
+    int2 d;
+    SP_HIP(hipMemcpyAsync(&d, ctx->dims.p, sizeof(d), hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    const bool tr = d.x > d.y;
+    const int64_t R = tr ? d.y : d.x, K = tr ? d.x : d.y;
+    if (R <= 4) {
+        *score = 0.0;
+        return SP_OK;
+    }
+    sd.rcap = (int32_t)round_up(R, 64);
+    sd.pitch = (int32_t)round_up(K, 32);
+    sd.g_pitch = sd.rcap;
+    const int2 d2 = make_int2((int)R, (int)K);
+    SP_CHECK(ctx->mats.ensure((size_t)sd.rcap * sd.pitch * 8));
+    SP_CHECK(ctx->grams.ensure((size_t)sd.rcap * sd.rcap * 8));
+    SP_CHECK(ctx->scores.ensure(8));
+    SP_CHECK(ctx->status.ensure(4));
+    SP_HIP(hipMemcpyAsync(ctx->splits.p, &sd, sizeof(sd), hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipMemcpyAsync(ctx->dims.p, &d2, sizeof(d2), hipMemcpyHostToDevice, ctx->stream));
+    SP_CHECK(launch_zero_scatter<double>(ctx, ctx->splits.as<SplitDev>(), plan.splits, nnz, ctx->dims.as<int2>(),
+                                         tr ? cc : rr, tr ? rr : cc, dv, ctx->mats.as<double>()));
+    SP_CHECK(launch_gram<double>(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(),
+                                 ctx->mats.as<double>(), ctx->grams.as<double>()));
+    SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.as<double>(),
+                          nullptr, ctx->scores.as<double>(), ctx->status.as<int>()));
+    SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}

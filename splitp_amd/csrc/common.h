@@ -1,0 +1,141 @@
+// Internal declarations shared by the .hip translation units of libsplitp_hip.so.
+// (The public C ABI is include/splitp_hip.h.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/splitp_hip.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+void sp_set_error(const char* fmt, ...);
+
+#define SP_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            sp_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return SP_EHIP;                                                                       \
+        }                                                                                         \
+    } while (0)
+
+#define SP_CHECK(call)          \
+    do {                        \
+        int r__ = (call);       \
+        if (r__ != SP_OK) return r__; \
+    } while (0)
+
+#define SP_REQUIRE(cond, code, ...) \
+    do {                            \
+        if (!(cond)) {              \
+            sp_set_error(__VA_ARGS__); \
+            return (code);          \
+        }                           \
+    } while (0)
+
+// Grow-only device buffer.  Re-allocation synchronises the device (rare: sizes settle after
+// the first call of a given shape; 288 GB of HBM means we never need to be frugal).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct PhaseTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[SP_N_PHASES];
+    std::vector<hipEvent_t> pool;
+    double ms[SP_N_PHASES] = {0};
+    int64_t launches[SP_N_PHASES] = {0};
+};
+
+struct sp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool timing = false;
+    PhaseTimer timer;
+    // workspace pools (see DESIGN.md "HBM layout")
+    DevBuf splits;     // SplitDev[n_splits]
+    DevBuf bitmaps;    // presence bitmaps + rank prefixes
+    DevBuf coords;     // compact (row, col) of every (split, pattern)
+    DevBuf dims;       // int2 (R, C) per split
+    DevBuf mats;       // compact count / weight matrices
+    DevBuf grams;      // Gram matrices (fp64)
+    DevBuf eigws;      // eigen workspace
+    DevBuf scores;     // double per split
+    DevBuf status;     // int per split
+    DevBuf misc;       // API scratch
+    DevBuf misc2;
+    int n_cu = 256;
+};
+
+struct sp_alignment {
+    sp_ctx* ctx = nullptr;
+    int n_taxa = 0;
+    int64_t D = 0;
+    int64_t N = 0;
+    bool exact = false;
+    DevBuf keys;     // u64[D]
+    DevBuf weights;  // double[D]
+    DevBuf counts;   // u32[D]   (exact only)
+    double sumsq_w = 0;  // sum of weights^2 (host-computed, informational)
+    // cached signed second-moment matrix (subflattening path)
+    bool moments_ready = false;
+    DevBuf moments;  // int64 or double [(3n+1)^2]
+    // state of the last sp_flatten_reduced_prepare
+    int64_t red_R = 0, red_C = 0;
+    bool red_ready = false;
+};
+
+// One candidate split as the kernels see it.
+struct SplitDev {
+    int32_t nr, nc;      // taxa on the row side / column side
+    int8_t taxa[32];     // row-side taxa (most significant first), then column-side taxa
+    int64_t bm_off;      // u64-word offset of the row bitmap in the bitmap pool; col bitmap follows
+    int32_t rw, cw;      // words in the row / col bitmaps
+    int64_t pfx_off;     // u32 offset of the rank-prefix arrays (row prefixes, then col prefixes)
+    int64_t mat_off;     // element offset of this split's compact matrix in the matrix pool
+    int32_t pitch;       // matrix row pitch in elements
+    int32_t rcap;        // allocated rows (multiple of 64)
+    int64_t g_off;       // element offset of the Gram matrix in the gram pool
+    int32_t g_pitch;     // Gram pitch (= rcap)
+    int32_t cls;         // size class (for launch grouping)
+};
+
+struct PhaseScope {
+    sp_ctx* c;
+    int phase;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    PhaseScope(sp_ctx* ctx, int ph);
+    ~PhaseScope();
+};
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int64_t pow4(int k) { return (int64_t)1 << (2 * k); }
+
+// ---- launchers implemented in the kernel translation units -------------------------------
+int launch_reindex(sp_ctx* ctx, const u64* keys, int64_t D, int n_taxa, const SplitDev* splits_dev,
+                   const std::vector<SplitDev>& splits, u64* bitmaps, u32* prefixes, int2* dims, u32* rr, u32* cc);
+int launch_reindex_coo(sp_ctx* ctx, const int64_t* rows_in, const int64_t* cols_in, int64_t nnz,
+                       const SplitDev* split_dev, u64* bitmaps, u32* prefixes, int2* dims, u32* rr, u32* cc);
+int launch_bit_indices(sp_ctx* ctx, const u64* keys, int64_t D, int n_taxa, const SplitDev* split_dev,
+                       int64_t* rows, int64_t* cols);
+template <typename T>
+int launch_zero_scatter(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits, int64_t D,
+                        const int2* dims, const u32* rr, const u32* cc, const T* vals, T* mats);
+int launch_used_keys(sp_ctx* ctx, const u64* keys, int64_t D, int n_taxa, const SplitDev* split_dev, const u32* rr,
+                     const u32* cc, int64_t* row_keys, int64_t* col_keys);
+int launch_dense_scatter(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, int n_taxa,
+                         const SplitDev* split_dev, const SplitDev& split, u32* out);
+template <typename T>
+int launch_gram(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits, const int2* dims,
+                const T* mats, double* grams);
+int launch_eigen(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits, const int2* dims,
+                 const double* grams, double* work, double* scores, int* status);
+int eigen_work_doubles_per_split(int rcap);

@@ -1,0 +1,290 @@
+// Site-pattern histogram: alignment columns -> (pattern key, count) table, on the device.
+//
+// The step that immediately precedes the path in the reference:
+//   splitp/parsers/fasta.py:48-63  get_pattern_counts (per-site Python loop; sites with any character
+//                                  outside ACGT after .upper() are skipped and do not count towards N)
+//   splitp/simulation.py:42-56     generate_alignment's counts dict
+//
+// Kernels
+//   k_pack_sites   n ASCII rows of L characters -> one 2-bit-per-taxon key per site (coalesced row reads),
+//                  invalid sites get the sentinel ~0.
+//   k_hist_lds     the histogram proper.  Keys stream in coalesced 8-byte reads; each workgroup first
+//                  aggregates its tile of sites in an LDS open-addressing table (ds_cmpst + ds_add), so the
+//                  very hot bins (at short branch lengths the four constant patterns hold ~10 % of the
+//                  sites EACH) cost one global atomic per workgroup instead of one per site; the table is
+//                  then flushed to the 4^n-bin count array in HBM with global_atomic_add.
+//   k_bins_count / k_bins_write   stream the bin array once each: per-block non-zero counts, exclusive scan
+//                  on the host-free path (single-block scan kernel), ordered compaction -> keys ascending
+//                  (= the A<C<G<T pattern order of simulation.py:51-54).
+// The bin array is 4 * 4^n bytes: 4 MiB at n = 10, 64 MiB at n = 12, 16 GiB at n = 16 - affordable on a
+// 288 GB part, which is why no sort is needed up to 16 taxa.
+#include <algorithm>
+#include <cstring>
+
+#include "common.h"
+
+#define HIST_THREADS 256
+#define HIST_PER_THREAD 8
+#define HIST_TILE (HIST_THREADS * HIST_PER_THREAD)  // sites per workgroup pass
+#define HIST_SLOTS 4096                             // LDS table slots (= 2 * HIST_TILE): 48 KiB
+
+__global__ __launch_bounds__(256) void k_pack_sites(const uint8_t* __restrict__ seqs, int n, int64_t L, int64_t stride,
+                                                    u64* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= L) return;
+    u64 k = 0;
+    bool ok = true;
+    for (int t = 0; t < n; ++t) {
+        const unsigned ch = seqs[(int64_t)t * stride + i] & 0xDFu;  // upper-case (fasta.py:53)
+        unsigned d;
+        if (ch == 'A') d = 0;
+        else if (ch == 'C') d = 1;
+        else if (ch == 'G') d = 2;
+        else if (ch == 'T') d = 3;
+        else { d = 0; ok = false; }
+        // '&0xDF' maps a few non-letters onto letters (e.g. '!' -> 0x01: no; 'a'-'z' -> 'A'-'Z' only for
+        // 0x61-0x7A; characters 0x41-0x5A are unchanged).  Bytes 0x01-0x1A / 0x21-0x3A cannot alias A,C,G,T.
+        k = (k << 2) | d;
+    }
+    keys[i] = ok ? k : ~0ull;
+}
+
+__global__ __launch_bounds__(HIST_THREADS) void k_hist_lds(const u64* __restrict__ keys, int64_t L,
+                                                           u32* __restrict__ bins, u32* __restrict__ n_valid) {
+    __shared__ u64 t_key[HIST_SLOTS];
+    __shared__ u32 t_cnt[HIST_SLOTS];
+    u32 valid = 0;
+    for (int64_t tile = (int64_t)blockIdx.x * HIST_TILE; tile < L; tile += (int64_t)gridDim.x * HIST_TILE) {
+        for (int i = threadIdx.x; i < HIST_SLOTS; i += HIST_THREADS) {
+            t_key[i] = ~0ull;
+            t_cnt[i] = 0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < HIST_PER_THREAD; ++j) {
+            const int64_t i = tile + (int64_t)j * HIST_THREADS + threadIdx.x;  // coalesced
+            if (i >= L) break;
+            const u64 k = keys[i];
+            if (k == ~0ull) continue;
+            ++valid;
+            u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 52) & (HIST_SLOTS - 1);
+            while (true) {
+                const u64 cur = ((volatile u64*)t_key)[h];
+                if (cur == k) break;
+                if (cur == ~0ull) {
+                    const u64 old = atomicCAS(&t_key[h], ~0ull, k);
+                    if (old == ~0ull || old == k) break;
+                }
+                h = (h + 1) & (HIST_SLOTS - 1);
+            }
+            atomicAdd(&t_cnt[h], 1u);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < HIST_SLOTS; i += HIST_THREADS) {
+            const u32 c = t_cnt[i];
+            if (c) atomicAdd(&bins[t_key[i]], c);
+        }
+        __syncthreads();
+    }
+    // number of usable sites (fasta.py:57)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) valid += __shfl_xor(valid, d, 64);
+    if ((threadIdx.x & 63) == 0 && valid) atomicAdd(n_valid, valid);
+}
+
+#define SCAN_BLOCK_ELEMS 4096  // bins per block in the count / write passes
+
+__global__ __launch_bounds__(256) void k_bins_count(const u32* __restrict__ bins, int64_t nbins,
+                                                    u32* __restrict__ block_nz) {
+    __shared__ u32 sh[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK_ELEMS;
+    u32 c = 0;
+    for (int j = 0; j < SCAN_BLOCK_ELEMS / 256 / 4; ++j) {
+        const int64_t i = base + ((int64_t)j * 256 + threadIdx.x) * 4;
+        if (i + 3 < nbins) {
+            const uint4 v = *reinterpret_cast<const uint4*>(bins + i);
+            c += (v.x != 0) + (v.y != 0) + (v.z != 0) + (v.w != 0);
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (i + e < nbins) c += bins[i + e] != 0;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_nz[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// exclusive scan of block_nz (one workgroup; nblocks up to a few million) -> offsets, total at [nblocks]
+__global__ __launch_bounds__(1024) void k_scan_blocks(const u32* __restrict__ in, int64_t nblocks,
+                                                      u64* __restrict__ out) {
+    __shared__ u64 sh[16];
+    __shared__ u64 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t base = 0; base < nblocks; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const u64 v = i < nblocks ? in[i] : 0;
+        u64 x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u64 y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) sh[w] = x;
+        __syncthreads();
+        u64 pre = carry;
+        for (int k = 0; k < w; ++k) pre += sh[k];
+        if (i < nblocks) out[i] = pre + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = pre + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[nblocks] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_bins_write(const u32* __restrict__ bins, int64_t nbins,
+                                                    const u64* __restrict__ block_off, u64* __restrict__ keys,
+                                                    u32* __restrict__ counts) {
+    __shared__ u32 sh[5];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK_ELEMS;
+    // each thread owns 16 consecutive bins -> ordered output
+    const int64_t lo = base + (int64_t)threadIdx.x * 16;
+    u32 v[16];
+    u32 c = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        v[e] = (lo + e < nbins) ? bins[lo + e] : 0;
+        c += v[e] != 0;
+    }
+    // block exclusive scan of c
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32 x = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) sh[w] = x;
+    __syncthreads();
+    u32 pre = 0;
+    for (int k = 0; k < w; ++k) pre += sh[k];
+    u64 o = block_off[blockIdx.x] + pre + x - c;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        if (v[e]) {
+            keys[o] = (u64)(lo + e);
+            counts[o] = v[e];
+            ++o;
+        }
+}
+
+__global__ void k_counts_to_weights(const u32* __restrict__ counts, int64_t D, double N, double* __restrict__ w) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D) w[i] = (double)counts[i] / N;  // counts[k] / float(L): simulation.py:54, fasta.py:66-70
+}
+
+static int build_from_device_keys(sp_ctx* ctx, const u64* dkeys, int64_t L, int n_taxa, sp_alignment** out) {
+    SP_REQUIRE(n_taxa <= 16, SP_ELIMIT,
+               "device histogram uses a direct 4^n bin array and supports n_taxa <= 16 (got %d); pass a "
+               "de-duplicated table to sp_alignment_create instead", n_taxa);
+    const int64_t nbins = pow4(n_taxa);
+    DevBuf bins, blk, off;
+    const int64_t nblocks = (nbins + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS;
+    int rc;
+    auto cleanup = [&]() {
+        bins.release();
+        blk.release();
+        off.release();
+    };
+    if ((rc = bins.ensure((size_t)nbins * 4 + 16)) || (rc = blk.ensure((size_t)nblocks * 4)) ||
+        (rc = off.ensure((size_t)(nblocks + 1) * 8))) {
+        cleanup();
+        return rc;
+    }
+    u32* n_valid = bins.as<u32>() + nbins;  // the 4 bytes after the bins
+    {
+        PhaseScope ps(ctx, SP_PHASE_HIST);
+        if (hipMemsetAsync(bins.p, 0, (size_t)nbins * 4 + 16, ctx->stream) != hipSuccess) {
+            cleanup();
+            sp_set_error("hipMemsetAsync of the bin array failed");
+            return SP_EHIP;
+        }
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((L + HIST_TILE - 1) / HIST_TILE, ctx->n_cu * 2));
+        hipLaunchKernelGGL(k_hist_lds, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, dkeys, L, bins.as<u32>(), n_valid);
+        hipLaunchKernelGGL(k_bins_count, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, bins.as<u32>(), nbins,
+                           blk.as<u32>());
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, blk.as<u32>(), nblocks, off.as<u64>());
+    }
+    u64 D64 = 0;
+    u32 N32 = 0;
+    hipError_t e = hipMemcpyAsync(&D64, off.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&N32, n_valid, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        cleanup();
+        sp_set_error("histogram failed: %s", hipGetErrorString(e));
+        return SP_EHIP;
+    }
+    const int64_t D = (int64_t)D64;
+    sp_alignment* al = new sp_alignment();
+    al->ctx = ctx;
+    al->n_taxa = n_taxa;
+    al->D = D;
+    al->N = N32;
+    al->exact = true;
+    const size_t d1 = (size_t)std::max<int64_t>(D, 1);
+    if ((rc = al->keys.ensure(d1 * 8)) || (rc = al->weights.ensure(d1 * 8)) || (rc = al->counts.ensure(d1 * 4))) {
+        cleanup();
+        sp_alignment_destroy(al);
+        return rc;
+    }
+    if (D > 0) {
+        PhaseScope ps(ctx, SP_PHASE_HIST);
+        hipLaunchKernelGGL(k_bins_write, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, bins.as<u32>(), nbins,
+                           off.as<u64>(), al->keys.as<u64>(), al->counts.as<u32>());
+        hipLaunchKernelGGL(k_counts_to_weights, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream,
+                           al->counts.as<u32>(), D, (double)N32, al->weights.as<double>());
+    }
+    e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    cleanup();
+    if (e != hipSuccess) {
+        sp_alignment_destroy(al);
+        sp_set_error("histogram compaction failed: %s", hipGetErrorString(e));
+        return SP_EHIP;
+    }
+    *out = al;
+    return SP_OK;
+}
+
+extern "C" int sp_alignment_from_site_keys(sp_ctx* ctx, const uint64_t* site_keys, int64_t L, int n_taxa,
+                                           sp_alignment** out) {
+    SP_REQUIRE(ctx && out && (site_keys || L == 0), SP_EINVAL, "NULL argument");
+    SP_REQUIRE(n_taxa >= 2 && n_taxa <= 32 && L >= 0, SP_EINVAL, "bad n_taxa / L");
+    SP_HIP(hipSetDevice(ctx->device));
+    SP_CHECK(ctx->misc.ensure((size_t)std::max<int64_t>(L, 1) * 8));
+    if (L > 0) SP_HIP(hipMemcpyAsync(ctx->misc.p, site_keys, (size_t)L * 8, hipMemcpyHostToDevice, ctx->stream));
+    return build_from_device_keys(ctx, ctx->misc.as<u64>(), L, n_taxa, out);
+}
+
+extern "C" int sp_alignment_from_sequences(sp_ctx* ctx, const uint8_t* seqs, int n_taxa, int64_t L, int64_t stride,
+                                           sp_alignment** out) {
+    SP_REQUIRE(ctx && out && (seqs || L == 0), SP_EINVAL, "NULL argument");
+    SP_REQUIRE(n_taxa >= 2 && n_taxa <= 32 && L >= 0 && stride >= L, SP_EINVAL, "bad n_taxa / L / stride");
+    SP_HIP(hipSetDevice(ctx->device));
+    SP_CHECK(ctx->misc.ensure((size_t)std::max<int64_t>(L, 1) * 8));
+    SP_CHECK(ctx->misc2.ensure((size_t)std::max<int64_t>(L, 1) * n_taxa));
+    if (L > 0) {
+        SP_HIP(hipMemcpy2DAsync(ctx->misc2.p, (size_t)L, seqs, (size_t)stride, (size_t)L, (size_t)n_taxa,
+                                hipMemcpyHostToDevice, ctx->stream));
+        PhaseScope ps(ctx, SP_PHASE_HIST);
+        hipLaunchKernelGGL(k_pack_sites, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ctx->misc2.as<uint8_t>(), n_taxa, L, L, ctx->misc.as<u64>());
+        SP_HIP(hipGetLastError());
+    }
+    return build_from_device_keys(ctx, ctx->misc.as<u64>(), L, n_taxa, out);
+}

@@ -1,0 +1,261 @@
+"""Host-side plumbing above the C ABI: per-device contexts and device-resident pattern tables.
+
+PyTorch appears here only as plumbing (current device / current stream, so that kernels
+launched by this package are ordered with torch work and with torch.distributed's RCCL
+collectives); all compute goes through libsplitp_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+from .constants import DNA_state_space_dict
+
+_contexts = {}
+
+
+class Context:
+    """One sp_ctx per (device); kernels run on torch's current stream for that device when
+    torch sees the GPU, else on a private stream."""
+
+    def __init__(self, device: int):
+        lib = _lib.load()
+        _lib.require_gpu()
+        self.device = device
+        self._lib = lib
+        self.handle = C.c_void_p()
+        _lib.check(lib.sp_ctx_create(device, self._torch_stream(device), C.byref(self.handle)))
+        self._stream = self._torch_stream(device)
+        self._fin = weakref.finalize(self, lib.sp_ctx_destroy, self.handle)
+
+    @staticmethod
+    def _torch_stream(device):
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        except Exception:
+            pass
+        return None
+
+    def sync_stream_with_torch(self):
+        s = self._torch_stream(self.device)
+        cur = None if s is None else s.value
+        old = None if self._stream is None else self._stream.value
+        if cur != old:
+            _lib.check(self._lib.sp_ctx_set_stream(self.handle, s))
+            self._stream = s
+
+    def synchronize(self):
+        _lib.check(self._lib.sp_ctx_synchronize(self.handle))
+
+    def enable_timing(self, on=True):
+        _lib.check(self._lib.sp_ctx_enable_timing(self.handle, 1 if on else 0))
+
+    def reset_timing(self):
+        _lib.check(self._lib.sp_ctx_reset_timing(self.handle))
+
+    def phase_times(self):
+        ms = (C.c_double * _lib.SP_N_PHASES)()
+        n = (C.c_int64 * _lib.SP_N_PHASES)()
+        _lib.check(self._lib.sp_ctx_phase_times(self.handle, ms, n))
+        return {name: (ms[i], n[i]) for i, name in enumerate(_lib.PHASE_NAMES)}
+
+
+def current_device():
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            return torch.cuda.current_device()
+    except Exception:
+        pass
+    return 0
+
+
+def get_context(device=None) -> Context:
+    if device is None:
+        device = current_device()
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = _contexts[device] = Context(device)
+    ctx.sync_stream_with_torch()
+    return ctx
+
+
+# ------------------------------------------------------------------------------------------
+_LUT = np.full(256, 255, dtype=np.uint8)
+for _ch, _d in DNA_state_space_dict.items():
+    _LUT[ord(_ch)] = _d
+
+
+def pack_patterns(patterns, n_taxa=None):
+    """List of pattern strings -> uint64 keys (taxon 0 = first character = most significant
+    base-4 digit, reference splitp/constructions.py:166-171).  A character outside ACGT raises
+    KeyError like the reference's DNA_state_space_dict lookup (:170)."""
+    d = len(patterns)
+    if d == 0:
+        return np.zeros(0, dtype=np.uint64), (n_taxa or 0)
+    n = len(patterns[0]) if n_taxa is None else n_taxa
+    if n > 32:
+        raise NotImplementedError("pattern keys are 64-bit: at most 32 taxa")
+    joined = "".join(str(c) for p in patterns for c in p) if not isinstance(patterns[0], str) else "".join(patterns)
+    raw = np.frombuffer(joined.encode("latin-1", errors="replace"), dtype=np.uint8)
+    if raw.size != d * n:
+        raise ValueError("all patterns must have the same length (one character per taxon)")
+    dig = _LUT[raw.reshape(d, n)]
+    if (dig == 255).any():
+        bad = raw.reshape(d, n)[dig == 255][0]
+        raise KeyError(chr(int(bad)))
+    keys = np.zeros(d, dtype=np.uint64)
+    for t in range(n):
+        keys = (keys << np.uint64(2)) | dig[:, t].astype(np.uint64)
+    return keys, n
+
+
+def infer_counts(weights):
+    """If the table is count-derived (value == count / N exactly, as produced by
+    splitp/simulation.py:54 and splitp/parsers/fasta.py:66-70) recover (counts, N); else None.
+    Any (counts, N) with counts / N == weights bit-for-bit is equivalent for this package
+    (scores are scale-invariant; matrices are returned as counts / N)."""
+    w = np.asarray(weights, dtype=np.float64)
+    if w.size == 0 or not np.isfinite(w).all() or (w < 0).any():
+        return None
+    pos = w[w > 0]
+    if pos.size == 0:
+        return None
+    wmin = float(pos.min())
+    for c in range(1, 65):
+        n = int(round(c / wmin))
+        if n <= 0 or n > (1 << 40):
+            continue
+        cnt = np.rint(w * n)
+        if cnt.max() < 2**32 and np.array_equal(cnt / float(n), w):
+            return cnt.astype(np.int64), n
+    return None
+
+
+class DeviceAlignment:
+    """A pattern table resident in HBM (sp_alignment).  It can be passed wherever the
+    reference takes `pattern_probabilities`; build it once when many splits are scored."""
+
+    def __init__(self, handle, ctx, n_taxa, taxa=None, host_table=None):
+        self.handle = handle
+        self.ctx = ctx
+        self.n_taxa = n_taxa
+        if taxa is not None:
+            self.taxa = tuple(taxa)
+        self._host = host_table
+        self._fin = weakref.finalize(self, ctx._lib.sp_alignment_destroy, handle)
+
+    # -- constructors ---------------------------------------------------------------------
+    @classmethod
+    def from_table(cls, table, taxa=None, device=None, exact="auto"):
+        """table: mapping pattern string -> value (the reference's `pattern_probabilities`)."""
+        ctx = get_context(device)
+        patterns = list(table.keys())
+        vals = np.fromiter((float(v) for v in table.values()), dtype=np.float64, count=len(patterns))
+        keys, n = pack_patterns(patterns)
+        if taxa is None:
+            taxa = getattr(table, "taxa", None)
+        return cls.from_arrays(keys, vals, n, taxa=taxa, ctx=ctx, exact=exact)
+
+    @classmethod
+    def from_arrays(cls, keys, weights, n_taxa, counts=None, n_sites=None, taxa=None, ctx=None, device=None,
+                    exact="auto"):
+        ctx = ctx or get_context(device)
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        if counts is None and exact in ("auto", True) and w is not None:
+            inf = infer_counts(w)
+            if inf is not None:
+                counts, n_sites = inf
+            elif exact is True:
+                raise ValueError("table values are not count / N for any integer N")
+        cnt = None if counts is None else np.ascontiguousarray(counts, dtype=np.int64)
+        if cnt is not None and n_sites is None:
+            n_sites = int(cnt.sum())
+        h = C.c_void_p()
+        _lib.check(ctx._lib.sp_alignment_create(
+            ctx.handle, _lib._ptr(keys, C.c_uint64), _lib._ptr(w, C.c_double), _lib._ptr(cnt, C.c_int64),
+            len(keys), int(n_taxa), int(n_sites or 0), C.byref(h)))
+        return cls(h, ctx, int(n_taxa), taxa)
+
+    @classmethod
+    def from_sequences(cls, seqs, taxa=None, device=None):
+        """seqs: (n_taxa, L) uint8 ASCII array or list of equal-length strings (FASTA rows).
+        The site-pattern histogram runs on the device (reference splitp/parsers/fasta.py:48-63)."""
+        ctx = get_context(device)
+        if not isinstance(seqs, np.ndarray):
+            seqs = np.stack([np.frombuffer(s.encode("latin-1"), dtype=np.uint8) for s in seqs])
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        n, length = seqs.shape
+        h = C.c_void_p()
+        _lib.check(ctx._lib.sp_alignment_from_sequences(ctx.handle, _lib._ptr(seqs, C.c_uint8), n, length, length,
+                                                        C.byref(h)))
+        return cls(h, ctx, n, taxa)
+
+    @classmethod
+    def from_site_keys(cls, site_keys, n_taxa, taxa=None, device=None):
+        ctx = get_context(device)
+        k = np.ascontiguousarray(site_keys, dtype=np.uint64)
+        h = C.c_void_p()
+        _lib.check(ctx._lib.sp_alignment_from_site_keys(ctx.handle, _lib._ptr(k, C.c_uint64), len(k), int(n_taxa),
+                                                        C.byref(h)))
+        return cls(h, ctx, int(n_taxa), taxa)
+
+    # -- queries --------------------------------------------------------------------------
+    def info(self):
+        d, n, big_n, ex = C.c_int64(), C.c_int(), C.c_int64(), C.c_int()
+        _lib.check(self.ctx._lib.sp_alignment_info(self.handle, C.byref(d), C.byref(n), C.byref(big_n), C.byref(ex)))
+        return {"D": d.value, "n_taxa": n.value, "N": big_n.value, "exact": bool(ex.value)}
+
+    def __len__(self):
+        return self.info()["D"]
+
+    def fetch(self):
+        """(keys, weights, counts or None) copied back from the device."""
+        inf = self.info()
+        keys = np.empty(inf["D"], dtype=np.uint64)
+        w = np.empty(inf["D"], dtype=np.float64)
+        cnt = np.empty(inf["D"], dtype=np.int64) if inf["exact"] else None
+        _lib.check(self.ctx._lib.sp_alignment_fetch(self.handle, _lib._ptr(keys, C.c_uint64), _lib._ptr(w, C.c_double),
+                                                    _lib._ptr(cnt, C.c_int64)))
+        return keys, w, cnt
+
+    def items(self):
+        """dict-like view (pattern string -> value), so generic code can still iterate it."""
+        keys, w, _ = self.fetch()
+        n = self.n_taxa
+        for k, v in zip(keys.tolist(), w.tolist()):
+            yield "".join("ACGT"[(k >> (2 * (n - 1 - t))) & 3] for t in range(n)), v
+
+
+def as_device_alignment(table, device=None):
+    if isinstance(table, DeviceAlignment):
+        table.ctx.sync_stream_with_torch()
+        return table
+    return DeviceAlignment.from_table(table, device=device)
+
+
+def normalise_split(split):
+    """reference: constructions.py:19-20 - a string "01|23" becomes ["01", "23"]."""
+    if isinstance(split, str):
+        split = split.split("|")
+    return split
+
+
+def resolve_split(split, table, n_taxa):
+    """(order_a, order_b) int32 arrays of taxon indices in the order the split lists them.
+    taxa = table.taxa if present, else sorted(union of the halves) (constructions.py:21-24)."""
+    split = normalise_split(split)
+    taxa = getattr(table, "taxa", None)
+    if taxa is None:
+        taxa = sorted(set.union(*map(set, split)))
+    where = {t: i for i, t in enumerate(taxa)}
+    oa = np.array([where[s] for s in split[0]], dtype=np.int32)  # KeyError for an unknown taxon, like the reference
+    ob = np.array([where[s] for s in split[1]], dtype=np.int32)
+    return oa, ob

@@ -1,0 +1,272 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden vectors.
+
+Bars: flattening values / indices / integer counts bit-exact; subflattening
+integer moments exact and value / N within 1e-13 of the matrix scale; fp64 scores within 1e-10
+absolute (all golden scores are >= 1e-3), score^2 within 1e-13 for degenerate inputs."""
+import numpy as np
+import pytest
+import scipy.sparse
+
+from oracle import splitp_oracle as O
+from tests.conftest import mask_to_split, taxa_names
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-10
+
+REF4_SPLITS = [({0, 1}, {2, 3}), ({0, 2}, {1, 3}), ({0, 3}, {1, 2})]
+REF4_TABLE = {"ATCG": 2 / 5, "GATC": 1 / 5, "CGAT": 1 / 5, "TCGA": 1 / 5}
+
+
+@pytest.fixture(scope="module")
+def sp():
+    import splitp_amd
+
+    splitp_amd._lib.require_gpu()
+    return splitp_amd
+
+
+def test_native_library_is_loaded(sp):
+    # the product path is the in-tree .so, nothing else
+    import os
+
+    assert os.path.exists(sp._lib.LIB_PATH)
+    assert sp._lib.device_count() >= 1
+    with open("/proc/self/maps") as f:
+        assert "libsplitp_hip.so" in f.read()
+
+
+# ---------------------------------------------------------------- the reference's own tests, restated
+def test_flattening_reference_vectors(sp):
+    F = np.zeros((16, 16))
+    F[3, 6] = .4; F[6, 3] = .2; F[8, 13] = .2; F[13, 8] = .2
+    got = sp.flattening(REF4_SPLITS[0], REF4_TABLE)
+    assert scipy.sparse.issparse(got) and got.shape == (16, 16) and got.dtype == np.float64
+    np.testing.assert_array_equal(got.todense(), F)
+    F = np.zeros((16, 16))
+    F[1, 14] = .4; F[4, 11] = .2; F[11, 1] = .2; F[14, 4] = .2
+    np.testing.assert_array_equal(sp.flattening(REF4_SPLITS[1], REF4_TABLE).todense(), F)
+
+
+def test_reduced_flattening_reference_vectors(sp):
+    F = np.array([[0, .4, 0, 0], [.2, 0, 0, 0], [0, 0, 0, .2], [0, 0, .2, 0]])
+    np.testing.assert_array_equal(sp.flattening(REF4_SPLITS[0], REF4_TABLE, flattening_format=sp.FlatFormat.reduced), F)
+    F = np.array([[0, 0, 0, .4], [0, 0, .2, 0], [.2, 0, 0, 0], [0, .2, 0, 0]])
+    np.testing.assert_array_equal(sp.flattening(REF4_SPLITS[1], REF4_TABLE, flattening_format=sp.FlatFormat.reduced), F)
+
+
+def test_subflattening_reference_identity(sp):
+    sel = [3, 7, 11, 12, 13, 14, 15]
+    S = np.array([[1, -1], [1, 1]])
+    S0 = np.kron(S, S)
+    S = np.kron(S0, S0)
+    for split in REF4_SPLITS:
+        F = np.asarray(sp.flattening(split, REF4_TABLE).todense())
+        want = (S @ F @ S.T)[np.ix_(sel, sel)]
+        np.testing.assert_allclose(sp.subflattening(split, REF4_TABLE), want, rtol=1e-15, atol=1e-15)
+
+
+def test_ref4_golden_and_split_forms(sp, golden):
+    g = golden("ref4")
+    for i, s in enumerate(REF4_SPLITS):
+        np.testing.assert_array_equal(np.asarray(sp.flattening(s, REF4_TABLE).todense()), g[f"sparse_{i}"])
+        np.testing.assert_array_equal(sp.flattening(s, REF4_TABLE, sp.FlatFormat.reduced), g[f"reduced_{i}"])
+        np.testing.assert_allclose(sp.subflattening(s, REF4_TABLE), g[f"subflat_{i}"], rtol=0, atol=1e-15)
+        assert sp.split_score(sp.subflattening(s, REF4_TABLE)) ** 2 <= 1e-13   # 7 x 7 of rank 4: degenerate, compare score^2
+        assert sp.split_score(sp.flattening(s, REF4_TABLE, sp.FlatFormat.reduced)) == 0.0  # 4 x 4
+    # string split, taxa listed in a non-sorted order inside each half
+    np.testing.assert_array_equal(np.asarray(sp.flattening("10|32", REF4_TABLE).todense()), g["sparse_str"])
+    np.testing.assert_array_equal(sp.flattening("10|32", REF4_TABLE, sp.FlatFormat.reduced), g["reduced_str"])
+    np.testing.assert_allclose(sp.subflattening("10|32", REF4_TABLE), g["subflat_str"], rtol=0, atol=1e-15)
+    assert sp.flattening("10|32", REF4_TABLE, "something else") is None
+    with pytest.raises(KeyError):
+        sp.flattening("10|32", {"ATCG": 0.5, "ATCN": 0.5})          # character outside ACGT
+    with pytest.raises(KeyError):
+        dev4 = sp.DeviceAlignment.from_table(REF4_TABLE, taxa=("0", "1", "2", "3"))
+        sp.flattening("10|39", dev4)                                # unknown taxon (table carries .taxa)
+    data = {}
+    sp.subflattening(REF4_SPLITS[0], REF4_TABLE, data)
+    assert set(data) == {"coeffs", "labels"} and data["labels"][2][-1] == "TT"
+
+
+# ---------------------------------------------------------------- 10 taxa
+def _n10(golden, name):
+    g = golden(name)
+    names = taxa_names(10)
+    splits = [mask_to_split(int(m), 10, names) for m in g["masks"]]
+    table = O.unpack_table(g["keys"], g["probs"], 10)
+    return g, names, splits, table
+
+
+@pytest.mark.parametrize("name", ["n10_L10k", "n10_L100k"])
+def test_n10_api_matrices_bit_exact(sp, golden, name):
+    g, names, splits, table = _n10(golden, name)
+    dev = sp.DeviceAlignment.from_table(table, taxa=names)
+    assert dev.info()["exact"] and dev.info()["N"] in (int(g["L"]), int(g["L"]) // 2, int(g["L"]) // 4)
+    for i in g["full_ids"]:
+        want = g[f"reduced_{i}"]
+        got = sp.flattening(splits[i], dev, sp.FlatFormat.reduced)
+        assert got.dtype == np.float64 and got.shape == want.shape
+        np.testing.assert_array_equal(got, want)                         # bit-exact vs the reference
+        got2 = sp.flattening(splits[i], table, sp.FlatFormat.reduced)    # plain dict input
+        np.testing.assert_array_equal(got2, want)
+        assert abs(sp.split_score(got) - g["scores"][i]) <= SCORE_TOL
+    # sparse format against the reference's stored triplets
+    i0 = int(g["sparse_ids"][0])
+    S = sp.flattening(splits[i0], dev)
+    want = scipy.sparse.coo_matrix((g["sparse0_vals"], (g["sparse0_rows"], g["sparse0_cols"])),
+                                   shape=tuple(g["sparse0_shape"]))
+    assert S.shape == want.shape and (abs(S.tocoo() - want)).nnz == 0
+    for j, i in enumerate(g["sparse_ids"][:3]):
+        assert abs(sp.split_score(sp.flattening(splits[int(i)], dev)) - g["sparse_scores"][j]) <= SCORE_TOL
+    # subflattening
+    big_n = int(g["L"])
+    for i in g["sub_ids"]:
+        want = g[f"subflat_{i}"]
+        got = sp.subflattening(splits[i], dev)
+        assert np.array_equal(np.rint(got * big_n), np.rint(want * big_n))
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=5e-14)
+        assert abs(sp.split_score(got) - g[f"subscore_{i}"]) <= SCORE_TOL
+
+
+@pytest.mark.parametrize("name", ["n10_L10k", "n10_L100k"])
+def test_n10_batched_scores_all_501(sp, golden, name):
+    g, names, splits, table = _n10(golden, name)
+    dev = sp.DeviceAlignment.from_table(table, taxa=names)
+    scores, status = sp.score_splits(dev, splits, return_status=True)
+    assert scores.shape == (501,)
+    assert np.all((status & 1) == 0), "eigen iteration hit its cap"
+    err = np.abs(scores - g["scores"])
+    assert err.max() <= SCORE_TOL, (err.max(), int(err.argmax()))
+    # weights-only (fp64 Gram, non-exact) route must agree too
+    dev_w = sp.DeviceAlignment.from_arrays(g["keys"], g["probs"], 10, taxa=names, exact=False)
+    assert not dev_w.info()["exact"]
+    s_w = sp.score_splits(dev_w, splits)
+    assert np.abs(s_w - g["scores"]).max() <= SCORE_TOL
+    # subflattening method, batched, against per-split reference values
+    sub = sp.score_splits(dev, [splits[int(i)] for i in g["sub_ids"]], method=sp.Method.subflattening)
+    want = np.array([g[f"subscore_{int(i)}"] for i in g["sub_ids"]])
+    assert np.abs(sub - want).max() <= SCORE_TOL
+
+
+def test_dense_counts_bit_exact(sp, golden):
+    g, names, splits, table = _n10(golden, "n10_L100k")
+    dev = sp.DeviceAlignment.from_table(table, taxa=names)
+    import ctypes as C
+    big_n = dev.info()["N"]
+    counts = np.rint(g["probs"] * big_n).astype(np.int64)
+    for i in (0, 100, 300, 500):
+        oa = np.array([names.index(t) for t in splits[i][0]], dtype=np.int32)
+        ob = np.array([names.index(t) for t in splits[i][1]], dtype=np.int32)
+        out = np.empty(4 ** 10, dtype=np.uint32)
+        sp._lib.check(dev.ctx._lib.sp_flatten_dense_counts(
+            dev.handle, oa.ctypes.data_as(C.POINTER(C.c_int32)), len(oa), ob.ctypes.data_as(C.POINTER(C.c_int32)),
+            len(ob), out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        want = O.dense_flattening_packed(g["keys"], counts, 10, oa, ob)
+        assert np.array_equal(out.reshape(want.shape), want.astype(np.uint32))
+        assert out.sum() == big_n
+
+
+def test_n16_subflattening(sp, golden):
+    g = golden("n16_L4k")
+    names = [str(x) for x in g["taxa"]]
+    table = O.unpack_table(g["keys"], g["probs"], 16)
+    dev = sp.DeviceAlignment.from_table(table, taxa=names)
+    big_n = int(g["L"])
+    splits, want_scores = [], []
+    for i in range(int(g["n_splits"])):
+        oa, ob = g[f"orderA_{i}"], g[f"orderB_{i}"]
+        split = (tuple(names[t] for t in oa), tuple(names[t] for t in ob))
+        got = sp.subflattening(split, dev)
+        want = g[f"subflat_{i}"]
+        assert np.array_equal(np.rint(got * big_n), np.rint(want * big_n))
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=5e-14)
+        splits.append(split)
+        want_scores.append(float(g[f"subscore_{i}"]))
+    got = sp.score_splits(dev, splits, method=sp.Method.subflattening)
+    assert np.abs(got - np.array(want_scores)).max() <= SCORE_TOL
+
+
+def test_degenerate_and_generic_matrices(sp, golden):
+    g = golden("degenerate")
+    for k in ("generic", "realvalued"):
+        assert abs(sp.split_score(g[k]) - g[k + "_score"]) <= SCORE_TOL
+        assert abs(sp.split_score(g[k].T.copy()) - g[k + "_score"]) <= SCORE_TOL
+    assert sp.split_score(g["thin3"]) == 0.0
+    r = sp.split_score(g["rank4"])          # reference: ~0 or nan (no clamp); here clamped
+    assert r * r <= 1e-13
+    assert np.isnan(sp.split_score(np.zeros((6, 9))))
+    S = scipy.sparse.coo_matrix((g["sp_vals"], (g["sp_rows"], g["sp_cols"])), shape=tuple(g["sp_shape"])).todok()
+    assert abs(sp.split_score(S) - g["sp_score"]) <= SCORE_TOL
+    assert isinstance(sp.split_score(S), float)
+    # randomised differential test against the oracle, ragged shapes incl. min(shape) in {5, 16, 17, 63, 65}
+    rng = np.random.default_rng(11)
+    for shape in [(5, 40), (40, 5), (16, 16), (17, 300), (63, 64), (65, 130), (200, 31), (257, 300)]:
+        M = rng.integers(0, 7, size=shape).astype(np.float64)
+        assert abs(sp.split_score(M) - O.dense_split_score(M)) <= SCORE_TOL, shape
+    # hard spectrum (no gap after the 4th singular value): slow convergence must still be correct
+    M = rng.standard_normal((120, 400))
+    assert abs(sp.split_score(M) - O.dense_split_score(M)) <= 1e-9
+
+
+def test_histogram_from_sequences(sp):
+    from splitp_amd import synthetic as syn
+
+    sites = syn.simulate_sites(10, 20000, 0.05, seed=3)
+    keys, counts = syn.pattern_table(sites)
+    seqs = syn.sequences_ascii(sites)
+    # sprinkle invalid characters: those sites must be dropped (fasta.py:54-57), lower case accepted
+    seqs = seqs.copy()
+    seqs[3, 10] = ord("N"); seqs[0, 11] = ord("-"); seqs[5, 12] = ord("a") if seqs[5, 12] == ord("A") else seqs[5, 12]
+    valid = np.ones(20000, dtype=bool); valid[[10, 11]] = False
+    k2, c2 = syn.pattern_table(sites[valid])
+    dev = sp.DeviceAlignment.from_sequences(seqs)
+    gk, gw, gc = dev.fetch()
+    assert dev.info()["N"] == int(valid.sum())
+    assert np.array_equal(gk, k2) and np.array_equal(gc, c2)
+    assert np.array_equal(gw, c2 / float(valid.sum()))
+    dev2 = sp.DeviceAlignment.from_site_keys(syn.site_keys(sites), 10)
+    gk, gw, gc = dev2.fetch()
+    assert np.array_equal(gk, keys) and np.array_equal(gc, counts)
+    # reference's FASTA test fixture (tests/test_files/test_alignment_1.fa + tests/test_parsers.py:16-25)
+    dev3 = sp.DeviceAlignment.from_sequences(["AAGCT", "TTAGC", "CCTAG", "GGCTA"])
+    assert dict(dev3.items()) == {"ATCG": 2 / 5, "CGAT": 1 / 5, "GATC": 1 / 5, "TCGA": 1 / 5}
+
+
+def test_full_size_properties(sp):
+    """BASELINE config 2 size (10 taxa, 100k bp, all 501 splits) on a fresh synthetic alignment:
+    size-independent properties instead of a stored answer."""
+    from splitp_amd import synthetic as syn
+
+    sites = syn.simulate_sites(10, 100_000, 0.05, seed=21)
+    keys, counts = syn.pattern_table(sites)
+    names = taxa_names(10)
+    dev = sp.DeviceAlignment.from_arrays(keys, None, 10, counts=counts, n_sites=100_000, taxa=names)
+    splits = list(sp.all_splits(names))
+    s1 = sp.score_splits(dev, splits)
+    # (1) run-to-run bitwise reproducibility (integer Gram, fixed reduction orders)
+    s2 = sp.score_splits(dev, splits)
+    assert np.array_equal(s1, s2)
+    # (2) side swap: score(A|B) == score(B|A) (transpose has the same singular values)
+    swapped = [(b, a) for a, b in splits]
+    s3 = sp.score_splits(dev, swapped)
+    assert np.abs(s1 - s3).max() <= 1e-12
+    # (3) taxon order inside a half only permutes rows/cols
+    perm = [(tuple(reversed(a)), b) for a, b in splits]
+    s4 = sp.score_splits(dev, perm)
+    assert np.abs(s1 - s4).max() <= 1e-12
+    # (4) the tree's true splits score lowest
+    tree = syn.tree_splits(syn.balanced_tree(10), 10)
+    is_true = np.array([frozenset(names.index(t) for t in a) in tree or frozenset(names.index(t) for t in b) in tree
+                        for a, b in splits])
+    assert is_true.sum() == 7 and s1[is_true].max() < s1[~is_true].min()
+    # (5) scale invariance: doubling every count leaves the scores unchanged
+    dev2 = sp.DeviceAlignment.from_arrays(keys, None, 10, counts=2 * counts, n_sites=200_000, taxa=names)
+    s5 = sp.score_splits(dev2, splits)
+    assert np.abs(s1 - s5).max() <= 1e-13
+    # (6) oracle spot checks at full size
+    for i in (0, 77, 250, 480):
+        oa = [names.index(t) for t in splits[i][0]]
+        ob = [names.index(t) for t in splits[i][1]]
+        M = O.reduced_flattening_packed(keys, counts / 100_000.0, 10, oa, ob)[0]
+        assert abs(O.dense_split_score(M) - s1[i]) <= SCORE_TOL

@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the real reference (js51/SplitP).
+
+Runs ONLY in the build container, where the reference is mounted read-only at
+/root/reference.  It imports the reference's `splitp` package (pure Python) and
+writes *data only* (inputs + expected outputs) as small .npz fixtures under
+tests/golden/.  Nothing of the reference's source text is stored.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_goldens.py [--only NAME]
+
+The fixtures pin the oracle (oracle/splitp_oracle.py) and, through it, the HIP
+path.  The GPU box never runs this script (no /root/reference there).
+"""
+import argparse
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+REF = os.environ.get("SPLITP_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+STATE = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+
+def pack(table):
+    """dict pattern->prob  ->  (keys uint64 [taxon 0 most significant], probs f64), dict order kept."""
+    keys = np.empty(len(table), dtype=np.uint64)
+    probs = np.empty(len(table), dtype=np.float64)
+    for i, (p, v) in enumerate(table.items()):
+        k = 0
+        for ch in p:
+            k = k * 4 + STATE[ch]
+        keys[i] = k
+        probs[i] = v
+    return keys, probs
+
+
+def split_to_orders(split, taxa):
+    idx = {t: i for i, t in enumerate(taxa)}
+    return (np.array([idx[t] for t in split[0]], dtype=np.int32),
+            np.array([idx[t] for t in split[1]], dtype=np.int32))
+
+
+def left_mask(split, taxa):
+    idx = {t: i for i, t in enumerate(taxa)}
+    m = 0
+    for t in split[0]:
+        m |= 1 << idx[t]
+    return m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    if not os.path.isdir(REF):
+        print("reference not present; nothing to do")
+        return 0
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    import splitp  # the REAL reference
+    from splitp.constructions import flattening, subflattening
+    from splitp.phylogenetics import split_score
+    from splitp.enums import FlatFormat
+    import scipy, networkx
+    os.makedirs(OUT, exist_ok=True)
+    versions = f"numpy {np.__version__} scipy {scipy.__version__} networkx {networkx.__version__} splitp {open(os.path.join(REF, 'VERSION')).read().strip()}"
+
+    def want(name):
+        return args.only is None or args.only == name
+
+    # ------------------------------------------------------------------ 4 taxa
+    if want("ref4"):
+        table = {"ATCG": 2 / 5, "GATC": 1 / 5, "CGAT": 1 / 5, "TCGA": 1 / 5}
+        splits = [({0, 1}, {2, 3}), ({0, 2}, {1, 3}), ({0, 3}, {1, 2})]
+        keys, probs = pack(table)
+        out = dict(keys=keys, probs=probs, n_taxa=4, versions=versions)
+        for i, s in enumerate(splits):
+            out[f"sparse_{i}"] = np.asarray(flattening(s, table).todense())
+            out[f"reduced_{i}"] = flattening(s, table, FlatFormat.reduced)
+            out[f"subflat_{i}"] = subflattening(s, table)
+            out[f"orderA_{i}"] = np.array(list(s[0]), dtype=np.int32)   # iteration order of the set
+            out[f"orderB_{i}"] = np.array(list(s[1]), dtype=np.int32)
+            out[f"score_sub_{i}"] = split_score(out[f"subflat_{i}"])
+            out[f"score_red_{i}"] = split_score(out[f"reduced_{i}"])   # 4x4, rank<=4 -> 0 or nan
+        # string-form split and a non-sorted taxon order inside a half
+        out["sparse_str"] = np.asarray(flattening("10|32", table).todense())
+        out["reduced_str"] = flattening("10|32", table, FlatFormat.reduced)
+        # subflattening("10|32", plain dict) raises KeyError in the reference (the '|' is counted as a
+        # taxon, constructions.py:114-117); it works when the table carries .taxa:
+        from splitp.alignment import Alignment
+        out["subflat_str"] = subflattening("10|32", Alignment(dict(table), taxa=("0", "1", "2", "3")))
+        np.savez_compressed(os.path.join(OUT, "ref4.npz"), **out)
+        print("ref4 done")
+
+    # ------------------------------------------------------- 10 taxa alignments
+    def do_n10(name, L, seed, n_full, n_sparse, n_sub):
+        t0 = time.time()
+        random.seed(seed)
+        np.random.seed(seed)
+        tree = splitp.trees.balanced_newick_tree(10, 0.05)
+        model = splitp.model.GTR.JukesCantor(1 / 2)
+        table = splitp.generate_alignment(tree, model, L)
+        t_gen = time.time() - t0
+        taxa = tree.taxa
+        splits = list(splitp.all_splits(tree))
+        true_splits = set()
+        for s in tree.splits():
+            true_splits.add(frozenset(s[0])); true_splits.add(frozenset(s[1]))
+        keys, probs = pack(table)
+        masks = np.array([left_mask(s, taxa) for s in splits], dtype=np.uint32)
+        is_true = np.array([frozenset(s[0]) in true_splits for s in splits], dtype=bool)
+        scores = np.empty(len(splits)); shapes = np.empty((len(splits), 2), dtype=np.int32)
+        t_flat = t_svd = 0.0
+        out = dict(keys=keys, probs=probs, n_taxa=10, L=L, seed=seed, masks=masks, is_true=is_true,
+                   taxa=np.array(list(taxa)), versions=versions)
+        full_ids = []
+        for k in (2, 3, 4, 5):
+            ids = [i for i, s in enumerate(splits) if len(s[0]) == k or len(s[1]) == k and len(s[0]) > len(s[1])]
+            ids = [i for i, s in enumerate(splits) if min(len(s[0]), len(s[1])) == k]
+            full_ids += ids[:: max(1, len(ids) // n_full)][:n_full]
+        for i, s in enumerate(splits):
+            t1 = time.time()
+            F = flattening(s, table, FlatFormat.reduced)
+            t2 = time.time()
+            scores[i] = split_score(F)
+            t3 = time.time()
+            t_flat += t2 - t1; t_svd += t3 - t2
+            shapes[i] = F.shape
+            if i in full_ids:
+                out[f"reduced_{i}"] = F
+        out["scores"] = scores; out["shapes"] = shapes; out["full_ids"] = np.array(full_ids)
+        # sparse (default) path on a sample
+        sp_ids = list(range(0, len(splits), max(1, len(splits) // n_sparse)))[:n_sparse]
+        sp_scores = []
+        for i in sp_ids:
+            Fs = flattening(splits[i], table)
+            sp_scores.append(split_score(Fs))
+            if i == sp_ids[0]:
+                coo = Fs.tocoo()
+                out["sparse0_rows"] = coo.row; out["sparse0_cols"] = coo.col; out["sparse0_vals"] = coo.data
+                out["sparse0_shape"] = np.array(Fs.shape)
+        out["sparse_ids"] = np.array(sp_ids); out["sparse_scores"] = np.array(sp_scores)
+        # subflattenings on a sample
+        sub_ids = []
+        for k in (2, 3, 4, 5):
+            ids = [i for i, s in enumerate(splits) if min(len(s[0]), len(s[1])) == k]
+            sub_ids += ids[:: max(1, len(ids) // n_sub)][:n_sub]
+        data = {}
+        for i in sub_ids:
+            S = subflattening(splits[i], table, data)
+            out[f"subflat_{i}"] = S
+            out[f"subscore_{i}"] = split_score(S)
+        out["sub_ids"] = np.array(sub_ids)
+        out["timing"] = np.array([t_gen, t_flat, t_svd])
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+        print(f"{name}: D={len(table)} gen {t_gen:.1f}s flat {t_flat:.1f}s svd {t_svd:.1f}s "
+              f"-> {len(splits)/(t_flat+t_svd):.2f} splits/s")
+
+    if want("n10_L10k"):
+        do_n10("n10_L10k", 10_000, 0, n_full=1, n_sparse=8, n_sub=2)
+    if want("n10_L100k"):
+        do_n10("n10_L100k", 100_000, 12345, n_full=1, n_sparse=4, n_sub=1)
+
+    # --------------------------------------------------- 16 taxa subflattening
+    if want("n16_L4k"):
+        random.seed(7)
+        tree = splitp.trees.balanced_newick_tree(16, 0.05)
+        model = splitp.model.GTR.JukesCantor(1 / 2)
+        table = splitp.generate_alignment(tree, model, 4000)
+        taxa = tree.taxa
+        keys, probs = pack(table)
+        out = dict(keys=keys, probs=probs, n_taxa=16, L=4000, versions=versions, taxa=np.array(list(taxa)))
+        import itertools
+        gen = splitp.all_splits(tree)
+        splits = []
+        for size in (2, 5, 8):
+            g = splitp.all_splits(tree, size=size)
+            ss = list(itertools.islice(g, 0, 4000, 1333))
+            splits += ss
+        # plus the true splits of the tree (non-trivial)
+        for s in tree.splits():
+            if min(len(s[0]), len(s[1])) >= 2:
+                splits.append((tuple(sorted(s[0], key=taxa.index)), tuple(sorted(s[1], key=taxa.index))))
+                if len(splits) >= 14:
+                    break
+        data = {}
+        for i, s in enumerate(splits):
+            oa, ob = split_to_orders(s, taxa)
+            out[f"orderA_{i}"] = oa; out[f"orderB_{i}"] = ob
+            S = subflattening(s, table, data)
+            out[f"subflat_{i}"] = S
+            out[f"subscore_{i}"] = split_score(S)
+        out["n_splits"] = len(splits)
+        np.savez_compressed(os.path.join(OUT, "n16_L4k.npz"), **out)
+        print("n16_L4k done, D =", len(table), "splits", len(splits))
+
+    # --------------------------------------------------------- degenerate cases
+    if want("degenerate"):
+        out = dict(versions=versions)
+        rng = np.random.default_rng(5)
+        # rank<=4 dense matrix: reference dense path gives ~0 (or nan when rounding goes negative)
+        A = rng.integers(0, 50, size=(12, 4)).astype(float); B = rng.integers(0, 50, size=(4, 30)).astype(float)
+        M = A @ B
+        out["rank4"] = M
+        with np.errstate(invalid="ignore"):
+            out["rank4_score"] = split_score(M)
+        M2 = rng.integers(0, 20, size=(3, 40)).astype(float)      # min(shape) < 4
+        out["thin3"] = M2; out["thin3_score"] = split_score(M2)
+        M3 = rng.integers(0, 9, size=(40, 25)).astype(float)      # generic full rank
+        out["generic"] = M3; out["generic_score"] = split_score(M3)
+        M4 = rng.random((33, 70))                                 # non-integer entries
+        out["realvalued"] = M4; out["realvalued_score"] = split_score(M4)
+        # sparse path on a generic sparse matrix
+        from scipy.sparse import dok_matrix
+        S = dok_matrix((64, 256))
+        for _ in range(600):
+            S[rng.integers(0, 64), rng.integers(0, 256)] = float(rng.integers(1, 30))
+        coo = S.tocoo()
+        out["sp_rows"] = coo.row; out["sp_cols"] = coo.col; out["sp_vals"] = coo.data; out["sp_shape"] = np.array(S.shape)
+        out["sp_score"] = split_score(S)
+        np.savez_compressed(os.path.join(OUT, "degenerate.npz"), **out)
+        print("degenerate done")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
