@@ -128,8 +128,9 @@ extern "C" int sp_ctx_destroy(sp_ctx* c) {
             (void)hipEventDestroy(pr.second);
         }
     for (auto e : c->timer.pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->splits, &c->bitmaps, &c->coords, &c->dims,   &c->mats, &c->grams,
-                      &c->eigws,  &c->scores,  &c->status, &c->misc,   &c->misc2};
+    DevBuf* bufs[] = {&c->splits, &c->bitmaps, &c->coords, &c->dims, &c->mats,  &c->grams,
+                      &c->eigws,  &c->scores,  &c->status, &c->misc, &c->misc2, &c->gram_items};
+    delete c->cache;
     for (auto* b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -285,11 +286,6 @@ static int check_split(int n, const int32_t* oa, int a, const int32_t* ob, int b
     return SP_OK;
 }
 
-struct Plan {
-    std::vector<SplitDev> splits;
-    size_t bm_words = 0, pf_words = 0, mat_elems = 0, g_elems = 0;
-};
-
 // rows_first_small: orient every split so that the smaller side indexes the rows (scoring).
 static int plan_splits(int n, int64_t D, const int32_t* split_taxa, const int32_t* split_a, int64_t S,
                        bool small_rows, bool want_mats, bool want_gram, Plan& plan) {
@@ -329,16 +325,23 @@ static int plan_splits(int n, int64_t D, const int32_t* split_taxa, const int32_
             plan.g_elems += (size_t)sd.rcap * sd.rcap;
         }
     }
+    if (want_gram) build_gram_items(plan);
     return SP_OK;
 }
 
 static int upload_plan(sp_ctx* ctx, const Plan& plan, int64_t D) {
     const size_t S = plan.splits.size();
+    if (ctx->cache) ctx->cache->valid = false;  // the device copy of any cached plan is overwritten
     SP_CHECK(ctx->splits.ensure(S * sizeof(SplitDev)));
     SP_CHECK(ctx->bitmaps.ensure(plan.bm_words * 8 + plan.pf_words * 4 + 64));
     SP_CHECK(ctx->coords.ensure(S * (size_t)std::max<int64_t>(D, 1) * 8));
     SP_CHECK(ctx->dims.ensure(S * sizeof(int2)));
     SP_HIP(hipMemcpyAsync(ctx->splits.p, plan.splits.data(), S * sizeof(SplitDev), hipMemcpyHostToDevice, ctx->stream));
+    if (!plan.gram_items.empty()) {
+        SP_CHECK(ctx->gram_items.ensure(plan.gram_items.size() * sizeof(GramItem)));
+        SP_HIP(hipMemcpyAsync(ctx->gram_items.p, plan.gram_items.data(), plan.gram_items.size() * sizeof(GramItem),
+                              hipMemcpyHostToDevice, ctx->stream));
+    }
     return SP_OK;
 }
 
@@ -363,6 +366,7 @@ extern "C" int sp_flatten_indices(sp_alignment* al, const int32_t* oa, int a, co
     for (int i = 0; i < b; ++i) sd.taxa[a + i] = (int8_t)ob[i];
     SP_CHECK(ctx->splits.ensure(sizeof(SplitDev)));
     SP_CHECK(ctx->misc.ensure((size_t)al->D * 16));
+    if (ctx->cache) ctx->cache->valid = false;
     SP_HIP(hipMemcpyAsync(ctx->splits.p, &sd, sizeof(sd), hipMemcpyHostToDevice, ctx->stream));
     int64_t* drows = ctx->misc.as<int64_t>();
     int64_t* dcols = drows + al->D;
@@ -456,6 +460,7 @@ extern "C" int sp_flatten_dense_counts(sp_alignment* al, const int32_t* oa, int 
     const int64_t cells = pow4(al->n_taxa);
     SP_CHECK(ctx->splits.ensure(sizeof(SplitDev)));
     SP_CHECK(ctx->mats.ensure((size_t)cells * 4));
+    if (ctx->cache) ctx->cache->valid = false;
     SP_HIP(hipMemcpyAsync(ctx->splits.p, &sd, sizeof(sd), hipMemcpyHostToDevice, ctx->stream));
     SP_CHECK(launch_dense_scatter(ctx, al->keys.as<u64>(), al->counts.as<u32>(), al->D, al->n_taxa,
                                   ctx->splits.as<SplitDev>(), sd, ctx->mats.as<u32>()));
@@ -465,11 +470,11 @@ extern "C" int sp_flatten_dense_counts(sp_alignment* al, const int32_t* oa, int 
 }
 
 // ------------------------------------------------------------------ scoring --------------------
-static int run_dense_route(sp_alignment* al, const Plan& plan) {
+static int run_dense_route(sp_alignment* al, const Plan& plan, bool plan_on_device) {
     sp_ctx* ctx = al->ctx;
     const size_t S = plan.splits.size();
     const int64_t D = al->D;
-    SP_CHECK(upload_plan(ctx, plan, D));
+    if (!plan_on_device) SP_CHECK(upload_plan(ctx, plan, D));
     SP_CHECK(ctx->grams.ensure(plan.g_elems * 8));
     SP_CHECK(ctx->scores.ensure(S * 8));
     SP_CHECK(ctx->status.ensure(S * 4));
@@ -481,12 +486,14 @@ static int run_dense_route(sp_alignment* al, const Plan& plan) {
         SP_CHECK(ctx->mats.ensure(plan.mat_elems * 4));
         SP_CHECK(launch_zero_scatter<u32>(ctx, sdev, plan.splits, D, dims, rr_ptr(ctx), cc_ptr(ctx, S, D),
                                           al->counts.as<u32>(), ctx->mats.as<u32>()));
-        SP_CHECK(launch_gram<u32>(ctx, sdev, plan.splits, dims, ctx->mats.as<u32>(), ctx->grams.as<double>()));
+        SP_CHECK(launch_gram<u32>(ctx, sdev, ctx->gram_items.as<GramItem>(), (int64_t)plan.gram_items.size(), dims,
+                                  ctx->mats.as<u32>(), ctx->grams.as<double>()));
     } else {
         SP_CHECK(ctx->mats.ensure(plan.mat_elems * 8));
         SP_CHECK(launch_zero_scatter<double>(ctx, sdev, plan.splits, D, dims, rr_ptr(ctx), cc_ptr(ctx, S, D),
                                              al->weights.as<double>(), ctx->mats.as<double>()));
-        SP_CHECK(launch_gram<double>(ctx, sdev, plan.splits, dims, ctx->mats.as<double>(), ctx->grams.as<double>()));
+        SP_CHECK(launch_gram<double>(ctx, sdev, ctx->gram_items.as<GramItem>(), (int64_t)plan.gram_items.size(), dims,
+                                     ctx->mats.as<double>(), ctx->grams.as<double>()));
     }
     SP_CHECK(launch_eigen(ctx, sdev, plan.splits, dims, ctx->grams.as<double>(), nullptr, ctx->scores.as<double>(),
                           ctx->status.as<int>()));
@@ -504,9 +511,22 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
     if (n_splits == 0) return SP_OK;
     SP_REQUIRE(al->D > 0, SP_EINVAL, "empty pattern table");
     if (method == SP_METHOD_FLATTENING) {
-        Plan plan;
-        SP_CHECK(plan_splits(al->n_taxa, al->D, split_taxa, split_a, n_splits, true, true, true, plan));
-        SP_CHECK(run_dense_route(al, plan));
+        if (!ctx->cache) ctx->cache = new PlanCache();
+        PlanCache& pc = *ctx->cache;
+        const size_t nt = (size_t)n_splits * al->n_taxa;
+        const bool hit = pc.valid && pc.n == al->n_taxa && pc.D == al->D && pc.a.size() == (size_t)n_splits &&
+                         memcmp(pc.a.data(), split_a, n_splits * 4) == 0 &&
+                         memcmp(pc.taxa.data(), split_taxa, nt * 4) == 0;
+        if (!hit) {
+            pc.valid = false;
+            SP_CHECK(plan_splits(al->n_taxa, al->D, split_taxa, split_a, n_splits, true, true, true, pc.plan));
+            pc.taxa.assign(split_taxa, split_taxa + nt);
+            pc.a.assign(split_a, split_a + n_splits);
+            pc.n = al->n_taxa;
+            pc.D = al->D;
+        }
+        SP_CHECK(run_dense_route(al, pc.plan, hit));
+        pc.valid = true;
     } else if (method == SP_METHOD_SUBFLATTENING) {
         SP_CHECK(run_subflat_route(al, split_taxa, split_a, n_splits));
     } else {
@@ -568,9 +588,15 @@ extern "C" int sp_score_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, i
     const int2 d = make_int2((int)R, (int)K);
     SP_HIP(hipMemcpyAsync(ctx->mats.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(hipMemcpyAsync(ctx->dims.p, &d, sizeof(d), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->cache) ctx->cache->valid = false;
     SP_HIP(hipMemcpyAsync(ctx->splits.p, &sd, sizeof(sd), hipMemcpyHostToDevice, ctx->stream));
-    SP_CHECK(launch_gram<double>(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(),
-                                 ctx->mats.as<double>(), ctx->grams.as<double>()));
+    build_gram_items(plan);
+    SP_CHECK(ctx->gram_items.ensure(plan.gram_items.size() * sizeof(GramItem)));
+    SP_HIP(hipMemcpyAsync(ctx->gram_items.p, plan.gram_items.data(), plan.gram_items.size() * sizeof(GramItem),
+                          hipMemcpyHostToDevice, ctx->stream));
+    SP_CHECK(launch_gram<double>(ctx, ctx->splits.as<SplitDev>(), ctx->gram_items.as<GramItem>(),
+                                 (int64_t)plan.gram_items.size(), ctx->dims.as<int2>(), ctx->mats.as<double>(),
+                                 ctx->grams.as<double>()));
     SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.as<double>(),
                           nullptr, ctx->scores.as<double>(), ctx->status.as<int>()));
     SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -625,6 +651,7 @@ extern "C" int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* c
     SP_HIP(hipMemcpyAsync(dri, ri, nnz * 8, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(hipMemcpyAsync(dci, ci, nnz * 8, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(hipMemcpyAsync(dv, v, nnz * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->cache) ctx->cache->valid = false;
     SP_HIP(hipMemcpyAsync(ctx->splits.p, &sd, sizeof(sd), hipMemcpyHostToDevice, ctx->stream));
     u32* rr = rr_ptr(ctx);
     u32* cc = rr + nnz;
@@ -647,12 +674,18 @@ extern "C" int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* c
     SP_CHECK(ctx->grams.ensure((size_t)sd.rcap * sd.rcap * 8));
     SP_CHECK(ctx->scores.ensure(8));
     SP_CHECK(ctx->status.ensure(4));
+    if (ctx->cache) ctx->cache->valid = false;
     SP_HIP(hipMemcpyAsync(ctx->splits.p, &sd, sizeof(sd), hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(hipMemcpyAsync(ctx->dims.p, &d2, sizeof(d2), hipMemcpyHostToDevice, ctx->stream));
     SP_CHECK(launch_zero_scatter<double>(ctx, ctx->splits.as<SplitDev>(), plan.splits, nnz, ctx->dims.as<int2>(),
                                          tr ? cc : rr, tr ? rr : cc, dv, ctx->mats.as<double>()));
-    SP_CHECK(launch_gram<double>(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(),
-                                 ctx->mats.as<double>(), ctx->grams.as<double>()));
+    build_gram_items(plan);
+    SP_CHECK(ctx->gram_items.ensure(plan.gram_items.size() * sizeof(GramItem)));
+    SP_HIP(hipMemcpyAsync(ctx->gram_items.p, plan.gram_items.data(), plan.gram_items.size() * sizeof(GramItem),
+                          hipMemcpyHostToDevice, ctx->stream));
+    SP_CHECK(launch_gram<double>(ctx, ctx->splits.as<SplitDev>(), ctx->gram_items.as<GramItem>(),
+                                 (int64_t)plan.gram_items.size(), ctx->dims.as<int2>(), ctx->mats.as<double>(),
+                                 ctx->grams.as<double>()));
     SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.as<double>(),
                           nullptr, ctx->scores.as<double>(), ctx->status.as<int>()));
     SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));

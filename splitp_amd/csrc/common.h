@@ -54,6 +54,7 @@ struct PhaseTimer {
     int64_t launches[SP_N_PHASES] = {0};
 };
 
+struct PlanCache;
 struct sp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -72,6 +73,8 @@ struct sp_ctx {
     DevBuf status;     // int per split
     DevBuf misc;       // API scratch
     DevBuf misc2;
+    DevBuf gram_items; // GramItem[]
+    PlanCache* cache = nullptr;
     int n_cu = 256;
 };
 
@@ -108,6 +111,27 @@ struct SplitDev {
     int32_t cls;         // size class (for launch grouping)
 };
 
+struct GramItem {
+    int32_t sid;
+    int16_t ti, tj;
+};
+
+// Host-side launch plan for one batch of splits (cached in the context: scoring the same split
+// list again - the benchmark loop, an erickson round replayed - skips planning and the uploads).
+struct Plan {
+    std::vector<SplitDev> splits;
+    std::vector<GramItem> gram_items;   // upper-triangle 64 x 64 tiles, heaviest splits first
+    size_t bm_words = 0, pf_words = 0, mat_elems = 0, g_elems = 0;
+};
+
+struct PlanCache {
+    bool valid = false;
+    int n = 0;
+    int64_t D = 0;
+    std::vector<int32_t> taxa, a;
+    Plan plan;
+};
+
 struct PhaseScope {
     sp_ctx* c;
     int phase;
@@ -134,8 +158,9 @@ int launch_used_keys(sp_ctx* ctx, const u64* keys, int64_t D, int n_taxa, const 
 int launch_dense_scatter(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, int n_taxa,
                          const SplitDev* split_dev, const SplitDev& split, u32* out);
 template <typename T>
-int launch_gram(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits, const int2* dims,
+int launch_gram(sp_ctx* ctx, const SplitDev* splits_dev, const GramItem* items_dev, int64_t n_items, const int2* dims,
                 const T* mats, double* grams);
+void build_gram_items(Plan& plan);
 int launch_eigen(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits, const int2* dims,
                  const double* grams, double* work, double* scores, int* status);
 int eigen_work_doubles_per_split(int rcap);

@@ -11,6 +11,8 @@
 // as fp64 (converted once from u32 counts at staging time, not per MFMA), row pitch 34 doubles so the
 // operand reads (16 rows x 2 k per 32-lane group, ds_read_b64) hit 32 distinct bank pairs.  The next
 // panel's global loads are issued before the current panel's MFMAs (register prefetch).
+#include <algorithm>
+
 #include "common.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -67,17 +69,18 @@ __device__ __forceinline__ void panel_store(const PanelRegs<double>& r, double* 
     }
 }
 
-// grid = (T*T, n_in_class) with T = rcap/64 of the class; ids[] maps blockIdx.y to the split index.
+// grid = one workgroup per work item (split, ti, tj), ti <= tj; items beyond the split's actual
+// (data-dependent) row count exit at once.
 template <typename T>
-__global__ __launch_bounds__(256) void k_gram(const SplitDev* __restrict__ splits, const int* __restrict__ ids,
+__global__ __launch_bounds__(256) void k_gram(const SplitDev* __restrict__ splits, const GramItem* __restrict__ items,
                                               const int2* __restrict__ dims, const T* __restrict__ mats,
-                                              double* __restrict__ grams, int tiles) {
+                                              double* __restrict__ grams) {
     __shared__ __attribute__((aligned(16))) double sA[G_TILE * G_PITCH];
     __shared__ __attribute__((aligned(16))) double sB[G_TILE * G_PITCH];
-    const int sid = ids[blockIdx.y];
+    const GramItem it = items[blockIdx.x];
+    const int sid = it.sid;
     const SplitDev& sp = splits[sid];
-    const int ti = blockIdx.x / tiles, tj = blockIdx.x % tiles;
-    if (ti > tj) return;
+    const int ti = it.ti, tj = it.tj;
     const int2 d = dims[sid];
     const int rpad = min((d.x + 63) & ~63, sp.rcap);
     if (tj * G_TILE >= rpad) return;
@@ -139,33 +142,33 @@ __global__ __launch_bounds__(256) void k_gram(const SplitDev* __restrict__ split
             }
 }
 
-template <typename T>
-int launch_gram(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits, const int2* dims,
-                const T* mats, double* grams) {
-    if (splits.empty()) return SP_OK;
-    PhaseScope ps(ctx, SP_PHASE_GRAM);
-    // group the splits by row capacity so every launch has a tight grid
-    std::vector<int> order(splits.size());
-    for (size_t i = 0; i < splits.size(); ++i) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return splits[a].rcap > splits[b].rcap; });
-    SP_CHECK(ctx->misc2.ensure(order.size() * sizeof(int)));
-    SP_HIP(hipMemcpyAsync(ctx->misc2.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    // the host vector dies at return; make sure the copy has been consumed (pageable memcpy is staged
-    // synchronously by the runtime, so this is already true - the sync below is only for clarity)
-    size_t i = 0;
-    while (i < order.size()) {
-        size_t j = i;
-        const int rcap = splits[order[i]].rcap;
-        while (j < order.size() && splits[order[j]].rcap == rcap) ++j;
-        const int tiles = rcap / G_TILE;
-        hipLaunchKernelGGL(k_gram<T>, dim3(tiles * tiles, (unsigned)(j - i)), dim3(256), 0, ctx->stream, splits_dev,
-                           ctx->misc2.as<int>() + i, dims, mats, grams, tiles);
-        i = j;
+void build_gram_items(Plan& plan) {
+    std::vector<int> order(plan.splits.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    // heaviest first: a tile costs ~pitch (the K extent), so sort by rows then K
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        const SplitDev &x = plan.splits[a], &y = plan.splits[b];
+        if (x.rcap != y.rcap) return x.rcap > y.rcap;
+        return x.pitch > y.pitch;
+    });
+    plan.gram_items.clear();
+    for (int sid : order) {
+        const int tiles = plan.splits[sid].rcap / G_TILE;
+        for (int ti = 0; ti < tiles; ++ti)
+            for (int tj = ti; tj < tiles; ++tj) plan.gram_items.push_back({sid, (int16_t)ti, (int16_t)tj});
     }
+}
+
+template <typename T>
+int launch_gram(sp_ctx* ctx, const SplitDev* splits_dev, const GramItem* items_dev, int64_t n_items, const int2* dims,
+                const T* mats, double* grams) {
+    if (n_items == 0) return SP_OK;
+    PhaseScope ps(ctx, SP_PHASE_GRAM);
+    hipLaunchKernelGGL(k_gram<T>, dim3((unsigned)n_items), dim3(256), 0, ctx->stream, splits_dev, items_dev, dims, mats,
+                       grams);
     SP_HIP(hipGetLastError());
     return SP_OK;
 }
-template int launch_gram<u32>(sp_ctx*, const SplitDev*, const std::vector<SplitDev>&, const int2*, const u32*,
-                              double*);
-template int launch_gram<double>(sp_ctx*, const SplitDev*, const std::vector<SplitDev>&, const int2*, const double*,
+template int launch_gram<u32>(sp_ctx*, const SplitDev*, const GramItem*, int64_t, const int2*, const u32*, double*);
+template int launch_gram<double>(sp_ctx*, const SplitDev*, const GramItem*, int64_t, const int2*, const double*,
                                  double*);

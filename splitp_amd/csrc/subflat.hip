@@ -172,6 +172,7 @@ extern "C" int sp_subflatten(sp_alignment* al, const int32_t* oa, int a, const i
     const int R = 3 * a + 1, C = 3 * b + 1;
     SP_CHECK(ctx->splits.ensure(sizeof(SplitDev)));
     SP_CHECK(ctx->misc2.ensure((size_t)R * C * 8));
+    if (ctx->cache) ctx->cache->valid = false;
     SP_HIP(hipMemcpyAsync(ctx->splits.p, &sd, sizeof(sd), hipMemcpyHostToDevice, ctx->stream));
     if (al->exact)
         hipLaunchKernelGGL(k_subflatten_gather<true>, dim3((R * C + 255) / 256), dim3(256), 0, ctx->stream,

@@ -11,7 +11,7 @@ NumPy walk down the same tree shape:
   * uniform root state (splitp/simulation.py:28).
 
 It is statistically equivalent to, but not stream-identical with, the reference simulator
-(different RNG); both the oracle and the HIP path are always fed the same generated table.
+(different RNG); the CPU checker and the HIP path are always fed the same generated table.
 """
 from __future__ import annotations
 

@@ -1,0 +1,151 @@
+"""CPU: the C-ABI library loads and exports every symbol include/splitp_hip.h declares (no compute
+calls without a GPU), and the host-side logic (packing, count inference, split encoding / ordering,
+sharding plan, error behaviour without a GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import splitp_amd as sp
+from oracle import splitp_oracle as O
+from splitp_amd import _lib, batch, device
+from splitp_amd import synthetic as syn
+from tests.conftest import ROOT, taxa_names
+
+
+def _built():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+
+
+def test_library_exports_every_declared_symbol():
+    _built()
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "splitp_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(sp_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert sorted(_lib.SYMBOLS) == declared
+    assert lib.sp_abi_version() == 1
+    assert isinstance(lib.sp_last_error(), bytes)
+
+
+def test_no_gpu_means_loud_failure():
+    _built()
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(sp.SplitPDeviceError):
+        sp.flattening("01|23", {"ATCG": 0.4, "GATC": 0.2, "CGAT": 0.2, "TCGA": 0.2})
+    with pytest.raises(sp.SplitPDeviceError):
+        sp.split_score(np.eye(6))
+    with pytest.raises(sp.SplitPDeviceError):
+        sp.subflattening("01|23", {"ATCG": 1.0})
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "splitp_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src and "oracle." not in src, fn
+
+
+def test_api_surface_matches_reference_signatures():
+    import inspect
+
+    assert str(inspect.signature(sp.flattening)) == "(split, pattern_probabilities, flattening_format=<FlatFormat.sparse: 'sparse'>)"
+    assert str(inspect.signature(sp.subflattening)) == "(split, pattern_probabilities, data=None)"
+    assert str(inspect.signature(sp.split_score)) == ("(matrix, return_singular_values=False, "
+                                                       "force_frob_norm_on_dense=False, data_table_for_frob_norm=None)")
+    assert [m.name for m in sp.FlatFormat] == ["sparse", "reduced"] and sp.FlatFormat.sparse.value == "sparse"
+    assert sp.constants.DNA_state_space == ("A", "C", "G", "T")
+    assert sp.constants.DNA_state_space_dict == {"A": 0, "C": 1, "G": 2, "T": 3}
+    assert sp.constructions.flattening is sp.flattening and sp.phylogenetics.split_score is sp.split_score
+
+
+def test_pack_patterns_and_keys():
+    pats = ["ACGT", "TTTT", "AAAA", "GATC"]
+    keys, n = device.pack_patterns(pats)
+    assert n == 4 and keys.dtype == np.uint64
+    assert keys.tolist() == [O.index_of(p) for p in pats] == [27, 255, 0, 141]
+    with pytest.raises(KeyError):
+        device.pack_patterns(["ACGN"])
+    with pytest.raises(ValueError):
+        device.pack_patterns(["ACG", "ACGT"])
+    k0, n0 = device.pack_patterns([])
+    assert len(k0) == 0
+    # round trip through the oracle's packer on a simulated table
+    sites = syn.simulate_sites(10, 3000, 0.05, seed=4)
+    keys, counts = syn.pattern_table(sites)
+    table = syn.table_as_dict(keys, counts, 10)
+    k2, _ = device.pack_patterns(list(table.keys()))
+    assert np.array_equal(k2, keys) and np.array_equal(O.pack_table(table)[0], keys)
+
+
+def test_infer_counts():
+    sites = syn.simulate_sites(8, 5000, 0.05, seed=9)
+    keys, counts = syn.pattern_table(sites)
+    w = counts / 5000.0
+    got = device.infer_counts(w)
+    assert got is not None
+    cnt, n = got
+    assert np.array_equal(cnt / float(n), w)          # equivalent (counts, N): same values bit for bit
+    assert device.infer_counts(np.array([0.4, 0.2, 0.2, 0.2]))[1] in (5, 10)
+    rng = np.random.default_rng(0)
+    p = rng.random(50); p /= p.sum()
+    assert device.infer_counts(p) is None             # exact probabilities are not count-derived
+    assert device.infer_counts(np.array([])) is None
+    assert device.infer_counts(np.array([0.0, 0.0])) is None
+
+
+def test_all_splits_order_and_counts():
+    for n in (4, 6, 10):
+        names = taxa_names(n)
+        mine = list(sp.all_splits(names))
+        assert mine == list(O.all_splits(names))
+        assert len(mine) == 2 ** (n - 1) - n - 1
+        assert all(s[0][0] == names[0] for s in mine)     # taxa[0] always on the left (splits.py:55-56)
+    assert len(list(sp.all_splits(taxa_names(10), size=5))) == 126
+    assert next(sp.all_splits(taxa_names(6), string_format=True)) == "01|2345"
+    assert len(list(sp.all_splits(taxa_names(4), trivial=True))) == 7
+
+
+def test_balanced_tree_matches_reference_topology():
+    assert syn.balanced_tree(10) == ((((0, 1), 2), (3, 4)), ((5, 6), (7, (8, 9))))
+    assert syn.balanced_tree(4) == ((0, 1), (2, 3))
+    sets = syn.tree_splits(syn.balanced_tree(10), 10)   # both sides of the root edge appear: 8 sets, 7 splits
+    assert len({min(s, frozenset(range(10)) - s, key=sorted) for s in sets}) == 7
+    assert syn.taxa_names(12)[:12] == ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "A", "B"]
+
+
+def test_encode_splits_and_resolve():
+    names = taxa_names(6)
+
+    class T(dict):
+        pass
+
+    t = T()
+    t.taxa = tuple(names)
+    taxa_arr, a_arr = batch.encode_splits(["01|2345", (("5", "0"), ("1", "2", "3", "4"))], t, 6)
+    assert a_arr.tolist() == [2, 2]
+    assert taxa_arr.tolist() == [[0, 1, 2, 3, 4, 5], [5, 0, 1, 2, 3, 4]]
+    with pytest.raises(ValueError):
+        batch.encode_splits(["01|234"], t, 6)
+    oa, ob = device.resolve_split(({0, 2}, {1, 3}), {}, 4)       # int taxa, sets (reference tests' form)
+    assert sorted(oa.tolist()) == [0, 2] and sorted(ob.tolist()) == [1, 3]
+
+
+def test_shard_plan_is_balanced_and_complete():
+    a = np.array([len(s[0]) for s in sp.all_splits(taxa_names(10))], dtype=np.int32)
+    costs = batch.split_costs(a, 10, _lib.SP_METHOD_FLATTENING)
+    for world in (1, 2, 4, 8):
+        shards = batch.shard_indices(costs, world)
+        allidx = np.sort(np.concatenate(shards))
+        assert np.array_equal(allidx, np.arange(501))
+        loads = [costs[s].sum() for s in shards]
+        assert max(loads) / min(loads) < 1.05          # every rank gets an equal share of every class
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
