@@ -65,6 +65,10 @@ int sp_ctx_create(int device, void* stream, sp_ctx** out);
 int sp_ctx_destroy(sp_ctx* ctx);
 int sp_ctx_set_stream(sp_ctx* ctx, void* stream);
 int sp_ctx_synchronize(sp_ctx* ctx);
+/* Gram-kernel selection of the dense flattening route: 0 = auto (exact integer Gram on the int8 matrix
+ * cores, count limbs of 7 bits, when the alignment holds counts < 128^3; fp64 MFMA otherwise),
+ * 1 = always the fp64 MFMA kernel.  Both give bit-identical Gram matrices for integer counts. */
+int sp_ctx_set_gram_mode(sp_ctx* ctx, int mode);
 
 /* Per-phase device timing.  When enabled, every batched call brackets each phase with
  * hipEvents on the context's stream; sp_ctx_phase_times() then synchronises and returns,

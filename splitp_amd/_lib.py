@@ -20,7 +20,7 @@ PHASE_NAMES = ("reindex", "scatter", "gram", "eigen", "moment", "subscore", "his
 # every symbol include/splitp_hip.h declares
 SYMBOLS = (
     "sp_abi_version", "sp_last_error", "sp_device_count",
-    "sp_ctx_create", "sp_ctx_destroy", "sp_ctx_set_stream", "sp_ctx_synchronize",
+    "sp_ctx_create", "sp_ctx_destroy", "sp_ctx_set_stream", "sp_ctx_synchronize", "sp_ctx_set_gram_mode",
     "sp_ctx_enable_timing", "sp_ctx_reset_timing", "sp_ctx_phase_times",
     "sp_alignment_create", "sp_alignment_from_sequences", "sp_alignment_from_site_keys",
     "sp_alignment_destroy", "sp_alignment_info", "sp_alignment_fetch",
@@ -68,6 +68,7 @@ def load():
         "sp_ctx_destroy": [vp],
         "sp_ctx_set_stream": [vp, vp],
         "sp_ctx_synchronize": [vp],
+        "sp_ctx_set_gram_mode": [vp, i32],
         "sp_ctx_enable_timing": [vp, i32],
         "sp_ctx_reset_timing": [vp],
         "sp_ctx_phase_times": [vp, P(dbl), P(i64)],

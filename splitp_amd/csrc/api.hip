@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -114,6 +115,8 @@ extern "C" int sp_ctx_create(int device, void* stream, sp_ctx** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    const char* gm = getenv("SPLITP_GRAM");
+    if (gm && strcmp(gm, "f64") == 0) c->gram_mode = 1;
     *out = c;
     return SP_OK;
 }
@@ -148,6 +151,14 @@ extern "C" int sp_ctx_set_stream(sp_ctx* c, void* stream) {
         SP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
+    return SP_OK;
+}
+
+extern "C" int sp_ctx_set_gram_mode(sp_ctx* c, int mode) {
+    SP_REQUIRE(c, SP_EINVAL, "ctx is NULL");
+    SP_REQUIRE(mode == 0 || mode == 1, SP_EINVAL, "gram mode must be 0 (auto) or 1 (fp64)");
+    c->gram_mode = mode;
+    if (c->cache) c->cache->valid = false;
     return SP_OK;
 }
 
@@ -193,12 +204,14 @@ extern "C" int sp_alignment_create(sp_ctx* ctx, const uint64_t* keys, const doub
     std::vector<u32> c32;
     std::vector<double> w;
     double sumsq = 0;
+    u32 maxc = 0;
     if (counts) {
         c32.resize(D);
         for (int64_t i = 0; i < D; ++i) {
             SP_REQUIRE(counts[i] >= 0 && counts[i] <= 0xFFFFFFFFll, SP_EINVAL, "count %lld out of uint32 range",
                        (long long)counts[i]);
             c32[i] = (u32)counts[i];
+            if (c32[i] > maxc) maxc = c32[i];
         }
         SP_REQUIRE(N > 0, SP_EINVAL, "N must be positive when counts are given");
     }
@@ -216,6 +229,7 @@ extern "C" int sp_alignment_create(sp_ctx* ctx, const uint64_t* keys, const doub
     al->N = counts ? N : 0;
     al->exact = counts != nullptr;
     al->sumsq_w = sumsq;
+    al->max_count = maxc;
     int rc = SP_OK;
     const size_t d1 = (size_t)std::max<int64_t>(D, 1);
     if ((rc = al->keys.ensure(d1 * 8)) || (rc = al->weights.ensure(d1 * 8)) || (rc = al->counts.ensure(d1 * 4))) {
@@ -287,8 +301,18 @@ static int check_split(int n, const int32_t* oa, int a, const int32_t* ob, int b
 }
 
 // rows_first_small: orient every split so that the smaller side indexes the rows (scoring).
+static int limbs_for(const sp_alignment* al) {
+    if (!al->exact || al->ctx->gram_mode == 1) return 0;
+    if (al->max_count < (1u << 7)) return 1;
+    if (al->max_count < (1u << 14)) return 2;
+    if (al->max_count < (1u << 21)) return 3;
+    return 0;
+}
+
+// nl > 0: matrices are nl int8 limb planes (pitch in bytes, multiple of 128) instead of one typed matrix.
 static int plan_splits(int n, int64_t D, const int32_t* split_taxa, const int32_t* split_a, int64_t S,
-                       bool small_rows, bool want_mats, bool want_gram, Plan& plan) {
+                       bool small_rows, bool want_mats, bool want_gram, Plan& plan, int nl = 0) {
+    plan = Plan();
     plan.splits.resize(S);
     for (int64_t s = 0; s < S; ++s) {
         const int a = split_a[s], b = n - a;
@@ -314,18 +338,33 @@ static int plan_splits(int n, int64_t D, const int32_t* split_taxa, const int32_
         const int64_t rmax = std::min<int64_t>(pow4(sd.nr), std::max<int64_t>(D, 1));
         const int64_t cmax = std::min<int64_t>(pow4(sd.nc), std::max<int64_t>(D, 1));
         sd.rcap = (int32_t)round_up(rmax, 64);
-        sd.pitch = (int32_t)round_up(cmax, 32);
+        sd.pitch = (int32_t)round_up(cmax, nl > 0 ? 128 : 32);
         if (want_mats) {
             sd.mat_off = (int64_t)plan.mat_elems;
-            plan.mat_elems += (size_t)sd.rcap * sd.pitch;
+            plan.mat_elems += (size_t)sd.rcap * sd.pitch * (nl > 0 ? nl : 1);
         }
         if (want_gram) {
             sd.g_pitch = sd.rcap;
             sd.g_off = (int64_t)plan.g_elems;
             plan.g_elems += (size_t)sd.rcap * sd.rcap;
+            sd.ev_off = (int64_t)plan.ev_elems;
+            plan.ev_elems += (size_t)sd.rcap * 16;
         }
     }
     if (want_gram) build_gram_items(plan);
+    return SP_OK;
+}
+
+static int upload_items(sp_ctx* ctx, const Plan& plan) {
+    if (plan.gram_items.empty()) return SP_OK;
+    const size_t ng = plan.gram_items.size(), nr = plan.row_items.size(), no = plan.order.size();
+    SP_CHECK(ctx->gram_items.ensure((ng + nr) * sizeof(GramItem) + no * sizeof(int)));
+    SP_HIP(hipMemcpyAsync(ctx->gram_items.as<GramItem>() + ng + nr, plan.order.data(), no * sizeof(int),
+                          hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipMemcpyAsync(ctx->gram_items.p, plan.gram_items.data(), ng * sizeof(GramItem), hipMemcpyHostToDevice,
+                          ctx->stream));
+    SP_HIP(hipMemcpyAsync(ctx->gram_items.as<GramItem>() + ng, plan.row_items.data(), nr * sizeof(GramItem),
+                          hipMemcpyHostToDevice, ctx->stream));
     return SP_OK;
 }
 
@@ -337,11 +376,7 @@ static int upload_plan(sp_ctx* ctx, const Plan& plan, int64_t D) {
     SP_CHECK(ctx->coords.ensure(S * (size_t)std::max<int64_t>(D, 1) * 8));
     SP_CHECK(ctx->dims.ensure(S * sizeof(int2)));
     SP_HIP(hipMemcpyAsync(ctx->splits.p, plan.splits.data(), S * sizeof(SplitDev), hipMemcpyHostToDevice, ctx->stream));
-    if (!plan.gram_items.empty()) {
-        SP_CHECK(ctx->gram_items.ensure(plan.gram_items.size() * sizeof(GramItem)));
-        SP_HIP(hipMemcpyAsync(ctx->gram_items.p, plan.gram_items.data(), plan.gram_items.size() * sizeof(GramItem),
-                              hipMemcpyHostToDevice, ctx->stream));
-    }
+    SP_CHECK(upload_items(ctx, plan));
     return SP_OK;
 }
 
@@ -482,7 +517,14 @@ static int run_dense_route(sp_alignment* al, const Plan& plan, bool plan_on_devi
     int2* dims = ctx->dims.as<int2>();
     SP_CHECK(launch_reindex(ctx, al->keys.as<u64>(), D, al->n_taxa, sdev, plan.splits, bm_ptr(ctx), pf_ptr(ctx, plan),
                             dims, rr_ptr(ctx), cc_ptr(ctx, S, D)));
-    if (al->exact) {
+    const int nl = ctx->cache ? ctx->cache->nl : 0;
+    if (al->exact && nl > 0) {
+        SP_CHECK(ctx->mats.ensure(plan.mat_elems + 256));
+        SP_CHECK(launch_zero_scatter_i8(ctx, nl, sdev, plan.splits, D, dims, rr_ptr(ctx), cc_ptr(ctx, S, D),
+                                        al->counts.as<u32>(), ctx->mats.as<uint8_t>()));
+        SP_CHECK(launch_gram_i8(ctx, nl, sdev, ctx->gram_items.as<GramItem>(), (int64_t)plan.gram_items.size(), dims,
+                                ctx->mats.as<uint8_t>(), ctx->grams.as<double>()));
+    } else if (al->exact) {
         SP_CHECK(ctx->mats.ensure(plan.mat_elems * 4));
         SP_CHECK(launch_zero_scatter<u32>(ctx, sdev, plan.splits, D, dims, rr_ptr(ctx), cc_ptr(ctx, S, D),
                                           al->counts.as<u32>(), ctx->mats.as<u32>()));
@@ -495,8 +537,11 @@ static int run_dense_route(sp_alignment* al, const Plan& plan, bool plan_on_devi
         SP_CHECK(launch_gram<double>(ctx, sdev, ctx->gram_items.as<GramItem>(), (int64_t)plan.gram_items.size(), dims,
                                      ctx->mats.as<double>(), ctx->grams.as<double>()));
     }
-    SP_CHECK(launch_eigen(ctx, sdev, plan.splits, dims, ctx->grams.as<double>(), nullptr, ctx->scores.as<double>(),
-                          ctx->status.as<int>()));
+    SP_CHECK(launch_eigen(ctx, sdev, plan.splits, dims, ctx->grams.as<double>(),
+                          ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
+                          reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
+                                                       plan.row_items.size()),
+                          ctx->scores.as<double>(), ctx->status.as<int>()));
     return SP_OK;
 }
 
@@ -514,12 +559,15 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
         if (!ctx->cache) ctx->cache = new PlanCache();
         PlanCache& pc = *ctx->cache;
         const size_t nt = (size_t)n_splits * al->n_taxa;
-        const bool hit = pc.valid && pc.n == al->n_taxa && pc.D == al->D && pc.a.size() == (size_t)n_splits &&
+        const int nl = limbs_for(al);
+        const bool hit = pc.valid && pc.nl == nl && pc.n == al->n_taxa && pc.D == al->D &&
+                         pc.a.size() == (size_t)n_splits &&
                          memcmp(pc.a.data(), split_a, n_splits * 4) == 0 &&
                          memcmp(pc.taxa.data(), split_taxa, nt * 4) == 0;
         if (!hit) {
             pc.valid = false;
-            SP_CHECK(plan_splits(al->n_taxa, al->D, split_taxa, split_a, n_splits, true, true, true, pc.plan));
+            SP_CHECK(plan_splits(al->n_taxa, al->D, split_taxa, split_a, n_splits, true, true, true, pc.plan, nl));
+            pc.nl = nl;
             pc.taxa.assign(split_taxa, split_taxa + nt);
             pc.a.assign(split_a, split_a + n_splits);
             pc.n = al->n_taxa;
@@ -591,14 +639,15 @@ extern "C" int sp_score_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, i
     if (ctx->cache) ctx->cache->valid = false;
     SP_HIP(hipMemcpyAsync(ctx->splits.p, &sd, sizeof(sd), hipMemcpyHostToDevice, ctx->stream));
     build_gram_items(plan);
-    SP_CHECK(ctx->gram_items.ensure(plan.gram_items.size() * sizeof(GramItem)));
-    SP_HIP(hipMemcpyAsync(ctx->gram_items.p, plan.gram_items.data(), plan.gram_items.size() * sizeof(GramItem),
-                          hipMemcpyHostToDevice, ctx->stream));
+    SP_CHECK(upload_items(ctx, plan));
     SP_CHECK(launch_gram<double>(ctx, ctx->splits.as<SplitDev>(), ctx->gram_items.as<GramItem>(),
                                  (int64_t)plan.gram_items.size(), ctx->dims.as<int2>(), ctx->mats.as<double>(),
                                  ctx->grams.as<double>()));
     SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.as<double>(),
-                          nullptr, ctx->scores.as<double>(), ctx->status.as<int>()));
+                          ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
+                          reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
+                                                       plan.row_items.size()),
+                          ctx->scores.as<double>(), ctx->status.as<int>()));
     SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;
@@ -680,14 +729,15 @@ extern "C" int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* c
     SP_CHECK(launch_zero_scatter<double>(ctx, ctx->splits.as<SplitDev>(), plan.splits, nnz, ctx->dims.as<int2>(),
                                          tr ? cc : rr, tr ? rr : cc, dv, ctx->mats.as<double>()));
     build_gram_items(plan);
-    SP_CHECK(ctx->gram_items.ensure(plan.gram_items.size() * sizeof(GramItem)));
-    SP_HIP(hipMemcpyAsync(ctx->gram_items.p, plan.gram_items.data(), plan.gram_items.size() * sizeof(GramItem),
-                          hipMemcpyHostToDevice, ctx->stream));
+    SP_CHECK(upload_items(ctx, plan));
     SP_CHECK(launch_gram<double>(ctx, ctx->splits.as<SplitDev>(), ctx->gram_items.as<GramItem>(),
                                  (int64_t)plan.gram_items.size(), ctx->dims.as<int2>(), ctx->mats.as<double>(),
                                  ctx->grams.as<double>()));
     SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.as<double>(),
-                          nullptr, ctx->scores.as<double>(), ctx->status.as<int>()));
+                          ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
+                          reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
+                                                       plan.row_items.size()),
+                          ctx->scores.as<double>(), ctx->status.as<int>()));
     SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;

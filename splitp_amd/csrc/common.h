@@ -60,6 +60,7 @@ struct sp_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool timing = false;
+    int gram_mode = 0;  // 0 = auto (int8 limbs when the alignment is exact and counts < 128^3), 1 = always fp64 MFMA
     PhaseTimer timer;
     // workspace pools (see DESIGN.md "HBM layout")
     DevBuf splits;     // SplitDev[n_splits]
@@ -73,7 +74,7 @@ struct sp_ctx {
     DevBuf status;     // int per split
     DevBuf misc;       // API scratch
     DevBuf misc2;
-    DevBuf gram_items; // GramItem[]
+    DevBuf gram_items; // GramItem[]: Gram tiles, then the row-block items
     PlanCache* cache = nullptr;
     int n_cu = 256;
 };
@@ -88,6 +89,7 @@ struct sp_alignment {
     DevBuf weights;  // double[D]
     DevBuf counts;   // u32[D]   (exact only)
     double sumsq_w = 0;  // sum of weights^2 (host-computed, informational)
+    uint32_t max_count = 0;  // largest count (exact only): decides the number of 7-bit limbs of the int8 Gram
     // cached signed second-moment matrix (subflattening path)
     bool moments_ready = false;
     DevBuf moments;  // int64 or double [(3n+1)^2]
@@ -109,6 +111,7 @@ struct SplitDev {
     int64_t g_off;       // element offset of the Gram matrix in the gram pool
     int32_t g_pitch;     // Gram pitch (= rcap)
     int32_t cls;         // size class (for launch grouping)
+    int64_t ev_off;      // element offset of the 16 x rcap iteration blocks (V^T, Y) in the eigen pools
 };
 
 struct GramItem {
@@ -121,11 +124,14 @@ struct GramItem {
 struct Plan {
     std::vector<SplitDev> splits;
     std::vector<GramItem> gram_items;   // upper-triangle 64 x 64 tiles, heaviest splits first
-    size_t bm_words = 0, pf_words = 0, mat_elems = 0, g_elems = 0;
+    std::vector<GramItem> row_items;    // 64-row blocks (ti = block index) for the G V product
+    std::vector<int> order;             // split ids, heaviest first (block -> split map of the per-split kernels)
+    size_t bm_words = 0, pf_words = 0, mat_elems = 0, g_elems = 0, ev_elems = 0;
 };
 
 struct PlanCache {
     bool valid = false;
+    int nl = 0;  // limb count the plan was laid out for (0 = element-typed u32 / f64 matrices)
     int n = 0;
     int64_t D = 0;
     std::vector<int32_t> taxa, a;
@@ -157,10 +163,14 @@ int launch_used_keys(sp_ctx* ctx, const u64* keys, int64_t D, int n_taxa, const 
                      const u32* cc, int64_t* row_keys, int64_t* col_keys);
 int launch_dense_scatter(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, int n_taxa,
                          const SplitDev* split_dev, const SplitDev& split, u32* out);
+int launch_zero_scatter_i8(sp_ctx* ctx, int nl, const SplitDev* splits_dev, const std::vector<SplitDev>& splits,
+                           int64_t D, const int2* dims, const u32* rr, const u32* cc, const u32* vals, uint8_t* mats);
+int launch_gram_i8(sp_ctx* ctx, int nl, const SplitDev* splits_dev, const GramItem* items_dev, int64_t n_items,
+                   const int2* dims, const uint8_t* mats, double* grams);
 template <typename T>
 int launch_gram(sp_ctx* ctx, const SplitDev* splits_dev, const GramItem* items_dev, int64_t n_items, const int2* dims,
                 const T* mats, double* grams);
 void build_gram_items(Plan& plan);
 int launch_eigen(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits, const int2* dims,
-                 const double* grams, double* work, double* scores, int* status);
-int eigen_work_doubles_per_split(int rcap);
+                 const double* grams, const GramItem* rowblocks_dev, int64_t n_rowblocks, const int* order_dev,
+                 double* scores, int* status);

@@ -332,3 +332,56 @@ int launch_dense_scatter(sp_ctx* ctx, const u64* keys, const u32* counts, int64_
     SP_HIP(hipGetLastError());
     return SP_OK;
 }
+
+// ---- int8 limb planes (input of gram_i8.hip) ------------------------------------------------------
+// Split s owns nl planes of rcap x pitch bytes; plane l holds (count >> 7l) & 127.
+__global__ __launch_bounds__(256) void k_zero_i8(const SplitDev* __restrict__ splits, const int2* __restrict__ dims,
+                                                 uint8_t* __restrict__ mats, int nl) {
+    const SplitDev& sp = splits[blockIdx.y];
+    const int2 d = dims[blockIdx.y];
+    const int rpad = min((d.x + 63) & ~63, sp.rcap);
+    const int kpad = min((d.y + 127) & ~127, sp.pitch);
+    const int kv = kpad / 16;
+    const int64_t per_plane = (int64_t)rpad * kv;
+    const int64_t total = per_plane * nl;
+    const int64_t plane = (int64_t)sp.rcap * sp.pitch;
+    uint8_t* base = mats + sp.mat_off;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int l = (int)(e / per_plane);
+        const int64_t r = e % per_plane;
+        const int row = (int)(r / kv), cv = (int)(r % kv);
+        *reinterpret_cast<uint4*>(base + l * plane + (int64_t)row * sp.pitch + (int64_t)cv * 16) = z;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_i8(const SplitDev* __restrict__ splits, int64_t D,
+                                                    const u32* __restrict__ rr, const u32* __restrict__ cc,
+                                                    const u32* __restrict__ vals, uint8_t* __restrict__ mats, int nl) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= D) return;
+    const SplitDev& sp = splits[blockIdx.y];
+    const int64_t o = (int64_t)blockIdx.y * D + i;
+    const int64_t plane = (int64_t)sp.rcap * sp.pitch;
+    uint8_t* p = mats + sp.mat_off + (int64_t)rr[o] * sp.pitch + cc[o];
+    u32 v = vals[i];
+    for (int l = 0; l < nl; ++l) {
+        p[l * plane] = (uint8_t)(v & 127u);
+        v >>= 7;
+    }
+}
+
+int launch_zero_scatter_i8(sp_ctx* ctx, int nl, const SplitDev* splits_dev, const std::vector<SplitDev>& splits,
+                           int64_t D, const int2* dims, const u32* rr, const u32* cc, const u32* vals, uint8_t* mats) {
+    if (splits.empty() || D == 0) return SP_OK;
+    PhaseScope ps(ctx, SP_PHASE_SCATTER);
+    const int S = (int)splits.size();
+    int64_t maxb = 0;
+    for (const auto& s : splits) maxb = std::max<int64_t>(maxb, (int64_t)s.rcap * s.pitch * nl);
+    const int zb = (int)std::min<int64_t>(64, std::max<int64_t>(1, maxb / 16 / 256 / 4));
+    hipLaunchKernelGGL(k_zero_i8, dim3(zb, S), dim3(256), 0, ctx->stream, splits_dev, dims, mats, nl);
+    hipLaunchKernelGGL(k_scatter_i8, dim3((unsigned)((D + 255) / 256), S), dim3(256), 0, ctx->stream, splits_dev, D, rr,
+                       cc, vals, mats, nl);
+    SP_HIP(hipGetLastError());
+    return SP_OK;
+}

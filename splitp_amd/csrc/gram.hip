@@ -152,10 +152,14 @@ void build_gram_items(Plan& plan) {
         return x.pitch > y.pitch;
     });
     plan.gram_items.clear();
+    plan.row_items.clear();
+    plan.order = order;
     for (int sid : order) {
         const int tiles = plan.splits[sid].rcap / G_TILE;
-        for (int ti = 0; ti < tiles; ++ti)
+        for (int ti = 0; ti < tiles; ++ti) {
+            plan.row_items.push_back({sid, (int16_t)ti, 0});
             for (int tj = ti; tj < tiles; ++tj) plan.gram_items.push_back({sid, (int16_t)ti, (int16_t)tj});
+        }
     }
 }
 

@@ -1,0 +1,162 @@
+// Exact Gram matrix of integer count matrices on the int8 matrix cores.
+//
+// Same job as gram.hip (G = C C^T over the smaller side, feeding the top-4 eigen step that replaces
+// LAPACK gesdd at splitp/phylogenetics.py:281-285) for alignments that hold integer site counts.
+// A count c < 128^NL is split into NL 7-bit limbs, c = sum_l 128^l c_l, stored as NL int8 planes;
+//     G = sum_{a,b} 128^(a+b) * (C_a C_b^T)
+// and every C_a C_b^T is an int8 x int8 -> int32 MFMA product (v_mfma_i32_32x32x32_i8, 64x the fp64
+// MFMA rate, so even NL^2 = 4 products are ~16x cheaper than one fp64 product).  The int32 partial
+// sums are exact (127^2 * K < 2^31 for K < 133k; longer K is flushed into fp64 every 32768 columns),
+// the limb recombination is exact in fp64 (< 2^53), so G is bit-identical to the fp64 kernel's.
+//
+// Tiling: one 256-thread workgroup per 64 x 64 upper-triangle tile of G; wave (wr, wc) owns a 32 x 32
+// sub-tile = one 32x32x32 MFMA per limb pair per 32-wide k-step.  K is consumed 128 bytes at a time:
+// the NL planes of both 64-row panels go global -> registers -> LDS (16-byte accesses; LDS row pitch
+// 144 B so the ds_read_b128 operand reads of 16 different rows hit 64 distinct banks).  Both operands
+// are fetched with the same lane -> k rule, so the product does not depend on the instruction's
+// internal k ordering; only the (dtype-independent) C/D layout matters.
+#include <algorithm>
+
+#include "common.h"
+
+typedef int int4_t __attribute__((ext_vector_type(4)));
+typedef int int16_t_v __attribute__((ext_vector_type(16)));
+
+#define GI_TILE 64
+#define GI_KS 128           // bytes of K per step
+#define GI_PITCH 144        // LDS row pitch in bytes
+#define GI_FLUSH 32768      // columns between int32 -> fp64 flushes
+
+template <int NL>
+__global__ __launch_bounds__(256) void k_gram_i8(const SplitDev* __restrict__ splits,
+                                                 const GramItem* __restrict__ items,
+                                                 const int2* __restrict__ dims, const uint8_t* __restrict__ mats,
+                                                 double* __restrict__ grams) {
+    __shared__ __attribute__((aligned(16))) uint8_t sA[NL][GI_TILE * GI_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t sB[NL][GI_TILE * GI_PITCH];
+    const GramItem it = items[blockIdx.x];
+    const int sid = it.sid;
+    const SplitDev& sp = splits[sid];
+    const int ti = it.ti, tj = it.tj;
+    const int2 d = dims[sid];
+    const int rpad = min((d.x + 63) & ~63, sp.rcap);
+    if (tj * GI_TILE >= rpad) return;
+    const int kpad = min((d.y + GI_KS - 1) & ~(GI_KS - 1), sp.pitch);
+    const int64_t pitch = sp.pitch;                       // bytes
+    const int64_t plane = (int64_t)sp.rcap * pitch;       // bytes per limb plane
+    const uint8_t* __restrict__ base = mats + sp.mat_off;
+    const bool diag = (ti == tj);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    // staging map: a panel limb is 64 rows x 128 B = 512 x 16 B -> 2 vectors per thread
+    const int v0 = threadIdx.x, v1 = threadIdx.x + 256;
+    const int r0 = v0 >> 3, c0 = (v0 & 7) * 16, r1 = v1 >> 3, c1 = (v1 & 7) * 16;
+
+    int16_t_v acc[NL][NL];
+    double facc[16];
+#pragma unroll
+    for (int a = 0; a < NL; ++a)
+#pragma unroll
+        for (int b = 0; b < NL; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) facc[e] = 0.0;
+
+    uint4 ra[NL][2], rb[NL][2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const uint8_t* pa = base + l * plane + (int64_t)(ti * GI_TILE) * pitch + k0;
+            ra[l][0] = *reinterpret_cast<const uint4*>(pa + (int64_t)r0 * pitch + c0);
+            ra[l][1] = *reinterpret_cast<const uint4*>(pa + (int64_t)r1 * pitch + c1);
+            if (!diag) {
+                const uint8_t* pb = base + l * plane + (int64_t)(tj * GI_TILE) * pitch + k0;
+                rb[l][0] = *reinterpret_cast<const uint4*>(pb + (int64_t)r0 * pitch + c0);
+                rb[l][1] = *reinterpret_cast<const uint4*>(pb + (int64_t)r1 * pitch + c1);
+            }
+        }
+    };
+    gload(0);
+    for (int kc = 0; kc < kpad; kc += GI_FLUSH) {           // int32 partial sums are flushed per chunk
+        const int kend = min(kpad, kc + GI_FLUSH);
+        for (int k0 = kc; k0 < kend; k0 += GI_KS) {
+            __syncthreads();  // previous panel fully consumed
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                *reinterpret_cast<uint4*>(&sA[l][r0 * GI_PITCH + c0]) = ra[l][0];
+                *reinterpret_cast<uint4*>(&sA[l][r1 * GI_PITCH + c1]) = ra[l][1];
+                if (!diag) {
+                    *reinterpret_cast<uint4*>(&sB[l][r0 * GI_PITCH + c0]) = rb[l][0];
+                    *reinterpret_cast<uint4*>(&sB[l][r1 * GI_PITCH + c1]) = rb[l][1];
+                }
+            }
+            __syncthreads();
+            if (k0 + GI_KS < kpad) gload(k0 + GI_KS);
+#pragma unroll
+            for (int kk = 0; kk < GI_KS / 32; ++kk) {
+                int4_t fa[NL], fb[NL];
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    fa[l] = *reinterpret_cast<const int4_t*>(&sA[l][(wr * 32 + fr) * GI_PITCH + kk * 32 + fh * 16]);
+                    fb[l] = diag
+                                ? *reinterpret_cast<const int4_t*>(&sA[l][(wc * 32 + fr) * GI_PITCH + kk * 32 + fh * 16])
+                                : *reinterpret_cast<const int4_t*>(&sB[l][(wc * 32 + fr) * GI_PITCH + kk * 32 + fh * 16]);
+                }
+#pragma unroll
+                for (int a = 0; a < NL; ++a)
+#pragma unroll
+                    for (int b = 0; b < NL; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NL; ++a)
+#pragma unroll
+            for (int b = 0; b < NL; ++b) {
+                const double wgt = (double)(1ll << (7 * (a + b)));
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    facc[e] += wgt * (double)acc[a][b][e];
+                    acc[a][b][e] = 0;
+                }
+            }
+    }
+    // epilogue: 32x32 C/D layout is col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    double* __restrict__ g = grams + sp.g_off;
+    const int64_t gp = sp.g_pitch;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = ti * GI_TILE + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int col = tj * GI_TILE + wc * 32 + fr;
+        g[(int64_t)row * gp + col] = facc[e];
+        if (!diag) g[(int64_t)col * gp + row] = facc[e];
+    }
+}
+
+int launch_gram_i8(sp_ctx* ctx, int nl, const SplitDev* splits_dev, const GramItem* items_dev, int64_t n_items,
+                   const int2* dims, const uint8_t* mats, double* grams) {
+    if (n_items == 0) return SP_OK;
+    PhaseScope ps(ctx, SP_PHASE_GRAM);
+    switch (nl) {
+        case 1:
+            hipLaunchKernelGGL(k_gram_i8<1>, dim3((unsigned)n_items), dim3(256), 0, ctx->stream, splits_dev, items_dev,
+                               dims, mats, grams);
+            break;
+        case 2:
+            hipLaunchKernelGGL(k_gram_i8<2>, dim3((unsigned)n_items), dim3(256), 0, ctx->stream, splits_dev, items_dev,
+                               dims, mats, grams);
+            break;
+        case 3:
+            hipLaunchKernelGGL(k_gram_i8<3>, dim3((unsigned)n_items), dim3(256), 0, ctx->stream, splits_dev, items_dev,
+                               dims, mats, grams);
+            break;
+        default:
+            sp_set_error("launch_gram_i8: unsupported limb count %d", nl);
+            return SP_EINVAL;
+    }
+    SP_HIP(hipGetLastError());
+    return SP_OK;
+}

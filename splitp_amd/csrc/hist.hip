@@ -251,6 +251,11 @@ static int build_from_device_keys(sp_ctx* ctx, const u64* dkeys, int64_t L, int 
     }
     e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess && D > 0) {  // largest count -> limb count of the int8 Gram (D x 4 bytes, one-time)
+        std::vector<u32> hc((size_t)D);
+        e = hipMemcpy(hc.data(), al->counts.p, (size_t)D * 4, hipMemcpyDeviceToHost);
+        for (u32 c : hc) al->max_count = std::max(al->max_count, c);
+    }
     cleanup();
     if (e != hipSuccess) {
         sp_alignment_destroy(al);

@@ -52,6 +52,10 @@ class Context:
     def synchronize(self):
         _lib.check(self._lib.sp_ctx_synchronize(self.handle))
 
+    def set_gram_mode(self, mode):
+        """'auto' (int8-limb exact Gram when the table holds counts) or 'f64' (always the fp64 MFMA kernel)."""
+        _lib.check(self._lib.sp_ctx_set_gram_mode(self.handle, {"auto": 0, "f64": 1}[mode]))
+
     def enable_timing(self, on=True):
         _lib.check(self._lib.sp_ctx_enable_timing(self.handle, 1 if on else 0))
 

@@ -270,3 +270,28 @@ def test_full_size_properties(sp):
         ob = [names.index(t) for t in splits[i][1]]
         M = O.reduced_flattening_packed(keys, counts / 100_000.0, 10, oa, ob)[0]
         assert abs(O.dense_split_score(M) - s1[i]) <= SCORE_TOL
+
+
+def test_gram_kernels_agree_bitwise(sp, golden):
+    """int8-limb Gram (default for count tables) vs fp64 MFMA Gram: both are exact for integer counts, so the
+    scores must be bit-identical; also covers 1-limb (all counts < 128) and 3-limb (counts >= 16384) tables."""
+    from splitp_amd import synthetic as syn
+
+    names = taxa_names(10)
+    splits = list(sp.all_splits(names))
+    for length, seed in ((100_000, 5), (300, 6), (400_000, 7)):
+        sites = syn.simulate_sites(10, length, 0.05, seed=seed)
+        keys, counts = syn.pattern_table(sites)
+        dev = sp.DeviceAlignment.from_arrays(keys, None, 10, counts=counts, n_sites=length, taxa=names)
+        sub = splits[::3]
+        dev.ctx.set_gram_mode("auto")
+        s_i8 = sp.score_splits(dev, sub)
+        dev.ctx.set_gram_mode("f64")
+        s_f64 = sp.score_splits(dev, sub)
+        dev.ctx.set_gram_mode("auto")
+        assert np.array_equal(s_i8, s_f64), (length, int(counts.max()), np.abs(s_i8 - s_f64).max())
+        for i in (0, 60, 150):
+            a, b = sub[i]
+            M = O.reduced_flattening_packed(keys, counts.astype(np.float64), 10, [names.index(t) for t in a],
+                                            [names.index(t) for t in b])[0]
+            assert abs(O.dense_split_score(M) - s_i8[i]) <= SCORE_TOL
