@@ -82,7 +82,8 @@ int sp_ctx_set_gram_mode(sp_ctx* ctx, int mode);
 #define SP_PHASE_SUBSCORE 5 /* gather + one-sided Jacobi SVD of the (3a+1)x(3b+1) blocks  */
 #define SP_PHASE_HIST 6     /* site-pattern histogram (alignment columns -> pattern table) */
 #define SP_PHASE_DENSE 7    /* full 4^a x 4^b dense scatter (sp_flatten_dense)             */
-#define SP_N_PHASES 8
+#define SP_PHASE_SPARSE 8   /* sparse route: one workgroup per split, everything in LDS     */
+#define SP_N_PHASES 9
 int sp_ctx_enable_timing(sp_ctx* ctx, int on);
 int sp_ctx_reset_timing(sp_ctx* ctx);
 int sp_ctx_phase_times(sp_ctx* ctx, double* ms /*[SP_N_PHASES]*/, int64_t* launches /*[SP_N_PHASES]*/);
@@ -152,12 +153,18 @@ int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* ci, const do
  * device (the README loop, README.md:36-41, as one call).
  *   split_taxa[n_splits * n]  for split s: order_a (a entries) then order_b (n - a entries)
  *   split_a[n_splits]         a of each split
- *   method                    SP_METHOD_FLATTENING or SP_METHOD_SUBFLATTENING
+ *   method                    SP_METHOD_FLATTENING (auto: the sparse in-LDS route when the table holds counts
+ *                             < 65536, the dense MFMA route otherwise or for splits the sparse kernel hands
+ *                             back), SP_METHOD_FLATTENING_DENSE, SP_METHOD_FLATTENING_SPARSE (error if a split
+ *                             cannot be handled there) or SP_METHOD_SUBFLATTENING
  *   scores_host               may be NULL; if given, the stream is synchronised
  *   scores_dev                may be NULL; device buffer of n_splits doubles
- *   status_host               may be NULL; per-split flags (bit 0: eigen iteration hit its cap) */
+ *   status_host               may be NULL; per-split flags (bit 0: eigen iteration hit its cap; bits 8..: number
+ *                             of operator applications) */
 #define SP_METHOD_FLATTENING 0
 #define SP_METHOD_SUBFLATTENING 1
+#define SP_METHOD_FLATTENING_DENSE 2
+#define SP_METHOD_FLATTENING_SPARSE 3
 int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
                     int method, double* scores_host, void* scores_dev, int32_t* status_host);
 

@@ -14,8 +14,10 @@ LIB_PATH = os.path.join(_HERE, "libsplitp_hip.so")
 
 SP_METHOD_FLATTENING = 0
 SP_METHOD_SUBFLATTENING = 1
-SP_N_PHASES = 8
-PHASE_NAMES = ("reindex", "scatter", "gram", "eigen", "moment", "subscore", "hist", "dense")
+SP_METHOD_FLATTENING_DENSE = 2
+SP_METHOD_FLATTENING_SPARSE = 3
+SP_N_PHASES = 9
+PHASE_NAMES = ("reindex", "scatter", "gram", "eigen", "moment", "subscore", "hist", "dense", "sparse")
 
 # every symbol include/splitp_hip.h declares
 SYMBOLS = (

@@ -41,7 +41,7 @@ def split_costs(split_a, n_taxa, method):
     """Relative cost of a split (for balanced sharding): the Gram over the smaller side costs
     ~ 4^k * D on the flattening route; the subflattening route's eigenproblem ~ (3k+1)^3."""
     k = np.minimum(split_a, n_taxa - split_a).astype(np.int64)
-    if method == _lib.SP_METHOD_FLATTENING:
+    if method != _lib.SP_METHOD_SUBFLATTENING:
         return (4.0 ** k)
     return (3.0 * k + 1.0) ** 3
 
@@ -54,10 +54,11 @@ def shard_indices(costs, world_size):
     return [order[r::world_size] for r in range(world_size)]
 
 
-def _method_code(method):
+def _method_code(method, route="auto"):
     name = getattr(method, "name", method)
     if name in ("flattening", Method.flattening):
-        return _lib.SP_METHOD_FLATTENING
+        return {"auto": _lib.SP_METHOD_FLATTENING, "dense": _lib.SP_METHOD_FLATTENING_DENSE,
+                "sparse": _lib.SP_METHOD_FLATTENING_SPARSE}[route]
     if name in ("subflattening", Method.subflattening):
         return _lib.SP_METHOD_SUBFLATTENING
     raise ValueError(f"unsupported method {method!r} (flattening or subflattening)")
@@ -108,14 +109,18 @@ def gather_scores(local_scores, shards, n_total, group=None, device_tensor=None)
 
 
 def score_splits(pattern_probabilities, splits, method=Method.flattening, distributed=None, group=None,
-                 return_status=False):
+                 return_status=False, route="auto"):
     """Scores of `splits` (any iterable of the reference's split forms) for one alignment.
+
+    route (flattening method only): "auto" - the sparse in-LDS kernel for count tables, with splits it
+    hands back re-scored on the dense route; "dense" - scatter + MFMA Gram + top-4 eigen through HBM;
+    "sparse" - sparse kernel only (raises if a split does not fit).
 
     distributed=None: use torch.distributed if it is initialised with world_size > 1.
     Every rank must call this with the same splits; every rank receives all scores."""
     splits = list(splits)
     al = as_device_alignment(pattern_probabilities)
-    code = _method_code(method)
+    code = _method_code(method, route)
     taxa_arr, a_arr = encode_splits(splits, pattern_probabilities, al.n_taxa)
     use_dist = distributed
     if use_dist is None:

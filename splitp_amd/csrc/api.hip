@@ -518,12 +518,15 @@ static int run_dense_route(sp_alignment* al, const Plan& plan, bool plan_on_devi
     SP_CHECK(launch_reindex(ctx, al->keys.as<u64>(), D, al->n_taxa, sdev, plan.splits, bm_ptr(ctx), pf_ptr(ctx, plan),
                             dims, rr_ptr(ctx), cc_ptr(ctx, S, D)));
     const int nl = ctx->cache ? ctx->cache->nl : 0;
+    bool g_i32 = false;
     if (al->exact && nl > 0) {
         SP_CHECK(ctx->mats.ensure(plan.mat_elems + 256));
         SP_CHECK(launch_zero_scatter_i8(ctx, nl, sdev, plan.splits, D, dims, rr_ptr(ctx), cc_ptr(ctx, S, D),
                                         al->counts.as<u32>(), ctx->mats.as<uint8_t>()));
-        SP_CHECK(launch_gram_i8(ctx, nl, sdev, ctx->gram_items.as<GramItem>(), (int64_t)plan.gram_items.size(), dims,
-                                ctx->mats.as<uint8_t>(), ctx->grams.as<double>()));
+        // G entries are bounded by max_i sum_c C[i][c]^2 <= max_count * N: store int32 when that fits
+        g_i32 = (unsigned long long)al->max_count * (unsigned long long)al->N < (1ull << 31);
+        SP_CHECK(launch_gram_i8(ctx, nl, g_i32, sdev, ctx->gram_items.as<GramItem>(), (int64_t)plan.gram_items.size(),
+                                dims, ctx->mats.as<uint8_t>(), ctx->grams.p));
     } else if (al->exact) {
         SP_CHECK(ctx->mats.ensure(plan.mat_elems * 4));
         SP_CHECK(launch_zero_scatter<u32>(ctx, sdev, plan.splits, D, dims, rr_ptr(ctx), cc_ptr(ctx, S, D),
@@ -537,12 +540,98 @@ static int run_dense_route(sp_alignment* al, const Plan& plan, bool plan_on_devi
         SP_CHECK(launch_gram<double>(ctx, sdev, ctx->gram_items.as<GramItem>(), (int64_t)plan.gram_items.size(), dims,
                                      ctx->mats.as<double>(), ctx->grams.as<double>()));
     }
-    SP_CHECK(launch_eigen(ctx, sdev, plan.splits, dims, ctx->grams.as<double>(),
+    SP_CHECK(launch_eigen(ctx, sdev, plan.splits, dims, ctx->grams.p, g_i32,
                           ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
                           reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
                                                        plan.row_items.size()),
                           ctx->scores.as<double>(), ctx->status.as<int>()));
     return SP_OK;
+}
+
+__global__ void k_patch_scores(const int* __restrict__ idx, int n, const double* __restrict__ src,
+                               const int* __restrict__ src_status, double* __restrict__ dst,
+                               int* __restrict__ dst_status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        dst[idx[i]] = src[i];
+        dst_status[idx[i]] = src_status[i];
+    }
+}
+
+// Sparse route + hand-back: splits the in-LDS kernel flags (status bit 1: lists do not fit, or no
+// convergence with the 4-wide block) are re-scored on the dense route and patched in.
+static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device, const int32_t* split_taxa,
+                            const int32_t* split_a, int64_t S, bool strict) {
+    sp_ctx* ctx = al->ctx;
+    const Plan& plan = pc.plan;
+    if (!plan_on_device) {
+        SP_CHECK(ctx->splits.ensure((size_t)S * sizeof(SplitDev)));
+        SP_HIP(hipMemcpyAsync(ctx->splits.p, plan.splits.data(), (size_t)S * sizeof(SplitDev), hipMemcpyHostToDevice,
+                              ctx->stream));
+        SP_CHECK(ctx->gram_items.ensure((size_t)S * sizeof(int)));
+        SP_HIP(hipMemcpyAsync(ctx->gram_items.p, plan.order.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice,
+                              ctx->stream));
+    }
+    SP_CHECK(ctx->scores.ensure((size_t)S * 8));
+    SP_CHECK(ctx->status.ensure((size_t)S * 4));
+    SP_CHECK(launch_sparse_score(ctx, al->keys.as<u64>(), al->counts.as<u32>(), al->D, al->n_taxa,
+                                 ctx->splits.as<SplitDev>(), ctx->gram_items.as<int>(), S, ctx->scores.as<double>(),
+                                 ctx->status.as<int>()));
+    pc.valid = true;
+    std::vector<int> st((size_t)S);
+    SP_HIP(hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int> redo;
+    for (int64_t i = 0; i < S; ++i)
+        if (st[i] & 2) redo.push_back((int)i);
+    if (redo.empty()) return SP_OK;
+    SP_REQUIRE(!strict, SP_ELIMIT, "sparse route: %zu of %lld splits do not fit the in-LDS kernel (first: %d)",
+               redo.size(), (long long)S, redo[0]);
+    // dense route on the handed-back subset (overwrites the context pools, hence the parking buffer)
+    const int n = al->n_taxa;
+    std::vector<int32_t> t2(redo.size() * (size_t)n), a2(redo.size());
+    for (size_t k = 0; k < redo.size(); ++k) {
+        memcpy(&t2[k * n], split_taxa + (size_t)redo[k] * n, (size_t)n * 4);
+        a2[k] = split_a[redo[k]];
+    }
+    DevBuf keep_scores, keep_status, idx;
+    int rc = SP_OK;
+    if ((rc = keep_scores.ensure((size_t)S * 8)) || (rc = keep_status.ensure((size_t)S * 4)) ||
+        (rc = idx.ensure(redo.size() * 4))) {
+        keep_scores.release(); keep_status.release(); idx.release();
+        return rc;
+    }
+    auto bail = [&](int code) {
+        keep_scores.release(); keep_status.release(); idx.release();
+        return code;
+    };
+    if (hipMemcpyAsync(keep_scores.p, ctx->scores.p, (size_t)S * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(keep_status.p, ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(idx.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        sp_set_error("sparse route hand-back: device copy failed");
+        return bail(SP_EHIP);
+    }
+    Plan sub;
+    const int nl = limbs_for(al);
+    PlanCache tmp_pc;
+    tmp_pc.nl = nl;
+    PlanCache* saved = ctx->cache;
+    ctx->cache = &tmp_pc;  // run_dense_route reads the limb count from the context's cache slot
+    rc = plan_splits(n, al->D, t2.data(), a2.data(), (int64_t)redo.size(), true, true, true, sub, nl > 0 ? nl : 0);
+    if (rc == SP_OK) rc = run_dense_route(al, sub, false);
+    ctx->cache = saved;
+    pc.valid = false;  // the device copy of the cached sparse plan was overwritten
+    if (rc != SP_OK) return bail(rc);
+    hipLaunchKernelGGL(k_patch_scores, dim3((unsigned)((redo.size() + 255) / 256)), dim3(256), 0, ctx->stream,
+                       idx.as<int>(), (int)redo.size(), ctx->scores.as<double>(), ctx->status.as<int>(),
+                       keep_scores.as<double>(), keep_status.as<int>());
+    if (hipMemcpyAsync(ctx->scores.p, keep_scores.p, (size_t)S * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(ctx->status.p, keep_status.p, (size_t)S * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        sp_set_error("sparse route hand-back: patch failed");
+        return bail(SP_EHIP);
+    }
+    return bail(SP_OK);
 }
 
 int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S);  // subflat.hip
@@ -555,26 +644,39 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
     SP_HIP(hipSetDevice(ctx->device));
     if (n_splits == 0) return SP_OK;
     SP_REQUIRE(al->D > 0, SP_EINVAL, "empty pattern table");
-    if (method == SP_METHOD_FLATTENING) {
+    if (method == SP_METHOD_FLATTENING || method == SP_METHOD_FLATTENING_DENSE ||
+        method == SP_METHOD_FLATTENING_SPARSE) {
         if (!ctx->cache) ctx->cache = new PlanCache();
         PlanCache& pc = *ctx->cache;
         const size_t nt = (size_t)n_splits * al->n_taxa;
-        const int nl = limbs_for(al);
+        const bool sparse_ok = al->exact && al->max_count < 65536u && al->D <= 65535;
+        SP_REQUIRE(method != SP_METHOD_FLATTENING_SPARSE || sparse_ok, SP_ELIMIT,
+                   "sparse route needs integer counts < 65536 and at most 65535 patterns");
+        const bool use_sparse = method == SP_METHOD_FLATTENING_SPARSE ||
+                                (method == SP_METHOD_FLATTENING && sparse_ok && ctx->gram_mode == 0);
+        const int nl = use_sparse ? -1 : limbs_for(al);
         const bool hit = pc.valid && pc.nl == nl && pc.n == al->n_taxa && pc.D == al->D &&
                          pc.a.size() == (size_t)n_splits &&
                          memcmp(pc.a.data(), split_a, n_splits * 4) == 0 &&
                          memcmp(pc.taxa.data(), split_taxa, nt * 4) == 0;
         if (!hit) {
             pc.valid = false;
-            SP_CHECK(plan_splits(al->n_taxa, al->D, split_taxa, split_a, n_splits, true, true, true, pc.plan, nl));
-            pc.nl = nl;
+            SP_CHECK(plan_splits(al->n_taxa, al->D, split_taxa, split_a, n_splits, true, !use_sparse, !use_sparse,
+                                 pc.plan, nl > 0 ? nl : 0));
+            if (use_sparse) build_gram_items(pc.plan);  // only for the heaviest-first order
             pc.taxa.assign(split_taxa, split_taxa + nt);
             pc.a.assign(split_a, split_a + n_splits);
             pc.n = al->n_taxa;
             pc.D = al->D;
+            pc.nl = nl;
         }
-        SP_CHECK(run_dense_route(al, pc.plan, hit));
-        pc.valid = true;
+        if (!use_sparse) {
+            SP_CHECK(run_dense_route(al, pc.plan, hit));
+            pc.valid = true;
+        } else {
+            SP_CHECK(run_sparse_route(al, pc, hit, split_taxa, split_a, n_splits,
+                                      method == SP_METHOD_FLATTENING_SPARSE));
+        }
     } else if (method == SP_METHOD_SUBFLATTENING) {
         SP_CHECK(run_subflat_route(al, split_taxa, split_a, n_splits));
     } else {
@@ -643,7 +745,7 @@ extern "C" int sp_score_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, i
     SP_CHECK(launch_gram<double>(ctx, ctx->splits.as<SplitDev>(), ctx->gram_items.as<GramItem>(),
                                  (int64_t)plan.gram_items.size(), ctx->dims.as<int2>(), ctx->mats.as<double>(),
                                  ctx->grams.as<double>()));
-    SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.as<double>(),
+    SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.p, false,
                           ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
                           reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
                                                        plan.row_items.size()),
@@ -733,7 +835,7 @@ extern "C" int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* c
     SP_CHECK(launch_gram<double>(ctx, ctx->splits.as<SplitDev>(), ctx->gram_items.as<GramItem>(),
                                  (int64_t)plan.gram_items.size(), ctx->dims.as<int2>(), ctx->mats.as<double>(),
                                  ctx->grams.as<double>()));
-    SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.as<double>(),
+    SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.p, false,
                           ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
                           reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
                                                        plan.row_items.size()),

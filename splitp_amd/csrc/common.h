@@ -131,7 +131,7 @@ struct Plan {
 
 struct PlanCache {
     bool valid = false;
-    int nl = 0;  // limb count the plan was laid out for (0 = element-typed u32 / f64 matrices)
+    int nl = 0;  // limb count the plan was laid out for (0 = element-typed u32 / f64 matrices, -1 = sparse route)
     int n = 0;
     int64_t D = 0;
     std::vector<int32_t> taxa, a;
@@ -165,12 +165,14 @@ int launch_dense_scatter(sp_ctx* ctx, const u64* keys, const u32* counts, int64_
                          const SplitDev* split_dev, const SplitDev& split, u32* out);
 int launch_zero_scatter_i8(sp_ctx* ctx, int nl, const SplitDev* splits_dev, const std::vector<SplitDev>& splits,
                            int64_t D, const int2* dims, const u32* rr, const u32* cc, const u32* vals, uint8_t* mats);
-int launch_gram_i8(sp_ctx* ctx, int nl, const SplitDev* splits_dev, const GramItem* items_dev, int64_t n_items,
-                   const int2* dims, const uint8_t* mats, double* grams);
+int launch_gram_i8(sp_ctx* ctx, int nl, bool g_i32, const SplitDev* splits_dev, const GramItem* items_dev,
+                   int64_t n_items, const int2* dims, const uint8_t* mats, void* grams);
+int launch_sparse_score(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, int n_taxa,
+                        const SplitDev* splits_dev, const int* order_dev, int64_t S, double* scores, int* status);
 template <typename T>
 int launch_gram(sp_ctx* ctx, const SplitDev* splits_dev, const GramItem* items_dev, int64_t n_items, const int2* dims,
                 const T* mats, double* grams);
 void build_gram_items(Plan& plan);
 int launch_eigen(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits, const int2* dims,
-                 const double* grams, const GramItem* rowblocks_dev, int64_t n_rowblocks, const int* order_dev,
-                 double* scores, int* status);
+                 const void* grams, bool g_i32, const GramItem* rowblocks_dev, int64_t n_rowblocks,
+                 const int* order_dev, double* scores, int* status);

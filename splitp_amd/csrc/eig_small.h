@@ -1,0 +1,333 @@
+// Small dense building blocks shared by the eigen kernels (eigen.hip) and the sparse route (sparse.hip):
+// 16-wide block operations on an R x NB block held in LDS, all on v_mfma_f64_16x16x4_f64, plus the one-wave
+// Jacobi eigen-solver for the 16 x 16 (or 8 x 8) projected matrices.  NB is the number of live columns
+// (16 or 8; with 8 the MFMA tiles are half empty, which is irrelevant at these sizes), VP the row pitch of
+// the block in doubles (odd, so that tile-wise and row-wise LDS reads are conflict-free).
+#pragma once
+#include "common.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define EIG_THREADS 512
+#define EIG_WAVES 8
+#define EIG_B 16
+#define EIG_VP 17        // V row pitch in doubles (odd pitch: row-wise and tile-wise reads conflict-free)
+#define EIG_MAXT 8       // row tiles of 16 per wave -> R_pad <= 8 * 8 * 16 = 1024
+#define EIG_MAXR 1024
+#define EIG_MAXIT 400
+
+struct EigShared {
+    double H[EIG_B * EIG_VP];
+    double Q[EIG_B * EIG_VP];
+    double L[EIG_B * EIG_VP];
+    double T[EIG_B * EIG_VP];   // L^-T (upper triangular), dead columns zeroed
+    double top4;
+    double part[(EIG_WAVES / 2) * 256];  // cross-wave reduction buffer (two waves share a slot)
+    double red[EIG_WAVES];
+    double theta[EIG_B];
+    int dead[EIG_B];
+    int flag;
+};
+
+__device__ __forceinline__ double hash_unit(unsigned a, unsigned b) {
+    unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (double)x * (2.0 / 4294967296.0) - 1.0;
+}
+
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
+// Sum one 16 x 16 MFMA accumulator over the 8 waves of the block into out (16 x EIG_VP, LDS).
+// Waves 4-7 deposit first, waves 0-3 add theirs on top, then 256 threads add the 4 slots in a
+// fixed order (deterministic).  Ends with a barrier.
+__device__ __forceinline__ void reduce16(const double4_t& acc, EigShared& sh, double* out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    if (w >= EIG_WAVES / 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sh.part[(w - EIG_WAVES / 2) * 256 + (fk + 4 * r) * 16 + fr] = acc[r];
+    }
+    __syncthreads();
+    if (w < EIG_WAVES / 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sh.part[w * 256 + (fk + 4 * r) * 16 + fr] += acc[r];
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        double s = 0;
+#pragma unroll
+        for (int i = 0; i < EIG_WAVES / 2; ++i) s += sh.part[i * 256 + threadIdx.x];
+        out[(threadIdx.x >> 4) * EIG_VP + (threadIdx.x & 15)] = s;
+    }
+    __syncthreads();
+}
+
+// S = X^T X for the R x 16 array X in LDS (rows >= Rp are not touched): per-wave MFMA partials
+// into sh.part, then summed into `out` (16 x EIG_VP).  Ends with a barrier.
+template <int NB, int VP>
+__device__ __forceinline__ void gram_nb(const double* X, int Rp, EigShared& sh, double* out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    double4_t acc = {0, 0, 0, 0};
+    for (int r0 = w * 4; r0 < Rp; r0 += EIG_WAVES * 4) {
+        const double x = (NB == 16 || fr < NB) ? X[(r0 + fk) * VP + fr] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+    }
+    reduce16(acc, sh, out);
+}
+
+// X <- X * B for the R x 16 array X in LDS and a 16 x 16 matrix B in LDS, by MFMA, in place
+// (each wave owns whole 16-row tiles: all reads of a tile precede its writes).  Ends with a barrier.
+template <int NB, int VP>
+__device__ __forceinline__ void rowmul_nb(double* X, int Rp, const double* B) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    constexpr int KB = NB / 4;
+    double bfrag[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) bfrag[kb] = B[(kb * 4 + fk) * EIG_VP + fr];
+    for (int tile = w; tile < (Rp >> 4); tile += EIG_WAVES) {
+        double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const double a = X[(tile * 16 + fr) * VP + kb * 4 + fk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[kb], acc, 0, 0, 0);
+        }
+        if (NB == 16 || fr < NB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[(tile * 16 + fk + 4 * r) * VP + fr] = acc[r];
+        }
+    }
+    __syncthreads();
+}
+
+
+// Accurate 1/sqrt(x) from an f32 seed and two Newton steps (fp64 sqrt/div sequences are serial
+// bottlenecks in a one-wave Jacobi).
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = (double)__frsqrt_rn((float)x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+
+// Jacobi rotation (c, s) for the symmetric 2 x 2 [app apq; apq aqq].  The angle is evaluated in f32
+// (cheap), c = rsqrt(1 + t^2) and s = t c in fp64, so the rotation is orthogonal to fp64 accuracy for
+// ANY t - an inexact angle only leaves a residual ~1e-7 |apq| that the next sweep removes.
+__device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double& c, double& s) {
+    c = 1.0;
+    s = 0.0;
+    if (apq * apq > 1e-40 * fabs(app * aqq) && apq != 0.0) {
+        const float num = (float)(aqq - app), den = 2.0f * (float)apq;
+        float tf;
+        if (fabsf(num) > 1e18f * fabsf(den)) {
+            tf = den / (2.0f * num);  // tiny angle; avoids inf / nan in the f32 quotient
+        } else {
+            const float tau = num / den;
+            tf = (tau >= 0.f ? 1.0f : -1.0f) / (fabsf(tau) + sqrtf(1.0f + tau * tau));
+        }
+        const double t = (double)tf;
+        c = rsqrt_nr(1.0 + t * t);
+        s = t * c;
+    }
+}
+
+// Eigen-decomposition of the symmetric positive semi-definite 16 x 16 matrix sh.H by parallel-order
+// (round-robin) Jacobi, wave 0 only: eigenvalues to sh.theta, eigenvectors to the columns of sh.Q.
+// Lane (a, b) owns the 2 x 2 block {p_a, q_a} x {p_b, q_b} of H for the round's 8 disjoint pairs and
+// computes new block = J_a^T block J_b in registers; it derives BOTH rotations itself from the two
+// diagonal blocks (extra broadcast LDS reads instead of cross-lane shuffles), so a round is one LDS
+// round trip, ~100 flops and one wave-level sync.  Convergence is judged relatively (|h_ij|^2 against
+// h_ii h_jj), which is what gives Jacobi its high relative accuracy on PSD matrices.  Ends with a barrier.
+template <int NB>
+__device__ __forceinline__ void jacobi_nb(EigShared& sh) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        constexpr int NP = NB / 2;  // disjoint pairs per round; lanes 0 .. NP*NP-1 each own a 2 x 2 block
+        const bool act = lane < NP * NP;
+        const int pa = act ? lane / NP : 0, pb = act ? lane % NP : 0;
+        for (int e = lane; e < EIG_B * EIG_B; e += 64) sh.Q[(e >> 4) * EIG_VP + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+        wave_sync_lds();
+        int sweep_count = 0;
+        for (int sweep = 0; sweep < 15; ++sweep) {
+            sweep_count = sweep;
+            double rel = 0, dmx = 0;
+            for (int k = 0; k < NB; ++k) dmx = fmax(dmx, fabs(sh.H[k * EIG_VP + k]));
+            for (int e = lane; e < EIG_B * EIG_B; e += 64) {
+                const int i = e >> 4, j = e & 15;
+                if (i < j && j < NB) {
+                    const double v = sh.H[i * EIG_VP + j];
+                    const double dd = fabs(sh.H[i * EIG_VP + i] * sh.H[j * EIG_VP + j]);
+                    // couplings below 1e-20 of the largest eigenvalue cannot matter (directions that small are
+                    // noise or dead) and would otherwise keep the sweeps going on rounding residue
+                    if (v * v > 1e-40 * dmx * dmx) rel = fmax(rel, dd > 0 ? v * v / dd : 1.0);
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) rel = fmax(rel, __shfl_xor(rel, d, 64));
+            if (!(rel > 1e-22)) break;
+            for (int round = 0; round < NB - 1; ++round) {
+                int ip, iq, jp, jq;  // rows of pair a, cols of pair b
+                if (pa == 0) { ip = NB - 1; iq = round; }
+                else { ip = (round + pa) % (NB - 1); iq = (round + (NB - 1) - pa) % (NB - 1); }
+                if (ip > iq) { const int t = ip; ip = iq; iq = t; }
+                if (pb == 0) { jp = NB - 1; jq = round; }
+                else { jp = (round + pb) % (NB - 1); jq = (round + (NB - 1) - pb) % (NB - 1); }
+                if (jp > jq) { const int t = jp; jp = jq; jq = t; }
+                const double hpp = sh.H[ip * EIG_VP + jp], hpq = sh.H[ip * EIG_VP + jq];
+                const double hqp = sh.H[iq * EIG_VP + jp], hqq = sh.H[iq * EIG_VP + jq];
+                const double a_pp = sh.H[ip * EIG_VP + ip], a_qq = sh.H[iq * EIG_VP + iq], a_pq = sh.H[ip * EIG_VP + iq];
+                const double b_pp = sh.H[jp * EIG_VP + jp], b_qq = sh.H[jq * EIG_VP + jq], b_pq = sh.H[jp * EIG_VP + jq];
+                const double q0p = sh.Q[(2 * pa) * EIG_VP + jp], q0q = sh.Q[(2 * pa) * EIG_VP + jq];
+                const double q1p = sh.Q[(2 * pa + 1) * EIG_VP + jp], q1q = sh.Q[(2 * pa + 1) * EIG_VP + jq];
+                double ca, sa, cb, sb;
+                jacobi_cs(a_pp, a_qq, a_pq, ca, sa);
+                jacobi_cs(b_pp, b_qq, b_pq, cb, sb);
+                // rows: [p'; q'] = [c -s; s c] [p; q]   (J^T from the left, J = [c s; -s c])
+                const double rpp = ca * hpp - sa * hqp, rpq = ca * hpq - sa * hqq;
+                const double rqp = sa * hpp + ca * hqp, rqq = sa * hpq + ca * hqq;
+                wave_sync_lds();  // every lane has read before anyone writes
+                // cols: [p' q'] = [p q] [c s; -s c]
+                if (act) {
+                sh.H[ip * EIG_VP + jp] = cb * rpp - sb * rpq;
+                sh.H[ip * EIG_VP + jq] = sb * rpp + cb * rpq;
+                sh.H[iq * EIG_VP + jp] = cb * rqp - sb * rqq;
+                sh.H[iq * EIG_VP + jq] = sb * rqp + cb * rqq;
+                // Q <- Q J: lane (a, b) updates rows {2a, 2a+1} of the column pair b
+                sh.Q[(2 * pa) * EIG_VP + jp] = cb * q0p - sb * q0q;
+                sh.Q[(2 * pa) * EIG_VP + jq] = sb * q0p + cb * q0q;
+                sh.Q[(2 * pa + 1) * EIG_VP + jp] = cb * q1p - sb * q1q;
+                sh.Q[(2 * pa + 1) * EIG_VP + jq] = sb * q1p + cb * q1q;
+                }
+                wave_sync_lds();
+            }
+        }
+        if (lane < EIG_B) sh.theta[lane] = lane < NB ? sh.H[lane * EIG_VP + lane] : 0.0;
+    }
+    __syncthreads();
+}
+
+// One Rayleigh-Ritz + orthonormalisation step on the R x 16 block X = G V (LDS), in place:
+//     S = X^T X = V^T G^2 V            (MFMA)
+//     S = P D P^T                      (one 16 x 16 Jacobi)
+//     X <- X P D^-1/2                  (MFMA; columns = orthonormal Ritz vectors of G^2 on span(V), images under G)
+//     polish: X <- X (1.5 I - 0.5 X^T X) until ||X^T X - I||_max <= 2e-15   (Newton-Schulz, MFMA)
+// sqrt(D_i) are Ritz values of G (from G^2 on the same subspace: lower bounds, second-order accurate like
+// the ones of V^T G V); sh.top4 = sum of the four largest.  Directions with D_i <= 1e-28 D_max are dead
+// (zero columns: exactly singular input, or R < 16).  No Cholesky, no serial 16-step chains, and no
+// data-dependent fallback path.  When `values_only` the block is left untouched after the Jacobi.
+template <int NB, int VP>
+__device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh) {
+    gram_nb<NB, VP>(X, Rp, sh, sh.H);
+    jacobi_nb<NB>(sh);
+    // top-4 sum + T = P D^-1/2 (256 threads)
+    {
+        double dmax = 0;
+        for (int k = 0; k < EIG_B; ++k) dmax = fmax(dmax, sh.theta[k]);
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            const double th = lane < EIG_B ? sqrt(fmax(sh.theta[lane], 0.0)) : -1.0;
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < EIG_B; ++j) {
+                const double o = __shfl(th, j, 64);
+                rank += (o > th || (o == th && j < lane)) ? 1 : 0;
+            }
+            double pick = (lane < EIG_B && rank < 4) ? th : 0.0;
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) pick += __shfl_xor(pick, d, 64);
+            if (lane == 0) sh.top4 = pick;
+        }
+        if (threadIdx.x < 256) {
+            const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+            const double dj = sh.theta[j];
+            const double rj = (dj > 1e-28 * dmax && dj > 0) ? rsqrt_nr(dj) : 0.0;
+            sh.T[i * EIG_VP + j] = (i < NB && j < NB) ? sh.Q[i * EIG_VP + j] * rj : 0.0;
+        }
+        __syncthreads();
+    }
+    rowmul_nb<NB, VP>(X, Rp, sh.T);
+    for (int iter = 0; iter < 10; ++iter) {
+        gram_nb<NB, VP>(X, Rp, sh, sh.H);
+        double err = 0;
+        if (threadIdx.x < 256) {
+            const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+            const double sv = sh.H[i * EIG_VP + j];
+            const double target = (i == j && sh.H[i * EIG_VP + i] > 0.25) ? 1.0 : 0.0;  // dead columns stay 0
+            err = (i < NB && j < NB) ? fabs(sv - target) : 0.0;
+            sh.T[i * EIG_VP + j] = (i < NB && j < NB) ? (i == j ? 1.5 : 0.0) - 0.5 * sv : 0.0;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) err = fmax(err, __shfl_xor(err, d, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = err;
+        __syncthreads();
+        double emx = 0;
+        for (int k = 0; k < EIG_WAVES; ++k) emx = fmax(emx, sh.red[k]);
+        __syncthreads();
+        if (emx <= 2e-15) break;
+        rowmul_nb<NB, VP>(X, Rp, sh.T);
+    }
+}
+
+struct EigState {
+    double trace, prev_sum, prev_delta, top4;
+    int it, done, R, pad;
+};
+
+#define EIG_NFAST 5
+
+__device__ __forceinline__ double block_sum(double v, EigShared& sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    __syncthreads();
+    if (lane == 0) sh.red[w] = v;
+    __syncthreads();
+    double t = 0;
+    for (int i = 0; i < EIG_WAVES; ++i) t += sh.red[i];
+    return t;
+}
+
+// Convergence bookkeeping shared by k_eig_rr and k_eig_finish (uniform across the block).
+__device__ __forceinline__ bool update_convergence(double s4, int it, double& prev_sum, double& prev_delta) {
+    bool conv = false;
+    const double delta = fabs(s4 - prev_sum);
+    if (it >= 2) {
+        double ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
+        ratio = fmin(fmax(ratio, 0.0), 0.9999);
+        const double tail = delta * ratio / (1.0 - ratio);
+        if (delta <= 4e-16 * s4 || (it >= 3 && tail <= 1e-14 * s4)) conv = true;
+    }
+    prev_delta = delta;
+    prev_sum = s4;
+    return conv;
+}
+
+__device__ __forceinline__ void write_score(double top4, double tr, int it, bool converged, double* scores,
+                                            int* status, int sid) {
+    const double op = 1.0 - top4 / tr;
+    scores[sid] = sqrt(op > 0 ? op : 0.0);
+    status[sid] = (converged ? 0 : 1) | (it << 8);
+}
+
+// V (LDS, R x 16, pitch EIG_VP) <-> Vt (global, 16 x vp column-major: the B operand of k_eig_gv reads
+// 4 consecutive k per lane)
+__device__ __forceinline__ void store_vt(const double* V, int Rp, double* __restrict__ Vt, int vp) {
+    for (int e = threadIdx.x; e < Rp * EIG_B; e += EIG_THREADS) {
+        const int col = e / Rp, row = e % Rp;
+        Vt[(int64_t)col * vp + row] = V[row * EIG_VP + col];
+    }
+}
+__device__ __forceinline__ void load_vt(double* V, int Rp, const double* __restrict__ Vt, int vp) {
+    for (int e = threadIdx.x; e < Rp * EIG_B; e += EIG_THREADS) {
+        const int col = e / Rp, row = e % Rp;
+        V[row * EIG_VP + col] = Vt[(int64_t)col * vp + row];
+    }
+}
+

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void k_gram(const SplitDev* __restrict__ split
     __shared__ __attribute__((aligned(16))) double sB[G_TILE * G_PITCH];
     const GramItem it = items[blockIdx.x];
     const int sid = it.sid;
+    if (sid < 0) return;  // padding item of the XCD interleave
     const SplitDev& sp = splits[sid];
     const int ti = it.ti, tj = it.tj;
     const int2 d = dims[sid];
@@ -142,6 +143,19 @@ __global__ __launch_bounds__(256) void k_gram(const SplitDev* __restrict__ split
             }
 }
 
+// Work lists.  Workgroups are dealt to the 8 XCDs round-robin (blocks b and b + 8 share an XCD and its
+// 4 MiB L2 - observed placement, used for speed only), and every tile of a split re-reads that
+// split's row panels; so the list is built as 8 interleaved streams, stream x holding all tiles of the
+// splits {x, x + 8, ...} (heaviest splits first): a split's matrix is then pulled into ONE L2
+// instead of all eight.  Shorter streams are padded with sid = -1 items (no-ops).
+static void interleave8(const std::vector<std::vector<GramItem>>& streams, std::vector<GramItem>& out) {
+    size_t longest = 0;
+    for (const auto& st : streams) longest = std::max(longest, st.size());
+    out.assign(longest * 8, GramItem{-1, 0, 0});
+    for (int x = 0; x < 8; ++x)
+        for (size_t j = 0; j < streams[x].size(); ++j) out[j * 8 + x] = streams[x][j];
+}
+
 void build_gram_items(Plan& plan) {
     std::vector<int> order(plan.splits.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
@@ -151,16 +165,19 @@ void build_gram_items(Plan& plan) {
         if (x.rcap != y.rcap) return x.rcap > y.rcap;
         return x.pitch > y.pitch;
     });
-    plan.gram_items.clear();
-    plan.row_items.clear();
     plan.order = order;
-    for (int sid : order) {
+    std::vector<std::vector<GramItem>> gs(8), rs(8);
+    for (size_t pos = 0; pos < order.size(); ++pos) {
+        const int sid = order[pos];
+        const int x = (int)(pos & 7);
         const int tiles = plan.splits[sid].rcap / G_TILE;
         for (int ti = 0; ti < tiles; ++ti) {
-            plan.row_items.push_back({sid, (int16_t)ti, 0});
-            for (int tj = ti; tj < tiles; ++tj) plan.gram_items.push_back({sid, (int16_t)ti, (int16_t)tj});
+            rs[x].push_back({sid, (int16_t)ti, 0});
+            for (int tj = ti; tj < tiles; ++tj) gs[x].push_back({sid, (int16_t)ti, (int16_t)tj});
         }
     }
+    interleave8(gs, plan.gram_items);
+    interleave8(rs, plan.row_items);
 }
 
 template <typename T>

@@ -1,0 +1,675 @@
+// Sparse route: flattening + split score of one split entirely inside one workgroup's LDS.
+//
+// Replaces, like the dense route, splitp/constructions.py:31-55 + splitp/phylogenetics.py:280-300 (and is
+// the device form of the reference's own sparse scorer, phylogenetics.py:303-312: top-4 singular values of
+// the sparse flattening + its Frobenius norm).  A flattening of a 100 k-site alignment has ~8 k non-zeros
+// in up to 10^6 cells, so instead of materialising the matrix (dense route: scatter -> Gram -> eigen, all
+// through HBM) the workgroup keeps the D non-zeros as CSC + CSR lists in LDS and runs block subspace
+// iteration on the implicit Gram operator:
+//       W = C^T V          (sparse, CSC: one 4-lane group per column, whole waves for heavy columns)
+//       Y = C W            (sparse, CSR)
+//       S = Y^T Y = V^T G^2 V,  S = P D P^T (4 x 4 Jacobi),  V <- Y P D^-1/2,  Newton-Schulz polish
+//       sum_i sqrt(D_i) -> sum of the 4 largest singular values^2 of C (converged when it stops moving)
+//   score = sqrt(max(0, 1 - top4 / trace)),  trace = sum of count^2 (exact integer).
+// Block width 4: on these matrices lambda_5..lambda_16 are of one magnitude, so guard vectors 5-8 buy almost
+// nothing (rate lambda_5/lambda_4 ~ 2e-3 vs lambda_9/lambda_4), while a 4-wide block halves every LDS array.
+// Small row sides (R <= 64, i.e. |A| <= 3 taxa) have a long column side whose W would not fit, but their
+// Gram matrix does: it is accumulated exactly (u64 LDS atomics over the pairs inside every column) and the
+// iteration runs on it densely.
+//
+// Everything is deterministic: the lists are ordered by a bitmap-rank construction (no atomic append), sums
+// run in a fixed order, heavy columns are reduced by a fixed shuffle tree, the Gram accumulation is integer.
+// A split whose lists / blocks do not fit the 160 KiB of LDS, or that has not converged after SPK_MAXIT
+// products, is flagged (status bit 1) and re-scored by the caller on the dense route.
+#include "common.h"
+
+#define SPK_THREADS 512
+#define SPK_WAVES 8
+#define SPK_NB 4
+#define SPK_VP 5            // row pitch of V / Y in doubles
+#ifndef SPK_HEAVY
+#define SPK_HEAVY 48
+#endif
+//        // a column / row with more entries than this is handled by a whole wave
+#define SPK_MAXIT 40
+#define SPK_LDS_BYTES 163840
+#define SPK_SMALL_R 64
+
+struct SpkShared {
+    double red[SPK_WAVES * 12];
+    double S[12];        // 10 unique entries of the symmetric 4 x 4 (row-major upper: 00 01 02 03 11 12 13 22 23 33)
+    double T[16];        // 4 x 4 transform applied to the block
+    double top4;
+    unsigned long long trace;
+    int R, Kc, nheavy_c, nheavy_r, flag, pad;
+    int shifts[32];
+    unsigned int scan[SPK_WAVES + 1];
+};
+
+__device__ __forceinline__ double spk_hash(unsigned a, unsigned b) {
+    unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (double)x * (2.0 / 4294967296.0) - 1.0;
+}
+
+__device__ __forceinline__ double spk_rsqrt(double x) {
+    double y = (double)__frsqrt_rn((float)x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+
+__device__ __forceinline__ void spk_rowcol(u64 key, const int* shifts, int nr, int nc, u32& r, u32& c) {
+    u32 rr = 0, cc = 0;
+    for (int i = 0; i < nr; ++i) rr = (rr << 2) | (u32)((key >> shifts[i]) & 3ull);
+    for (int i = 0; i < nc; ++i) cc = (cc << 2) | (u32)((key >> shifts[nr + i]) & 3ull);
+    r = rr;
+    c = cc;
+}
+
+// exclusive scan of one u32 per thread over the 512-thread block; returns the exclusive prefix, total in `total`
+__device__ __forceinline__ u32 spk_scan(u32 v, SpkShared& sh, u32& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    u32 x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) sh.scan[w] = x;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+    for (int i = 0; i < SPK_WAVES; ++i) {
+        if (i < w) base += sh.scan[i];
+        tot += sh.scan[i];
+    }
+    total = tot;
+    return base + x - v;
+}
+
+// rank of key k in a presence bitmap with per-word exclusive popcount prefixes
+__device__ __forceinline__ u32 bm_rank(const u64* bm, const u32* pf, u32 k) {
+    return pf[k >> 6] + __popcll(bm[k >> 6] & ((1ull << (k & 63)) - 1));
+}
+
+// Sum the 10 unique entries of X^T X (X: R x 4 block, pitch SPK_VP) into sh.S.  Fixed reduction tree.
+__device__ __forceinline__ void spk_gram(const double* X, int R, SpkShared& sh) {
+    double s[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) s[i] = 0;
+    for (int row = threadIdx.x; row < R; row += SPK_THREADS) {
+        const double a = X[row * SPK_VP], b = X[row * SPK_VP + 1], c = X[row * SPK_VP + 2], d = X[row * SPK_VP + 3];
+        s[0] += a * a; s[1] += a * b; s[2] += a * c; s[3] += a * d;
+        s[4] += b * b; s[5] += b * c; s[6] += b * d;
+        s[7] += c * c; s[8] += c * d; s[9] += d * d;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s[i] += __shfl_xor(s[i], d, 64);
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) sh.red[w * 12 + i] = s[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        double t = 0;
+        for (int i = 0; i < SPK_WAVES; ++i) t += sh.red[i * 12 + threadIdx.x];
+        sh.S[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+// X <- X * T (T 4 x 4 row-major in sh.T), row-wise.  Ends with a barrier.
+__device__ __forceinline__ void spk_apply(double* X, int R, const SpkShared& sh) {
+    double t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = sh.T[i];
+    for (int row = threadIdx.x; row < R; row += SPK_THREADS) {
+        const double a = X[row * SPK_VP], b = X[row * SPK_VP + 1], c = X[row * SPK_VP + 2], d = X[row * SPK_VP + 3];
+        X[row * SPK_VP + 0] = a * t[0] + b * t[4] + c * t[8] + d * t[12];
+        X[row * SPK_VP + 1] = a * t[1] + b * t[5] + c * t[9] + d * t[13];
+        X[row * SPK_VP + 2] = a * t[2] + b * t[6] + c * t[10] + d * t[14];
+        X[row * SPK_VP + 3] = a * t[3] + b * t[7] + c * t[11] + d * t[15];
+    }
+    __syncthreads();
+}
+
+// 4 x 4 symmetric Jacobi in registers (cyclic order), executed by wave 0 (all lanes redundantly):
+// S (sh.S) = P D P^T.  Writes T = P D^-1/2 (dead directions zeroed) and sh.top4 = sum sqrt(D_i).
+__device__ __forceinline__ void spk_jacobi4(SpkShared& sh) {
+    if (threadIdx.x < 64) {
+        double a[4][4], p[4][4];
+        a[0][0] = sh.S[0]; a[0][1] = sh.S[1]; a[0][2] = sh.S[2]; a[0][3] = sh.S[3];
+        a[1][1] = sh.S[4]; a[1][2] = sh.S[5]; a[1][3] = sh.S[6];
+        a[2][2] = sh.S[7]; a[2][3] = sh.S[8]; a[3][3] = sh.S[9];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < i) a[i][j] = a[j][i];
+                p[i][j] = i == j ? 1.0 : 0.0;
+            }
+        for (int sweep = 0; sweep < 12; ++sweep) {
+            double rel = 0;
+            const double dmx = fmax(fmax(fabs(a[0][0]), fabs(a[1][1])), fmax(fabs(a[2][2]), fabs(a[3][3])));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = i + 1; j < 4; ++j) {
+                    const double v = a[i][j], dd = fabs(a[i][i] * a[j][j]);
+                    if (v * v > 1e-40 * dmx * dmx) rel = fmax(rel, dd > 0 ? v * v / dd : 1.0);
+                }
+            if (!(rel > 1e-22)) break;
+#pragma unroll
+            for (int ip = 0; ip < 3; ++ip)
+#pragma unroll
+                for (int iq = ip + 1; iq < 4; ++iq) {
+                    const double app = a[ip][ip], aqq = a[iq][iq], apq = a[ip][iq];
+                    double c = 1.0, s = 0.0;
+                    if (apq != 0.0 && apq * apq > 1e-40 * fabs(app * aqq)) {
+                        // angle in f32 (cheap); c = rsqrt(1 + t^2), s = t c in fp64: orthogonal to fp64 accuracy for
+                        // any t, an inexact angle only leaves a ~1e-7 |apq| residue for the next sweep
+                        const float num = (float)(aqq - app), den = 2.0f * (float)apq;
+                        float tf;
+                        if (fabsf(num) > 1e18f * fabsf(den)) {
+                            tf = den / (2.0f * num);
+                        } else {
+                            const float tau = num / den;
+                            tf = (tau >= 0.f ? 1.0f : -1.0f) / (fabsf(tau) + sqrtf(1.0f + tau * tau));
+                        }
+                        const double t = (double)tf;
+                        c = spk_rsqrt(1.0 + t * t);
+                        s = t * c;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {  // columns p, q of A and P
+                        const double akp = a[k][ip], akq = a[k][iq];
+                        a[k][ip] = c * akp - s * akq;
+                        a[k][iq] = s * akp + c * akq;
+                        const double pkp = p[k][ip], pkq = p[k][iq];
+                        p[k][ip] = c * pkp - s * pkq;
+                        p[k][iq] = s * pkp + c * pkq;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {  // rows p, q of A
+                        const double apk = a[ip][k], aqk = a[iq][k];
+                        a[ip][k] = c * apk - s * aqk;
+                        a[iq][k] = s * apk + c * aqk;
+                    }
+                }
+        }
+        const double dmax = fmax(fmax(a[0][0], a[1][1]), fmax(a[2][2], a[3][3]));
+        double top = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double dj = a[j][j];
+            const bool alive = dj > 1e-28 * dmax && dj > 0;
+            const double rj = alive ? spk_rsqrt(dj) : 0.0;
+            top += alive ? sqrt(dj) : 0.0;
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sh.T[i * 4 + j] = p[i][j] * rj;
+            }
+        }
+        if (threadIdx.x == 0) sh.top4 = top;
+    }
+    __syncthreads();
+}
+
+// Ritz values + next orthonormal block from Y (in X): S = X^T X, Jacobi, X <- X P D^-1/2, Newton-Schulz polish.
+__device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh) {
+    spk_gram(X, R, sh);
+    spk_jacobi4(sh);
+    spk_apply(X, R, sh);
+    for (int iter = 0; iter < 8; ++iter) {
+        spk_gram(X, R, sh);
+        // M = 1.5 I - 0.5 S ; err = max |S - I| over live columns (uniform: every thread reads sh.S)
+        const double s00 = sh.S[0], s01 = sh.S[1], s02 = sh.S[2], s03 = sh.S[3], s11 = sh.S[4], s12 = sh.S[5],
+                     s13 = sh.S[6], s22 = sh.S[7], s23 = sh.S[8], s33 = sh.S[9];
+        double err = fmax(fmax(fabs(s01), fabs(s02)), fmax(fabs(s03), fmax(fabs(s12), fmax(fabs(s13), fabs(s23)))));
+        err = fmax(err, s00 > 0.25 ? fabs(s00 - 1.0) : fabs(s00));
+        err = fmax(err, s11 > 0.25 ? fabs(s11 - 1.0) : fabs(s11));
+        err = fmax(err, s22 > 0.25 ? fabs(s22 - 1.0) : fabs(s22));
+        err = fmax(err, s33 > 0.25 ? fabs(s33 - 1.0) : fabs(s33));
+        if (err <= 2e-15) break;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double m[16] = {1.5 - 0.5 * s00, -0.5 * s01, -0.5 * s02, -0.5 * s03,
+                                  -0.5 * s01, 1.5 - 0.5 * s11, -0.5 * s12, -0.5 * s13,
+                                  -0.5 * s02, -0.5 * s12, 1.5 - 0.5 * s22, -0.5 * s23,
+                                  -0.5 * s03, -0.5 * s13, -0.5 * s23, 1.5 - 0.5 * s33};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sh.T[i] = m[i];
+        }
+        __syncthreads();
+        spk_apply(X, R, sh);
+    }
+    __syncthreads();
+}
+
+// Build one sorted list (grouped by `major`, ordered by `minor` inside a group) with the bitmap-rank
+// construction, in chunks of `major` values so that the occupancy bitmap fits `tmp`.  Inputs are the compact
+// coordinates pc[i] = rr << 16 | cc and the counts cnt[i] staged in LDS.
+//   MAJOR_IS_COL: true -> CSC (major = compact column, minor = compact row), false -> CSR.
+//   ptr[nmajor + 1] (u16, LDS), ent[D] (u32 = minor | count << 16, LDS), heavy[] = groups with > SPK_HEAVY entries.
+template <bool MAJOR_IS_COL>
+__device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned short* cnt, int D, int nmajor, int nminor,
+                                               unsigned short* ptr, u32* ent, unsigned short* heavy, int* nheavy,
+                                               u64* tmp, int tmp_words, SpkShared& sh) {
+    const int mw = (nminor + 63) >> 6;                 // bitmap words per major index
+    const int per_chunk = max(1, tmp_words / mw);       // major indices per chunk
+    if (threadIdx.x == 0) *nheavy = 0;
+    // pass 1: counts per major index -> ptr (exclusive scan)
+    for (int c0 = 0; c0 < nmajor; c0 += per_chunk) {
+        const int c1 = min(nmajor, c0 + per_chunk);
+        for (int i = threadIdx.x; i < (c1 - c0) * mw; i += SPK_THREADS) tmp[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < D; i += SPK_THREADS) {
+            const u32 v = pc[i];
+            const int mj = MAJOR_IS_COL ? (int)(v & 0xFFFF) : (int)(v >> 16);
+            const int mn = MAJOR_IS_COL ? (int)(v >> 16) : (int)(v & 0xFFFF);
+            if (mj >= c0 && mj < c1) atomicOr(&tmp[(mj - c0) * mw + (mn >> 6)], 1ull << (mn & 63));
+        }
+        __syncthreads();
+        for (int m = c0 + threadIdx.x; m < c1; m += SPK_THREADS) {
+            int c = 0;
+            for (int w = 0; w < mw; ++w) c += __popcll(tmp[(m - c0) * mw + w]);
+            ptr[m] = (unsigned short)c;  // counts for now
+            if (c > SPK_HEAVY) heavy[atomicAdd(nheavy, 1)] = (unsigned short)m;  // order irrelevant to results
+        }
+        __syncthreads();
+    }
+    {   // exclusive scan of the counts
+        const int per = (nmajor + SPK_THREADS - 1) / SPK_THREADS;
+        const int lo = min(nmajor, (int)threadIdx.x * per), hi = min(nmajor, lo + per);
+        u32 s = 0;
+        for (int i = lo; i < hi; ++i) s += ptr[i];
+        u32 tot;
+        u32 run = spk_scan(s, sh, tot);
+        for (int i = lo; i < hi; ++i) {
+            const u32 c = ptr[i];
+            ptr[i] = (unsigned short)run;
+            run += c;
+        }
+        if (threadIdx.x == 0) ptr[nmajor] = (unsigned short)tot;
+        __syncthreads();
+    }
+    // pass 2: placement by rank inside the major group
+    for (int c0 = 0; c0 < nmajor; c0 += per_chunk) {
+        const int c1 = min(nmajor, c0 + per_chunk);
+        if (nmajor > per_chunk) {  // bitmap of this chunk has to be rebuilt (single-chunk case: still valid)
+            for (int i = threadIdx.x; i < (c1 - c0) * mw; i += SPK_THREADS) tmp[i] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < D; i += SPK_THREADS) {
+                const u32 v = pc[i];
+                const int mj = MAJOR_IS_COL ? (int)(v & 0xFFFF) : (int)(v >> 16);
+                const int mn = MAJOR_IS_COL ? (int)(v >> 16) : (int)(v & 0xFFFF);
+                if (mj >= c0 && mj < c1) atomicOr(&tmp[(mj - c0) * mw + (mn >> 6)], 1ull << (mn & 63));
+            }
+            __syncthreads();
+        }
+        for (int i = threadIdx.x; i < D; i += SPK_THREADS) {
+            const u32 v = pc[i];
+            const int mj = MAJOR_IS_COL ? (int)(v & 0xFFFF) : (int)(v >> 16);
+            const int mn = MAJOR_IS_COL ? (int)(v >> 16) : (int)(v & 0xFFFF);
+            if (mj >= c0 && mj < c1) {
+                const u64* row = tmp + (mj - c0) * mw;
+                int rank = 0;
+                for (int w = 0; w < (mn >> 6); ++w) rank += __popcll(row[w]);
+                rank += __popcll(row[mn >> 6] & ((1ull << (mn & 63)) - 1));
+                ent[ptr[mj] + rank] = (u32)mn | ((u32)cnt[i] << 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// out[m][0..3] = sum over the entries e of major group m of count_e * in[minor_e][0..3].
+// Light groups: one 4-lane group each (two independent accumulation chains, combined in a fixed order).
+// Heavy groups (> SPK_HEAVY entries, listed in heavy[]): one wave each, 16 sub-groups striding the entries,
+// fixed shuffle-tree reduction.  Ends with a barrier.
+__device__ __forceinline__ void spk_spmm(const unsigned short* ptr, const u32* ent, int nmajor,
+                                         const unsigned short* heavy, int nheavy, const double* in, int in_pitch,
+                                         double* out, int out_pitch) {
+    const int j = threadIdx.x & 3, g = threadIdx.x >> 2;
+    for (int m = g; m < nmajor; m += SPK_THREADS / 4) {
+        const int p0 = ptr[m], p1 = ptr[m + 1];
+        if (p1 - p0 > SPK_HEAVY) continue;
+        double acc0 = 0, acc1 = 0;
+        int e = p0;
+        for (; e + 1 < p1; e += 2) {
+            const u32 v0 = ent[e], v1 = ent[e + 1];
+            acc0 += (double)(v0 >> 16) * in[(v0 & 0xFFFFu) * in_pitch + j];
+            acc1 += (double)(v1 >> 16) * in[(v1 & 0xFFFFu) * in_pitch + j];
+        }
+        if (e < p1) {
+            const u32 v0 = ent[e];
+            acc0 += (double)(v0 >> 16) * in[(v0 & 0xFFFFu) * in_pitch + j];
+        }
+        out[m * out_pitch + j] = acc0 + acc1;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int sg = lane >> 2;
+    for (int h = w; h < nheavy; h += SPK_WAVES) {
+        const int m = heavy[h];
+        const int p0 = ptr[m], p1 = ptr[m + 1];
+        double acc = 0;
+        for (int e = p0 + sg; e < p1; e += 16) {
+            const u32 v = ent[e];
+            acc += (double)(v >> 16) * in[(v & 0xFFFFu) * in_pitch + j];
+        }
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 8, 64);
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        if (lane < 4) out[m * out_pitch + j] = acc;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool spk_converged(double s4, int it, double& prev_sum, double& prev_delta) {
+    bool conv = false;
+    const double delta = fabs(s4 - prev_sum);
+    if (it >= 2) {
+        double ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
+        ratio = fmin(fmax(ratio, 0.0), 0.9999);
+        const double tail = delta * ratio / (1.0 - ratio);
+        if (delta <= 4e-16 * s4 || (it >= 3 && tail <= 1e-14 * s4)) conv = true;
+    }
+    prev_delta = delta;
+    prev_sum = s4;
+    return conv;
+}
+
+// status: bit 0 = iteration cap hit (score written but flagged), bit 1 = not handled here (re-score on the
+// dense route), bits 8.. = number of operator applications.
+#ifdef SPK_STAMPS
+__device__ long long g_spk_stamps[64];
+#define SSTAMP(i)                                                                              \
+    do {                                                                                       \
+        __syncthreads();                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_spk_stamps[i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+extern "C" int sp_debug_spk_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spk_stamps), sizeof(long long) * 64) == hipSuccess ? 0 : 2;
+}
+#else
+#define SSTAMP(i)
+#endif
+
+__global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restrict__ keys,
+                                                              const u32* __restrict__ counts, int64_t D, int n,
+                                                              const SplitDev* __restrict__ splits,
+                                                              const int* __restrict__ order,
+                                                              double* __restrict__ scores, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    SpkShared& sh = *reinterpret_cast<SpkShared*>(smem);
+    const int sid = order[blockIdx.x];
+    const SplitDev& sp = splits[sid];
+    const int nr = sp.nr, nc = sp.nc, rw = sp.rw, cw = sp.cw;
+    if (threadIdx.x < 32) {
+        const int t = threadIdx.x < nr + nc ? sp.taxa[threadIdx.x] : 0;
+        sh.shifts[threadIdx.x] = 2 * (n - 1 - t);
+    }
+    if (threadIdx.x == 0) sh.flag = 0;
+    __syncthreads();  // shifts are read by every wave below
+    size_t off = (sizeof(SpkShared) + 15) & ~(size_t)15;
+    auto carve = [&](size_t bytes) {
+        unsigned char* p = smem + off;
+        off = (off + bytes + 15) & ~(size_t)15;
+        return p;
+    };
+    // ---- stage the table in LDS once: cell[i] = (row key << 2 nc) | col key, cnt[i] = count -----------------------
+    // (every later pass reads LDS; a pass over global memory costs D / 512 serialised load latencies)
+    const int W = rw + cw;
+    const int Di = (int)D;
+    // a-priori bounds min(4^side, D) on the compact sizes (the actual R, Kc are known only after ranking)
+    const int kc_cap = (int)min((long long)D, nc >= 8 ? (long long)D : (1ll << (2 * nc)));
+    const int r_cap = (int)min((long long)D, nr >= 8 ? (long long)D : (1ll << (2 * nr)));
+    const bool small_sure = r_cap <= SPK_SMALL_R;   // then no CSR list is needed
+    const size_t need_build = off + (size_t)D * (small_sure ? 4 : 8) + ((size_t)D / SPK_HEAVY + 2) * 4 +
+                              (size_t)(kc_cap + r_cap + 2) * 2 + (size_t)D * 6 + (size_t)W * 12 + 256;
+    if (D > 65535 || n > 16 || need_build + 2048 > SPK_LDS_BYTES) {
+        if (threadIdx.x == 0) {
+            scores[sid] = 0.0;
+            status[sid] = 2;
+        }
+        return;
+    }
+    SSTAMP(0);
+    // region A (persistent): CSC list, CSR list, pointers, heavy lists.  Region B: staging + bitmaps while
+    // building, then V and W (or G).  Sizes that depend on R / Kc are carved after the ranks are known.
+    u32* csc_ent = reinterpret_cast<u32*>(carve((size_t)D * 4));
+    u32* csr_ent = small_sure ? nullptr : reinterpret_cast<u32*>(carve((size_t)D * 4));
+    unsigned short* heavy_c = reinterpret_cast<unsigned short*>(carve(((size_t)D / SPK_HEAVY + 2) * 2));
+    unsigned short* heavy_r = reinterpret_cast<unsigned short*>(carve(((size_t)D / SPK_HEAVY + 2) * 2));
+    unsigned short* csc_ptr = reinterpret_cast<unsigned short*>(carve((size_t)(kc_cap + 1) * 2));
+    unsigned short* csr_ptr = reinterpret_cast<unsigned short*>(carve((size_t)(r_cap + 1) * 2));
+    const size_t off_after_lists = off;
+    u32* pc = reinterpret_cast<u32*>(carve((size_t)D * 4));
+    unsigned short* cnt = reinterpret_cast<unsigned short*>(carve((size_t)D * 2));
+    u64* bm = reinterpret_cast<u64*>(carve((size_t)W * 8));
+    u32* pf = reinterpret_cast<u32*>(carve((size_t)W * 4));
+    const int* shifts = sh.shifts;
+    for (int i = threadIdx.x; i < W; i += SPK_THREADS) bm[i] = 0;
+    unsigned long long tr = 0;
+    for (int i = threadIdx.x; i < Di; i += SPK_THREADS) {  // no atomics in this loop: the loads pipeline
+        u32 r, c;
+        spk_rowcol(keys[i], shifts, nr, nc, r, c);
+        pc[i] = (r << (2 * nc)) | c;
+        const u32 v = counts[i];
+        cnt[i] = (unsigned short)v;
+        tr += (unsigned long long)v * v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tr += __shfl_xor(tr, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long*>(sh.red)[threadIdx.x >> 6] = tr;
+    const u32 cmask = (nc >= 16) ? 0xFFFFFFFFu : ((1u << (2 * nc)) - 1);
+    for (int i = threadIdx.x; i < Di; i += SPK_THREADS) {
+        const u32 cell = pc[i];
+        const u32 r = cell >> (2 * nc), c = cell & cmask;
+        const u64 rb = 1ull << (r & 63), cb = 1ull << (c & 63);
+        if (!(*(volatile u64*)(bm + (r >> 6)) & rb)) atomicOr(bm + (r >> 6), rb);
+        if (!(*(volatile u64*)(bm + rw + (c >> 6)) & cb)) atomicOr(bm + rw + (c >> 6), cb);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < SPK_WAVES; ++i) t += reinterpret_cast<unsigned long long*>(sh.red)[i];
+        sh.trace = t;
+    }
+    int dimsRC[2];
+    for (int which = 0; which < 2; ++which) {
+        const int base = which ? rw : 0, cntw = which ? cw : rw;
+        const int per = (cntw + SPK_THREADS - 1) / SPK_THREADS;
+        const int lo = min(cntw, (int)threadIdx.x * per), hi = min(cntw, lo + per);
+        u32 s = 0;
+        for (int i = lo; i < hi; ++i) s += __popcll(bm[base + i]);
+        u32 tot;
+        u32 run = spk_scan(s, sh, tot);
+        for (int i = lo; i < hi; ++i) {
+            pf[base + i] = run;
+            run += __popcll(bm[base + i]);
+        }
+        dimsRC[which] = (int)tot;
+    }
+    __syncthreads();
+    SSTAMP(1);
+    const int R = dimsRC[0], Kc = dimsRC[1];
+    const double trace = (double)sh.trace;
+    if (R <= 4 || !(trace > 0)) {
+        // min(shape) <= 4: the reference computes 1 - x/x = 0 exactly; all-zero table: 0/0 = nan
+        if (threadIdx.x == 0) {
+            scores[sid] = trace > 0 ? 0.0 : __builtin_nan("");
+            status[sid] = 0;
+        }
+        return;
+    }
+    // compact coordinates in place: pc[i] = rr << 16 | cc
+    for (int i = threadIdx.x; i < Di; i += SPK_THREADS) {
+        const u32 cell = pc[i];
+        const u32 r = cell >> (2 * nc), c = cell & cmask;
+        pc[i] = (bm_rank(bm, pf, r) << 16) | bm_rank(bm + rw, pf + rw, c);
+    }
+    __syncthreads();
+    const bool small = small_sure;   // (R <= 64 with a larger bound simply takes the general path)
+    const int Rp = (R + 3) & ~3;
+    // the key bitmaps are dead now: the occupancy bitmap of the list builder starts there
+    const size_t build_end = reinterpret_cast<unsigned char*>(bm) - smem;
+    // iteration-time layout of region B:  V  W|G
+    const size_t need_iter = off_after_lists + (size_t)Rp * SPK_VP * 8 + 16 +
+                             (small ? (size_t)R * R * 8 : (size_t)Kc * 4 * 8);
+    const size_t min_tmp = (size_t)(((R > Kc ? R : Kc) + 63) / 64) * 8 * 8;  // at least 8 major indices per chunk
+    if (need_iter > SPK_LDS_BYTES || build_end + min_tmp > SPK_LDS_BYTES || Kc > 65535) {
+        if (threadIdx.x == 0) {
+            scores[sid] = 0.0;
+            status[sid] = 2;
+        }
+        return;
+    }
+    u64* tmp = reinterpret_cast<u64*>(smem + build_end);
+    const int tmp_words = (int)((SPK_LDS_BYTES - build_end) / 8);
+    spk_build_list<true>(pc, cnt, Di, Kc, R, csc_ptr, csc_ent, heavy_c, &sh.nheavy_c, tmp, tmp_words, sh);
+    SSTAMP(2);
+    if (!small) spk_build_list<false>(pc, cnt, Di, R, Kc, csr_ptr, csr_ent, heavy_r, &sh.nheavy_r, tmp, tmp_words, sh);
+    SSTAMP(3);
+    // ---- start block: unit vectors on the rows of the 4 largest counts (distinct rows) ----------------------------
+    // (the dominant singular vectors of a count flattening sit on the few very frequent patterns); chosen by four
+    // rounds of a block arg-max over (count, index), deterministic tie-break.
+    int top_row[SPK_NB];
+    {
+        unsigned long long* slot = reinterpret_cast<unsigned long long*>(sh.red);
+        for (int k = 0; k < SPK_NB; ++k) {
+            unsigned long long best = 0;  // (count << 32) | (0xFFFFFFFF - index): max picks the largest count, lowest index
+            for (int i = threadIdx.x; i < Di; i += SPK_THREADS) {
+                const int rr = (int)(pc[i] >> 16);
+                bool taken = false;
+                for (int q = 0; q < k; ++q) taken |= (top_row[q] == rr);
+                if (!taken) {
+                    const unsigned long long cand = ((unsigned long long)cnt[i] << 32) | (0xFFFFFFFFull - (unsigned)i);
+                    best = cand > best ? cand : best;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long o = __shfl_xor(best, d, 64);
+                best = o > best ? o : best;
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = best;
+            __syncthreads();
+            unsigned long long b = 0;
+            for (int i = 0; i < SPK_WAVES; ++i) b = slot[i] > b ? slot[i] : b;
+            top_row[k] = b ? (int)(pc[(int)(0xFFFFFFFFull - (b & 0xFFFFFFFFull))] >> 16) : -1;
+            __syncthreads();
+        }
+    }
+    SSTAMP(4);
+    // V and W / G are laid out over the (now dead) staging area
+    off = off_after_lists;
+    double* V = reinterpret_cast<double*>(carve((size_t)Rp * SPK_VP * 8));
+    double* Wb = reinterpret_cast<double*>(smem + off);   // large: W (Kc x 4);  small: G (R x R)
+    if (small) {
+        unsigned long long* G64 = reinterpret_cast<unsigned long long*>(Wb);
+        for (int i = threadIdx.x; i < R * R; i += SPK_THREADS) G64[i] = 0;
+        __syncthreads();
+        // exact Gram: pairs inside every column; one 4-lane group per column, lanes split the second index
+        const int j = threadIdx.x & 3, g = threadIdx.x >> 2;
+        for (int c = g; c < Kc; c += SPK_THREADS / 4) {
+            const int p0 = csc_ptr[c], p1 = csc_ptr[c + 1];
+            for (int a = p0; a < p1; ++a) {
+                const u32 va = csc_ent[a];
+                const unsigned long long ca = va >> 16;
+                const int ra = va & 0xFFFF;
+                for (int b = a + j; b < p1; b += 4) {
+                    const u32 vb = csc_ent[b];
+                    atomicAdd(&G64[ra * R + (vb & 0xFFFF)], ca * (unsigned long long)(vb >> 16));  // ra <= rb
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < R * R; i += SPK_THREADS) {  // exact integer -> fp64, in place
+            const int r = i / R, c = i % R;
+            if (r > c) continue;
+            G64[r * R + c] = (unsigned long long)__double_as_longlong((double)G64[r * R + c]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < R * R; i += SPK_THREADS) {
+            const int r = i / R, c = i % R;
+            if (r > c) Wb[r * R + c] = Wb[c * R + r];
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < Rp * SPK_VP; e += SPK_THREADS) V[e] = 0.0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < R; i += SPK_THREADS) {
+#pragma unroll
+        for (int k = 0; k < SPK_NB; ++k) V[i * SPK_VP + k] = 0.02 * spk_hash(i, k) + (top_row[k] == i ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    SSTAMP(5);
+    spk_ritz_orth(V, R, sh);
+    SSTAMP(6);
+    // ---- iteration ------------------------------------------------------------------------------------------
+    double prev_sum = 0, prev_delta = 0, top4 = 0;
+    int it = 0, conv = 0;
+    for (it = 1; it <= SPK_MAXIT; ++it) {
+        if (small) {
+            // Y = G V densely (R <= 64): thread (row, j); Y staged in registers, then written over V
+            const int row = threadIdx.x >> 2, j = threadIdx.x & 3;
+            double acc = 0;
+            if (row < R)
+                for (int k = 0; k < R; ++k) acc += Wb[row * R + k] * V[k * SPK_VP + j];
+            __syncthreads();
+            if (row < R) V[row * SPK_VP + j] = acc;
+            __syncthreads();
+        } else {
+            if (it == 1) SSTAMP(7);
+            spk_spmm(csc_ptr, csc_ent, Kc, heavy_c, sh.nheavy_c, V, SPK_VP, Wb, 4);   // W = C^T V
+            if (it == 1) SSTAMP(8);
+            spk_spmm(csr_ptr, csr_ent, R, heavy_r, sh.nheavy_r, Wb, 4, V, SPK_VP);    // Y = C W  (overwrites V)
+            if (it == 1) SSTAMP(9);
+        }
+        spk_ritz_orth(V, R, sh);
+        if (it == 1) SSTAMP(10);
+        top4 = sh.top4;
+        if (spk_converged(top4, it, prev_sum, prev_delta)) {
+            conv = 1;
+            break;
+        }
+    }
+    SSTAMP(11);
+    if (threadIdx.x == 0) {
+        if (conv) {
+            const double op = 1.0 - top4 / trace;
+            scores[sid] = sqrt(op > 0 ? op : 0.0);
+            status[sid] = it << 8;
+        } else {
+            scores[sid] = 0.0;
+            status[sid] = 2 | (it << 8);  // no spectral gap behind the 4th value: let the 16-wide dense route do it
+        }
+    }
+}
+
+int launch_sparse_score(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, int n_taxa,
+                        const SplitDev* splits_dev, const int* order_dev, int64_t S, double* scores, int* status) {
+    if (S == 0) return SP_OK;
+    PhaseScope ps(ctx, SP_PHASE_SPARSE);
+    static bool attr = false;
+    if (!attr) {
+        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_score),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_BYTES));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_sparse_score, dim3((unsigned)S), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream, keys, counts, D,
+                       n_taxa, splits_dev, order_dev, scores, status);
+    SP_HIP(hipGetLastError());
+    return SP_OK;
+}

@@ -285,9 +285,9 @@ def test_gram_kernels_agree_bitwise(sp, golden):
         dev = sp.DeviceAlignment.from_arrays(keys, None, 10, counts=counts, n_sites=length, taxa=names)
         sub = splits[::3]
         dev.ctx.set_gram_mode("auto")
-        s_i8 = sp.score_splits(dev, sub)
+        s_i8 = sp.score_splits(dev, sub, route="dense")
         dev.ctx.set_gram_mode("f64")
-        s_f64 = sp.score_splits(dev, sub)
+        s_f64 = sp.score_splits(dev, sub, route="dense")
         dev.ctx.set_gram_mode("auto")
         assert np.array_equal(s_i8, s_f64), (length, int(counts.max()), np.abs(s_i8 - s_f64).max())
         for i in (0, 60, 150):
@@ -295,3 +295,48 @@ def test_gram_kernels_agree_bitwise(sp, golden):
             M = O.reduced_flattening_packed(keys, counts.astype(np.float64), 10, [names.index(t) for t in a],
                                             [names.index(t) for t in b])[0]
             assert abs(O.dense_split_score(M) - s_i8[i]) <= SCORE_TOL
+
+
+def test_routes_agree(sp, golden):
+    """dense route (scatter + MFMA Gram + 16-wide eigen through HBM), sparse route (one workgroup per split, all in
+    LDS, 4-wide block) and auto must give the same scores; sparse twice must be bit-identical (deterministic)."""
+    names = taxa_names(10)
+    for name in ("n10_L100k", "n10_L10k"):
+        g = golden(name)
+        splits = [mask_to_split(int(m), 10, names) for m in g["masks"]]
+        dev = sp.DeviceAlignment.from_table(O.unpack_table(g["keys"], g["probs"], 10), taxa=names)
+        s_dense, st_d = sp.score_splits(dev, splits, route="dense", return_status=True)
+        s_sparse, st_s = sp.score_splits(dev, splits, route="sparse", return_status=True)
+        s_auto = sp.score_splits(dev, splits)
+        assert np.all((st_d & 3) == 0) and np.all((st_s & 3) == 0)
+        assert np.abs(s_dense - g["scores"]).max() <= SCORE_TOL
+        assert np.abs(s_sparse - g["scores"]).max() <= SCORE_TOL
+        assert np.array_equal(s_auto, s_sparse)
+        for _ in range(3):
+            assert np.array_equal(sp.score_splits(dev, splits, route="sparse"), s_sparse)
+    # hand-back: a table the sparse kernel cannot take (counts >= 65536) silently uses the dense route
+    from splitp_amd import synthetic as syn
+    sites = syn.simulate_sites(10, 700_000, 0.05, seed=8)
+    keys, counts = syn.pattern_table(sites)
+    assert counts.max() >= 65536
+    big = sp.DeviceAlignment.from_arrays(keys, None, 10, counts=counts, n_sites=700_000, taxa=names)
+    with pytest.raises(NotImplementedError):
+        sp.score_splits(big, splits[:5], route="sparse")
+    sb = sp.score_splits(big, splits[::25])
+    for i, spl in enumerate(splits[::25][:4]):
+        M = O.reduced_flattening_packed(keys, counts.astype(np.float64), 10, [names.index(t) for t in spl[0]],
+                                        [names.index(t) for t in spl[1]])[0]
+        assert abs(O.dense_split_score(M) - sb[i]) <= SCORE_TOL
+    # slow-convergence hand-back: a table without a gap behind the 4th singular value (uniform random patterns)
+    rng = np.random.default_rng(3)
+    rk = np.unique(rng.integers(0, 4 ** 10, size=3000).astype(np.uint64))
+    rc = rng.integers(1, 40, size=len(rk)).astype(np.int64)
+    flat = sp.DeviceAlignment.from_arrays(rk, None, 10, counts=rc, n_sites=int(rc.sum()), taxa=names)
+    sub = splits[::40]
+    s_a, st_a = sp.score_splits(flat, sub, return_status=True)
+    s_d = sp.score_splits(flat, sub, route="dense")
+    assert np.abs(s_a - s_d).max() <= 1e-9
+    for i in (0, 5, 12):
+        M = O.reduced_flattening_packed(rk, rc.astype(np.float64), 10, [names.index(t) for t in sub[i][0]],
+                                        [names.index(t) for t in sub[i][1]])[0]
+        assert abs(O.dense_split_score(M) - s_a[i]) <= 1e-9
