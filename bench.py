@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--alignments", type=int, default=1, help="alignments scored per rank per step")
+    ap.add_argument("--route", default="auto", choices=["auto", "dense", "sparse"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -107,7 +108,7 @@ def main():
         aligns.append(sp.DeviceAlignment.from_arrays(keys, None, N_TAXA, counts=counts, n_sites=N_SITES, taxa=names))
         tables.append((keys, counts))
     taxa_arr, a_arr = batch.encode_splits(splits, aligns[0], N_TAXA)
-    code = _lib.SP_METHOD_FLATTENING
+    code = batch._method_code(sp.Method.flattening, args.route)
     ctx = aligns[0].ctx
     per_rank = args.alignments * n_splits
     send = torch.zeros(per_rank, dtype=torch.float64, device=dev_t)
@@ -151,34 +152,48 @@ def main():
         total_splits = world * per_rank * args.steps
         value = total_splits / elapsed
         # ---- roofline of the dominant kernel (phase) -------------------------------------------
-        launches_per_step = args.alignments
         ph = {k: v for k, v in phases.items() if v[1] > 0}
         dom = max(ph, key=lambda k: ph[k][0])
         dom_ms = ph[dom][0] / ph[dom][1]                      # average duration of one launch (group)
         k_small = np.minimum(a_arr, N_TAXA - a_arr).astype(np.float64)
         algo_flops_gram = float(np.sum(2.0 * 4.0 ** N_TAXA * 4.0 ** k_small))   # 2*4^n*4^k per split
         algo_bytes_scatter = float(n_splits * (4.0 * N_SITES + 4.0 * 4.0 ** N_TAXA))  # 4L + 4*4^n
+        kernel_names = {"gram": "k_gram_i8<2,int> (int8-limb MFMA Gram)", "eigen": "k_eig_gv / k_eig_rr (fp64 MFMA)",
+                        "sparse": "k_sparse_score (one workgroup per split, CSC/CSR lists + 4-wide block in LDS)",
+                        "scatter": "k_zero_i8 + k_scatter_i8", "reindex": "k_reindex"}
         if dom in ("gram", "eigen"):
             achieved = algo_flops_gram / (dom_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": {"gram": "k_gram<u32>", "eigen": "k_eigen"}[dom],
+            roof = {"bound": "mfma", "kernel": kernel_names[dom],
                     "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": None,
-                    "note": "achieved = SURVEY 8(d) algorithmic Gram flops (2*4^n*4^k per split, 501 splits per "
+                    "note": "achieved = SURVEY 8(d) algorithmic fp64 Gram flops (2*4^n*4^k per split, 501 splits per "
                             "launch) / measured launch duration; the kernels work on the compacted upper-triangular "
-                            "problem, so executed MFMA flops are lower (DESIGN.md)"}
+                            "problem (int8 limbs for the Gram), so executed MFMA work is lower (DESIGN.md)"}
         else:
             achieved = algo_bytes_scatter / (dom_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+            roof = {"bound": "hbm", "kernel": kernel_names.get(dom, dom), "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "note": "achieved = SURVEY 8(d) algorithmic bytes of the flattening (4L + 4*4^n per split: every "
+                            "site word read once, every dense cell written once) / measured launch duration.  The "
+                            "sparse route never materialises the 4^a x 4^b matrix (it keeps the D non-zeros in LDS), so "
+                            "its real HBM traffic is ~3 orders of magnitude below this figure and the kernel is bound by "
+                            "LDS latency, not HBM (DESIGN.md section 5)"}
         roof["launch_ms"] = dom_ms
         roof["phase_ms_per_step"] = {k: round(v[0] / args.steps, 5) for k, v in ph.items()}
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                roof["traffic"] = json.load(open(pmc)).get(dom)
+            except Exception:
+                pass
         out = {
             "metric": "splits scored/sec (whole node), 10-taxon 100k-bp JC alignment",
             "value": value, "unit": "splits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 10-taxon balanced tree (branch 0.05, JC), 100k bp, all 501 "
-                                   "splits, dense-route flattening + fp64 score, scores copied to host every step",
+                                   "splits, flattening + fp64 split score, scores copied to host every step",
+                       "route": args.route,
                        "alignments_per_rank_per_step": args.alignments, "splits_per_alignment": n_splits,
                        "patterns": int(len(tables[0][0])), "parallelism": f"alignment-sharded x{world}, all_gather of scores"
                        if world > 1 else "single GPU"},

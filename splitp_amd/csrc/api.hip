@@ -585,8 +585,10 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
     for (int64_t i = 0; i < S; ++i)
         if (st[i] & 2) redo.push_back((int)i);
     if (redo.empty()) return SP_OK;
-    SP_REQUIRE(!strict, SP_ELIMIT, "sparse route: %zu of %lld splits do not fit the in-LDS kernel (first: %d)",
-               redo.size(), (long long)S, redo[0]);
+    SP_REQUIRE(!strict, SP_ELIMIT,
+               "sparse route: %zu of %lld splits were handed back by the in-LDS kernel (first: split %d, status 0x%x: "
+               "%s)", redo.size(), (long long)S, redo[0], st[redo[0]],
+               (st[redo[0]] >> 8) ? "no convergence with the 4-wide block" : "lists / blocks do not fit LDS");
     // dense route on the handed-back subset (overwrites the context pools, hence the parking buffer)
     const int n = al->n_taxa;
     std::vector<int32_t> t2(redo.size() * (size_t)n), a2(redo.size());

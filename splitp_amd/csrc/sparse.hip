@@ -35,6 +35,20 @@
 #define SPK_LDS_BYTES 163840
 #define SPK_SMALL_R 64
 
+#ifdef SPK_STAMPS
+__device__ long long g_spk_stamps[64];
+#define SSTAMP(i)                                                                              \
+    do {                                                                                       \
+        __syncthreads();                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_spk_stamps[i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+extern "C" int sp_debug_spk_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spk_stamps), sizeof(long long) * 64) == hipSuccess ? 0 : 2;
+}
+#else
+#define SSTAMP(i)
+#endif
+
 struct SpkShared {
     double red[SPK_WAVES * 12];
     double S[12];        // 10 unique entries of the symmetric 4 x 4 (row-major upper: 00 01 02 03 11 12 13 22 23 33)
@@ -44,6 +58,7 @@ struct SpkShared {
     int R, Kc, nheavy_c, nheavy_r, flag, pad;
     int shifts[32];
     unsigned int scan[SPK_WAVES + 1];
+    unsigned int bucket[68];
 };
 
 __device__ __forceinline__ double spk_hash(unsigned a, unsigned b) {
@@ -222,77 +237,181 @@ __device__ __forceinline__ void spk_jacobi4(SpkShared& sh) {
     __syncthreads();
 }
 
-// Ritz values + next orthonormal block from Y (in X): S = X^T X, Jacobi, X <- X P D^-1/2, Newton-Schulz polish.
-__device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh) {
-    spk_gram(X, R, sh);
-    spk_jacobi4(sh);
-    spk_apply(X, R, sh);
-    for (int iter = 0; iter < 8; ++iter) {
-        spk_gram(X, R, sh);
-        // M = 1.5 I - 0.5 S ; err = max |S - I| over live columns (uniform: every thread reads sh.S)
-        const double s00 = sh.S[0], s01 = sh.S[1], s02 = sh.S[2], s03 = sh.S[3], s11 = sh.S[4], s12 = sh.S[5],
-                     s13 = sh.S[6], s22 = sh.S[7], s23 = sh.S[8], s33 = sh.S[9];
-        double err = fmax(fmax(fabs(s01), fabs(s02)), fmax(fabs(s03), fmax(fabs(s12), fmax(fabs(s13), fabs(s23)))));
-        err = fmax(err, s00 > 0.25 ? fabs(s00 - 1.0) : fabs(s00));
-        err = fmax(err, s11 > 0.25 ? fabs(s11 - 1.0) : fabs(s11));
-        err = fmax(err, s22 > 0.25 ? fabs(s22 - 1.0) : fabs(s22));
-        err = fmax(err, s33 > 0.25 ? fabs(s33 - 1.0) : fabs(s33));
-        if (err <= 2e-15) break;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const double m[16] = {1.5 - 0.5 * s00, -0.5 * s01, -0.5 * s02, -0.5 * s03,
-                                  -0.5 * s01, 1.5 - 0.5 * s11, -0.5 * s12, -0.5 * s13,
-                                  -0.5 * s02, -0.5 * s12, 1.5 - 0.5 * s22, -0.5 * s23,
-                                  -0.5 * s03, -0.5 * s13, -0.5 * s23, 1.5 - 0.5 * s33};
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sh.T[i] = m[i];
-        }
-        __syncthreads();
-        spk_apply(X, R, sh);
+// 4 x 4 helpers on row-major arrays (every thread computes them redundantly from LDS broadcasts: no serial
+// single-wave section, no extra barriers)
+__device__ __forceinline__ void spk_sym_from(const double* S10, double (&s)[16]) {
+    s[0] = S10[0]; s[1] = S10[1]; s[2] = S10[2]; s[3] = S10[3];
+    s[4] = S10[1]; s[5] = S10[4]; s[6] = S10[5]; s[7] = S10[6];
+    s[8] = S10[2]; s[9] = S10[5]; s[10] = S10[7]; s[11] = S10[8];
+    s[12] = S10[3]; s[13] = S10[6]; s[14] = S10[8]; s[15] = S10[9];
+}
+__device__ __forceinline__ void spk_apply_reg(double* X, int R, const double (&t)[16]) {
+    for (int row = threadIdx.x; row < R; row += SPK_THREADS) {
+        const double a = X[row * SPK_VP], b = X[row * SPK_VP + 1], c = X[row * SPK_VP + 2], d = X[row * SPK_VP + 3];
+        X[row * SPK_VP + 0] = a * t[0] + b * t[4] + c * t[8] + d * t[12];
+        X[row * SPK_VP + 1] = a * t[1] + b * t[5] + c * t[9] + d * t[13];
+        X[row * SPK_VP + 2] = a * t[2] + b * t[6] + c * t[10] + d * t[14];
+        X[row * SPK_VP + 3] = a * t[3] + b * t[7] + c * t[11] + d * t[15];
     }
     __syncthreads();
 }
 
-// Build one sorted list (grouped by `major`, ordered by `minor` inside a group) with the bitmap-rank
-// construction, in chunks of `major` values so that the occupancy bitmap fits `tmp`.  Inputs are the compact
-// coordinates pc[i] = rr << 16 | cc and the counts cnt[i] staged in LDS.
-//   MAJOR_IS_COL: true -> CSC (major = compact column, minor = compact row), false -> CSR.
-//   ptr[nmajor + 1] (u16, LDS), ent[D] (u32 = minor | count << 16, LDS), heavy[] = groups with > SPK_HEAVY entries.
-template <bool MAJOR_IS_COL>
-__device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned short* cnt, int D, int nmajor, int nminor,
-                                               unsigned short* ptr, u32* ent, unsigned short* heavy, int* nheavy,
-                                               u64* tmp, int tmp_words, SpkShared& sh) {
-    const int mw = (nminor + 63) >> 6;                 // bitmap words per major index
-    const int per_chunk = max(1, tmp_words / mw);       // major indices per chunk
-    if (threadIdx.x == 0) *nheavy = 0;
-    // pass 1: counts per major index -> ptr (exclusive scan)
-    for (int c0 = 0; c0 < nmajor; c0 += per_chunk) {
-        const int c1 = min(nmajor, c0 + per_chunk);
-        for (int i = threadIdx.x; i < (c1 - c0) * mw; i += SPK_THREADS) tmp[i] = 0;
-        __syncthreads();
-        for (int i = threadIdx.x; i < D; i += SPK_THREADS) {
-            const u32 v = pc[i];
-            const int mj = MAJOR_IS_COL ? (int)(v & 0xFFFF) : (int)(v >> 16);
-            const int mn = MAJOR_IS_COL ? (int)(v >> 16) : (int)(v & 0xFFFF);
-            if (mj >= c0 && mj < c1) atomicOr(&tmp[(mj - c0) * mw + (mn >> 6)], 1ull << (mn & 63));
-        }
-        __syncthreads();
-        for (int m = c0 + threadIdx.x; m < c1; m += SPK_THREADS) {
-            int c = 0;
-            for (int w = 0; w < mw; ++w) c += __popcll(tmp[(m - c0) * mw + w]);
-            ptr[m] = (unsigned short)c;  // counts for now
-            if (c > SPK_HEAVY) heavy[atomicAdd(nheavy, 1)] = (unsigned short)m;  // order irrelevant to results
-        }
-        __syncthreads();
+// Ritz values + next orthonormal block from Y (held in X), in place.
+//   Fast path - polar decomposition by Newton-Schulz: Y = U H with U = Y (Y^T Y)^-1/2 orthonormal and
+//   H = (Y^T Y)^1/2, so trace(H) = sum_i sqrt(eig_i(Y^T Y)) is exactly the sum of the four Ritz values and U is
+//   the next block.  With S0 = Y^T Y, X = c Y and X <- X (1.5 I - 0.5 X^T X) repeated, U = Y T (T the accumulated
+//   4 x 4 transform, starting at c I) and trace(H) = trace(T^T S0).  Everything is 4 x 4 algebra done redundantly by
+//   every thread plus one 10-value block reduction per step.  Taken when Y is well conditioned (column norms within
+//   a factor 7, scaled off-diagonals <= 0.25) - true from the first product on for count flattenings, whose four
+//   leading singular values are of one magnitude; then 3-4 steps reach fp64 orthonormality.
+//   Robust path (anything else: arbitrary start blocks / matrices): Jacobi eigen-decomposition of S0, X <- X P D^-1/2,
+//   then the same Newton-Schulz polish.
+__device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh) {
+    spk_gram(X, R, sh);
+    double s0[16], t[16];
+    spk_sym_from(sh.S, s0);
+    const double dmax = fmax(fmax(s0[0], s0[5]), fmax(s0[10], s0[15]));
+    double d[4];
+    bool alive[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        alive[i] = s0[5 * i] > 1e-28 * dmax && s0[5 * i] > 0;
+        d[i] = alive[i] ? spk_rsqrt(s0[5 * i]) : 0.0;
     }
-    {   // exclusive scan of the counts
+    double offmax = 0, dmin = dmax;
+    bool all_alive = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        all_alive = all_alive && alive[i];
+        dmin = fmin(dmin, s0[5 * i]);
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) offmax = fmax(offmax, fabs(s0[4 * i + j]) * d[i] * d[j]);
+    }
+    double top_jacobi = -1.0;
+    if (all_alive && offmax <= 0.25 && dmin >= 0.02 * dmax) {
+        // ONE scalar scale (a column scaling would change the polar factor and trace(U^T Y) would no longer be the
+        // sum of the singular values): 1 / sqrt(Gershgorin bound) puts every singular value of X in (0, 1]
+        double gb = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            gb = fmax(gb, fabs(s0[4 * i]) + fabs(s0[4 * i + 1]) + fabs(s0[4 * i + 2]) + fabs(s0[4 * i + 3]));
+        const double c = spk_rsqrt(gb);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[5 * i] = c;
+    } else {
+        __syncthreads();
+        spk_jacobi4(sh);   // writes sh.T = P D^-1/2 and sh.top4
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = sh.T[i];
+        top_jacobi = sh.top4;
+    }
+    spk_apply_reg(X, R, t);
+    double pred = 1.0;
+    for (int iter = 0; iter < 12; ++iter) {
+        spk_gram(X, R, sh);
+        double sk[16];
+        spk_sym_from(sh.S, sk);
+        double err = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double target = (i == j && alive[i] && sk[5 * i] > 0.25) ? 1.0 : 0.0;
+                err = fmax(err, fabs(sk[4 * i + j] - target));
+            }
+        if (err <= 2e-15) break;
+        // M = 1.5 I - 0.5 S ;  T <- T M ;  X <- X M
+        double m[16], tn[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[4 * i + j] = (i == j ? 1.5 : 0.0) - 0.5 * sk[4 * i + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                tn[4 * i + j] = t[4 * i] * m[j] + t[4 * i + 1] * m[4 + j] + t[4 * i + 2] * m[8 + j] + t[4 * i + 3] * m[12 + j];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = tn[i];
+        spk_apply_reg(X, R, m);
+        pred = err * err;           // Newton-Schulz squares the defect (constant < 1)
+        if (pred <= 1e-17) break;   // the step just applied brought it below fp64 resolution: no need to re-measure
+    }
+#ifdef SPK_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_spk_stamps[30] = top_jacobi >= 0 ? 100 : 0;
+#endif
+    // sum of the Ritz values = trace(T^T S0)   (Jacobi path: S0's eigenvalues were computed directly)
+    double tr = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tr += t[i] * s0[i];
+    __syncthreads();
+    if (threadIdx.x == 0) sh.top4 = top_jacobi >= 0 ? top_jacobi : tr;
+    __syncthreads();
+}
+
+// Build one list grouped by `major` (CSC: compact column, CSR: compact row) as a STABLE counting sort of the
+// table order: the table is cut into SPK_WAVES contiguous chunks, wave w owns chunk w and a private row of
+// per-group counters (BITS-wide fields packed into 32-bit LDS words); position of an entry = ptr[group] + (entries of
+// the group in earlier chunks) + (rank among the wave's own earlier entries).  The last term is the value returned by
+// the wave's own LDS atomic add: lanes of one ds_add_rtn instruction that hit the same word are resolved by the LDS in
+// a fixed order, and no other wave touches that counter row, so the layout - and with it every later summation
+// order - is reproducible run to run (checked by the bitwise-repeat tests).  No occupancy bitmaps, no chunking.
+//   ptr[nmajor + 1] (u16), ent[D] (u32 = minor | count << 16), perm[nmajor] = groups sorted by size (descending, so
+//   that the 16 four-lane groups of a wave work on groups of similar length); *nheavy = #groups > SPK_HEAVY.
+template <bool MAJOR_IS_COL, int BITS>
+__device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned short* cnt, int D, int nmajor,
+                                               unsigned short* ptr, u32* ent, unsigned short* perm, int* nheavy,
+                                               u32* cw, SpkShared& sh) {
+    constexpr int PER = 32 / BITS;                     // counters per word
+    constexpr u32 FMASK = (1u << BITS) - 1;
+    const int stride = (nmajor + PER - 1) / PER;       // words per wave row
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int chunk = ((D + SPK_WAVES * 64 - 1) / (SPK_WAVES * 64)) * 64;
+    const int lo = min(D, w * chunk), hi = min(D, lo + chunk);
+    for (int i = threadIdx.x; i < SPK_WAVES * stride; i += SPK_THREADS) cw[i] = 0;
+    if (threadIdx.x < 68) sh.bucket[threadIdx.x] = 0;
+    __syncthreads();
+    u32* myrow = cw + w * stride;
+    for (int i = lo + lane; i < hi; i += 64) {           // pass A: per-chunk group sizes
+        const u32 v = pc[i];
+        const int mj = MAJOR_IS_COL ? (int)(v & 0xFFFF) : (int)(v >> 16);
+        atomicAdd(&myrow[mj / PER], 1u << (BITS * (mj % PER)));
+    }
+    __syncthreads();
+    // exclusive prefix over the chunks, one thread per packed word (PER groups); totals -> ptr
+    for (int q = threadIdx.x; q < stride; q += SPK_THREADS) {
+        u32 run[PER];
+#pragma unroll
+        for (int f = 0; f < PER; ++f) run[f] = 0;
+        for (int ww = 0; ww < SPK_WAVES; ++ww) {
+            const u32 word = cw[ww * stride + q];
+            u32 outw = 0;
+#pragma unroll
+            for (int f = 0; f < PER; ++f) {
+                outw |= run[f] << (BITS * f);
+                run[f] += (word >> (BITS * f)) & FMASK;
+            }
+            cw[ww * stride + q] = outw;
+        }
+#pragma unroll
+        for (int f = 0; f < PER; ++f)
+            if (q * PER + f < nmajor) ptr[q * PER + f] = (unsigned short)run[f];
+    }
+    __syncthreads();
+    {   // exclusive scan of the group sizes -> ptr ; size buckets for the permutation
         const int per = (nmajor + SPK_THREADS - 1) / SPK_THREADS;
-        const int lo = min(nmajor, (int)threadIdx.x * per), hi = min(nmajor, lo + per);
-        u32 s = 0;
-        for (int i = lo; i < hi; ++i) s += ptr[i];
+        const int l0 = min(nmajor, (int)threadIdx.x * per), h0 = min(nmajor, l0 + per);
+        u32 sum = 0;
+        for (int i = l0; i < h0; ++i) {
+            const u32 c = ptr[i];
+            sum += c;
+            atomicAdd(&sh.bucket[c > 64 ? 64 : c], 1u);
+        }
         u32 tot;
-        u32 run = spk_scan(s, sh, tot);
-        for (int i = lo; i < hi; ++i) {
+        u32 run = spk_scan(sum, sh, tot);
+        for (int i = l0; i < h0; ++i) {
             const u32 c = ptr[i];
             ptr[i] = (unsigned short)run;
             run += c;
@@ -300,70 +419,81 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
         if (threadIdx.x == 0) ptr[nmajor] = (unsigned short)tot;
         __syncthreads();
     }
-    // pass 2: placement by rank inside the major group
-    for (int c0 = 0; c0 < nmajor; c0 += per_chunk) {
-        const int c1 = min(nmajor, c0 + per_chunk);
-        if (nmajor > per_chunk) {  // bitmap of this chunk has to be rebuilt (single-chunk case: still valid)
-            for (int i = threadIdx.x; i < (c1 - c0) * mw; i += SPK_THREADS) tmp[i] = 0;
-            __syncthreads();
-            for (int i = threadIdx.x; i < D; i += SPK_THREADS) {
-                const u32 v = pc[i];
-                const int mj = MAJOR_IS_COL ? (int)(v & 0xFFFF) : (int)(v >> 16);
-                const int mn = MAJOR_IS_COL ? (int)(v >> 16) : (int)(v & 0xFFFF);
-                if (mj >= c0 && mj < c1) atomicOr(&tmp[(mj - c0) * mw + (mn >> 6)], 1ull << (mn & 63));
-            }
-            __syncthreads();
+    if (threadIdx.x == 0) {   // descending bucket offsets; groups above SPK_HEAVY come first
+        u32 run = 0, heavy = 0;
+        for (int bkt = 64; bkt >= 0; --bkt) {
+            const u32 c = sh.bucket[bkt];
+            sh.bucket[bkt] = run;
+            run += c;
+            if (bkt > SPK_HEAVY) heavy = run;
         }
-        for (int i = threadIdx.x; i < D; i += SPK_THREADS) {
-            const u32 v = pc[i];
-            const int mj = MAJOR_IS_COL ? (int)(v & 0xFFFF) : (int)(v >> 16);
-            const int mn = MAJOR_IS_COL ? (int)(v >> 16) : (int)(v & 0xFFFF);
-            if (mj >= c0 && mj < c1) {
-                const u64* row = tmp + (mj - c0) * mw;
-                int rank = 0;
-                for (int w = 0; w < (mn >> 6); ++w) rank += __popcll(row[w]);
-                rank += __popcll(row[mn >> 6] & ((1ull << (mn & 63)) - 1));
-                ent[ptr[mj] + rank] = (u32)mn | ((u32)cnt[i] << 16);
-            }
-        }
-        __syncthreads();
+        *nheavy = (int)heavy;
     }
+    __syncthreads();
+    for (int m = threadIdx.x; m < nmajor; m += SPK_THREADS) {
+        const int c = ptr[m + 1] - ptr[m];
+        perm[atomicAdd(&sh.bucket[c > 64 ? 64 : c], 1u)] = (unsigned short)m;   // order inside a bucket is irrelevant
+    }
+    for (int i = lo + lane; i < hi; i += 64) {           // pass B: placement
+        const u32 v = pc[i];
+        const int mj = MAJOR_IS_COL ? (int)(v & 0xFFFF) : (int)(v >> 16);
+        const int mn = MAJOR_IS_COL ? (int)(v >> 16) : (int)(v & 0xFFFF);
+        const u32 old = atomicAdd(&myrow[mj / PER], 1u << (BITS * (mj % PER)));
+        ent[ptr[mj] + ((old >> (BITS * (mj % PER))) & FMASK)] = (u32)mn | ((u32)cnt[i] << 16);
+    }
+    __syncthreads();
 }
 
 // out[m][0..3] = sum over the entries e of major group m of count_e * in[minor_e][0..3].
-// Light groups: one 4-lane group each (two independent accumulation chains, combined in a fixed order).
-// Heavy groups (> SPK_HEAVY entries, listed in heavy[]): one wave each, 16 sub-groups striding the entries,
-// fixed shuffle-tree reduction.  Ends with a barrier.
+// Light groups: one 4-lane group each; heavy groups (> SPK_HEAVY entries, listed in heavy[]): one wave each,
+// 16 sub-groups striding the entries, fixed shuffle-tree reduction.  Four independent accumulation chains per
+// lane keep four LDS round trips in flight (the loop is pure LDS latency otherwise); they are combined in a
+// fixed order, so the result is reproducible.  Ends with a barrier.
+__device__ __forceinline__ double spk_term(const u32* ent, int e, const double* in, int in_pitch, int j) {
+    const u32 v = ent[e];
+    return (double)(v >> 16) * in[(v & 0xFFFFu) * in_pitch + j];
+}
+
 __device__ __forceinline__ void spk_spmm(const unsigned short* ptr, const u32* ent, int nmajor,
-                                         const unsigned short* heavy, int nheavy, const double* in, int in_pitch,
-                                         double* out, int out_pitch) {
+                                         const unsigned short* perm, int nheavy, const double* in, int in_pitch,
+                                         double* out, int out_pitch, int stamp_at = -1) {
     const int j = threadIdx.x & 3, g = threadIdx.x >> 2;
-    for (int m = g; m < nmajor; m += SPK_THREADS / 4) {
+    for (int idx = nheavy + g; idx < nmajor; idx += SPK_THREADS / 4) {
+        const int m = perm[idx];
         const int p0 = ptr[m], p1 = ptr[m + 1];
-        if (p1 - p0 > SPK_HEAVY) continue;
-        double acc0 = 0, acc1 = 0;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         int e = p0;
-        for (; e + 1 < p1; e += 2) {
-            const u32 v0 = ent[e], v1 = ent[e + 1];
-            acc0 += (double)(v0 >> 16) * in[(v0 & 0xFFFFu) * in_pitch + j];
-            acc1 += (double)(v1 >> 16) * in[(v1 & 0xFFFFu) * in_pitch + j];
+        for (; e + 3 < p1; e += 4) {
+            a0 += spk_term(ent, e, in, in_pitch, j);
+            a1 += spk_term(ent, e + 1, in, in_pitch, j);
+            a2 += spk_term(ent, e + 2, in, in_pitch, j);
+            a3 += spk_term(ent, e + 3, in, in_pitch, j);
         }
-        if (e < p1) {
-            const u32 v0 = ent[e];
-            acc0 += (double)(v0 >> 16) * in[(v0 & 0xFFFFu) * in_pitch + j];
-        }
-        out[m * out_pitch + j] = acc0 + acc1;
+        if (e < p1) a0 += spk_term(ent, e, in, in_pitch, j);
+        if (e + 1 < p1) a1 += spk_term(ent, e + 1, in, in_pitch, j);
+        if (e + 2 < p1) a2 += spk_term(ent, e + 2, in, in_pitch, j);
+        out[m * out_pitch + j] = (a0 + a1) + (a2 + a3);
     }
+#ifdef SPK_STAMPS
+    if (stamp_at >= 0) SSTAMP(stamp_at);
+#endif
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int sg = lane >> 2;
     for (int h = w; h < nheavy; h += SPK_WAVES) {
-        const int m = heavy[h];
+        const int m = perm[h];
         const int p0 = ptr[m], p1 = ptr[m + 1];
-        double acc = 0;
-        for (int e = p0 + sg; e < p1; e += 16) {
-            const u32 v = ent[e];
-            acc += (double)(v >> 16) * in[(v & 0xFFFFu) * in_pitch + j];
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int e = p0 + sg;
+        for (; e + 48 < p1; e += 64) {
+            a0 += spk_term(ent, e, in, in_pitch, j);
+            a1 += spk_term(ent, e + 16, in, in_pitch, j);
+            a2 += spk_term(ent, e + 32, in, in_pitch, j);
+            a3 += spk_term(ent, e + 48, in, in_pitch, j);
         }
+        if (e < p1) a0 += spk_term(ent, e, in, in_pitch, j);
+        if (e + 16 < p1) a1 += spk_term(ent, e + 16, in, in_pitch, j);
+        if (e + 32 < p1) a2 += spk_term(ent, e + 32, in, in_pitch, j);
+        double acc = (a0 + a1) + (a2 + a3);
         acc += __shfl_xor(acc, 4, 64);
         acc += __shfl_xor(acc, 8, 64);
         acc += __shfl_xor(acc, 16, 64);
@@ -380,7 +510,8 @@ __device__ __forceinline__ bool spk_converged(double s4, int it, double& prev_su
         double ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
         ratio = fmin(fmax(ratio, 0.0), 0.9999);
         const double tail = delta * ratio / (1.0 - ratio);
-        if (delta <= 4e-16 * s4 || (it >= 3 && tail <= 1e-14 * s4)) conv = true;
+        // (the Ritz sum itself carries ~2e-15 of rounding noise: a change below 2e-14 is at the floor)
+        if (it >= 3 && (delta <= 2e-14 * s4 || tail <= 1e-14 * s4)) conv = true;
     }
     prev_delta = delta;
     prev_sum = s4;
@@ -389,19 +520,6 @@ __device__ __forceinline__ bool spk_converged(double s4, int it, double& prev_su
 
 // status: bit 0 = iteration cap hit (score written but flagged), bit 1 = not handled here (re-score on the
 // dense route), bits 8.. = number of operator applications.
-#ifdef SPK_STAMPS
-__device__ long long g_spk_stamps[64];
-#define SSTAMP(i)                                                                              \
-    do {                                                                                       \
-        __syncthreads();                                                                       \
-        if (threadIdx.x == 0 && blockIdx.x == 0) g_spk_stamps[i] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-extern "C" int sp_debug_spk_stamps(long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spk_stamps), sizeof(long long) * 64) == hipSuccess ? 0 : 2;
-}
-#else
-#define SSTAMP(i)
-#endif
 
 __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restrict__ keys,
                                                               const u32* __restrict__ counts, int64_t D, int n,
@@ -433,8 +551,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
     const int kc_cap = (int)min((long long)D, nc >= 8 ? (long long)D : (1ll << (2 * nc)));
     const int r_cap = (int)min((long long)D, nr >= 8 ? (long long)D : (1ll << (2 * nr)));
     const bool small_sure = r_cap <= SPK_SMALL_R;   // then no CSR list is needed
-    const size_t need_build = off + (size_t)D * (small_sure ? 4 : 8) + ((size_t)D / SPK_HEAVY + 2) * 4 +
-                              (size_t)(kc_cap + r_cap + 2) * 2 + (size_t)D * 6 + (size_t)W * 12 + 256;
+    const size_t need_build = off + (size_t)D * (small_sure ? 4 : 8) + (size_t)D * 6 + (size_t)W * 12 + 256;
     if (D > 65535 || n > 16 || need_build + 2048 > SPK_LDS_BYTES) {
         if (threadIdx.x == 0) {
             scores[sid] = 0.0;
@@ -447,10 +564,6 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
     // building, then V and W (or G).  Sizes that depend on R / Kc are carved after the ranks are known.
     u32* csc_ent = reinterpret_cast<u32*>(carve((size_t)D * 4));
     u32* csr_ent = small_sure ? nullptr : reinterpret_cast<u32*>(carve((size_t)D * 4));
-    unsigned short* heavy_c = reinterpret_cast<unsigned short*>(carve(((size_t)D / SPK_HEAVY + 2) * 2));
-    unsigned short* heavy_r = reinterpret_cast<unsigned short*>(carve(((size_t)D / SPK_HEAVY + 2) * 2));
-    unsigned short* csc_ptr = reinterpret_cast<unsigned short*>(carve((size_t)(kc_cap + 1) * 2));
-    unsigned short* csr_ptr = reinterpret_cast<unsigned short*>(carve((size_t)(r_cap + 1) * 2));
     const size_t off_after_lists = off;
     u32* pc = reinterpret_cast<u32*>(carve((size_t)D * 4));
     unsigned short* cnt = reinterpret_cast<unsigned short*>(carve((size_t)D * 2));
@@ -521,24 +634,38 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
     __syncthreads();
     const bool small = small_sure;   // (R <= 64 with a larger bound simply takes the general path)
     const int Rp = (R + 3) & ~3;
-    // the key bitmaps are dead now: the occupancy bitmap of the list builder starts there
+    // pointer + permutation arrays (now that R and Kc are known) are carved top-down from the end of LDS; the
+    // key bitmaps are dead: the counting-sort counters start where they were
+    size_t top = SPK_LDS_BYTES;
+    auto carve_top = [&](size_t bytes) {
+        top = (top - bytes) & ~(size_t)15;
+        return smem + top;
+    };
+    unsigned short* csc_ptr = reinterpret_cast<unsigned short*>(carve_top((size_t)(Kc + 1) * 2));
+    unsigned short* csr_ptr = reinterpret_cast<unsigned short*>(carve_top((size_t)(R + 1) * 2));
+    unsigned short* perm_c = reinterpret_cast<unsigned short*>(carve_top((size_t)Kc * 2));
+    unsigned short* perm_r = reinterpret_cast<unsigned short*>(carve_top((size_t)R * 2));
     const size_t build_end = reinterpret_cast<unsigned char*>(bm) - smem;
-    // iteration-time layout of region B:  V  W|G
     const size_t need_iter = off_after_lists + (size_t)Rp * SPK_VP * 8 + 16 +
                              (small ? (size_t)R * R * 8 : (size_t)Kc * 4 * 8);
-    const size_t min_tmp = (size_t)(((R > Kc ? R : Kc) + 63) / 64) * 8 * 8;  // at least 8 major indices per chunk
-    if (need_iter > SPK_LDS_BYTES || build_end + min_tmp > SPK_LDS_BYTES || Kc > 65535) {
+    // counters: SPK_WAVES rows of 16-bit (8-bit when a group cannot exceed 255 entries) fields
+    const bool bits8 = R <= 255 && small;
+    const size_t cw_c = (size_t)SPK_WAVES * ((Kc + (bits8 ? 3 : 1)) / (bits8 ? 4 : 2)) * 4;
+    const size_t cw_r = small ? 0 : (size_t)SPK_WAVES * ((R + 1) / 2) * 4;
+    if (need_iter > top || build_end + (cw_c > cw_r ? cw_c : cw_r) > top || Kc > 65535) {
         if (threadIdx.x == 0) {
             scores[sid] = 0.0;
             status[sid] = 2;
         }
         return;
     }
-    u64* tmp = reinterpret_cast<u64*>(smem + build_end);
-    const int tmp_words = (int)((SPK_LDS_BYTES - build_end) / 8);
-    spk_build_list<true>(pc, cnt, Di, Kc, R, csc_ptr, csc_ent, heavy_c, &sh.nheavy_c, tmp, tmp_words, sh);
+    u32* cwbuf = reinterpret_cast<u32*>(smem + build_end);
+    if (bits8)
+        spk_build_list<true, 8>(pc, cnt, Di, Kc, csc_ptr, csc_ent, perm_c, &sh.nheavy_c, cwbuf, sh);
+    else
+        spk_build_list<true, 16>(pc, cnt, Di, Kc, csc_ptr, csc_ent, perm_c, &sh.nheavy_c, cwbuf, sh);
     SSTAMP(2);
-    if (!small) spk_build_list<false>(pc, cnt, Di, R, Kc, csr_ptr, csr_ent, heavy_r, &sh.nheavy_r, tmp, tmp_words, sh);
+    if (!small) spk_build_list<false, 16>(pc, cnt, Di, R, csr_ptr, csr_ent, perm_r, &sh.nheavy_r, cwbuf, sh);
     SSTAMP(3);
     // ---- start block: unit vectors on the rows of the 4 largest counts (distinct rows) ----------------------------
     // (the dominant singular vectors of a count flattening sit on the few very frequent patterns); chosen by four
@@ -590,7 +717,8 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
                 const int ra = va & 0xFFFF;
                 for (int b = a + j; b < p1; b += 4) {
                     const u32 vb = csc_ent[b];
-                    atomicAdd(&G64[ra * R + (vb & 0xFFFF)], ca * (unsigned long long)(vb >> 16));  // ra <= rb
+                    const int rb = vb & 0xFFFF;   // entries of a column are in table order, not row order
+                    atomicAdd(&G64[min(ra, rb) * R + max(ra, rb)], ca * (unsigned long long)(vb >> 16));
                 }
             }
         }
@@ -632,9 +760,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
             __syncthreads();
         } else {
             if (it == 1) SSTAMP(7);
-            spk_spmm(csc_ptr, csc_ent, Kc, heavy_c, sh.nheavy_c, V, SPK_VP, Wb, 4);   // W = C^T V
+            spk_spmm(csc_ptr, csc_ent, Kc, perm_c, sh.nheavy_c, V, SPK_VP, Wb, 4, it == 1 ? 20 : -1);   // W = C^T V
             if (it == 1) SSTAMP(8);
-            spk_spmm(csr_ptr, csr_ent, R, heavy_r, sh.nheavy_r, Wb, 4, V, SPK_VP);    // Y = C W  (overwrites V)
+            spk_spmm(csr_ptr, csr_ent, R, perm_r, sh.nheavy_r, Wb, 4, V, SPK_VP, it == 1 ? 21 : -1);    // Y = C W  (overwrites V)
             if (it == 1) SSTAMP(9);
         }
         spk_ritz_orth(V, R, sh);
