@@ -256,16 +256,25 @@ __device__ __forceinline__ void spk_apply_reg(double* X, int R, const double (&t
     __syncthreads();
 }
 
+// 4 x 4 matrix product c = a b (row-major), registers
+__device__ __forceinline__ void mm4(const double (&a)[16], const double (&b)[16], double (&c)[16]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            c[4 * i + j] = a[4 * i] * b[j] + a[4 * i + 1] * b[4 + j] + a[4 * i + 2] * b[8 + j] + a[4 * i + 3] * b[12 + j];
+}
+
 // Ritz values + next orthonormal block from Y (held in X), in place.
-//   Fast path - polar decomposition by Newton-Schulz: Y = U H with U = Y (Y^T Y)^-1/2 orthonormal and
-//   H = (Y^T Y)^1/2, so trace(H) = sum_i sqrt(eig_i(Y^T Y)) is exactly the sum of the four Ritz values and U is
-//   the next block.  With S0 = Y^T Y, X = c Y and X <- X (1.5 I - 0.5 X^T X) repeated, U = Y T (T the accumulated
-//   4 x 4 transform, starting at c I) and trace(H) = trace(T^T S0).  Everything is 4 x 4 algebra done redundantly by
-//   every thread plus one 10-value block reduction per step.  Taken when Y is well conditioned (column norms within
-//   a factor 7, scaled off-diagonals <= 0.25) - true from the first product on for count flattenings, whose four
-//   leading singular values are of one magnitude; then 3-4 steps reach fp64 orthonormality.
-//   Robust path (anything else: arbitrary start blocks / matrices): Jacobi eigen-decomposition of S0, X <- X P D^-1/2,
-//   then the same Newton-Schulz polish.
+//   Polar decomposition Y = U H:  U = Y (Y^T Y)^-1/2 is orthonormal and H = (Y^T Y)^1/2, so trace(H) =
+//   sum_i sqrt(eig_i(Y^T Y)) is exactly the sum of the four Ritz values and U is the next block.
+//   S0 = Y^T Y (one block reduction);  Z = S0^-1/2 by the coupled Newton-Schulz iteration on the 4 x 4 matrix itself
+//   (registers of wave 0: A <- A (3I - Z A)/2, Z <- (3I - Z A) Z / 2 from A = c S0, Z = I with c = 1 / Gershgorin
+//   bound, quadratic);  X <- X Z sqrt(c);  one Newton-Schulz polish step on the block removes the rounding of the 4 x 4
+//   solve;  trace(H) = trace(T^T S0) with T the total transform.
+//   Taken when Y is well conditioned (column norms within a factor 7, scaled off-diagonals <= 0.25) - true from the
+//   first product on for count flattenings, whose four leading singular values are of one magnitude.
+//   Otherwise (arbitrary blocks / matrices): Jacobi eigen-decomposition of S0, X <- X P D^-1/2, then the same polish.
 __device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh) {
     spk_gram(X, R, sh);
     double s0[16], t[16];
@@ -288,28 +297,51 @@ __device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh) {
         for (int j = i + 1; j < 4; ++j) offmax = fmax(offmax, fabs(s0[4 * i + j]) * d[i] * d[j]);
     }
     double top_jacobi = -1.0;
+    __syncthreads();
     if (all_alive && offmax <= 0.25 && dmin >= 0.02 * dmax) {
-        // ONE scalar scale (a column scaling would change the polar factor and trace(U^T Y) would no longer be the
-        // sum of the singular values): 1 / sqrt(Gershgorin bound) puts every singular value of X in (0, 1]
-        double gb = 0;
+        if (threadIdx.x < 64) {   // wave 0: Z = (c S0)^-1/2
+            double gb = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            gb = fmax(gb, fabs(s0[4 * i]) + fabs(s0[4 * i + 1]) + fabs(s0[4 * i + 2]) + fabs(s0[4 * i + 3]));
-        const double c = spk_rsqrt(gb);
+            for (int i = 0; i < 4; ++i)
+                gb = fmax(gb, fabs(s0[4 * i]) + fabs(s0[4 * i + 1]) + fabs(s0[4 * i + 2]) + fabs(s0[4 * i + 3]));
+            const double c = 1.0 / gb;
+            double a[16], z[16], m[16], tmp[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t[i] = 0.0;
+            for (int i = 0; i < 16; ++i) {
+                a[i] = c * s0[i];
+                z[i] = (i % 5 == 0) ? 1.0 : 0.0;
+            }
+            for (int iter = 0; iter < 12; ++iter) {
+                mm4(z, a, m);                      // m = Z A  -> I
+                double err = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) t[5 * i] = c;
-    } else {
+                for (int i = 0; i < 16; ++i) {
+                    err = fmax(err, fabs(m[i] - ((i % 5 == 0) ? 1.0 : 0.0)));
+                    m[i] = ((i % 5 == 0) ? 1.5 : 0.0) - 0.5 * m[i];
+                }
+                if (err <= 1e-15) break;
+                mm4(a, m, tmp);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a[i] = tmp[i];
+                mm4(m, z, tmp);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i] = tmp[i];
+            }
+            const double sc = sqrt(c);
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sh.T[i] = z[i] * sc;
+            }
+        }
         __syncthreads();
+    } else {
         spk_jacobi4(sh);   // writes sh.T = P D^-1/2 and sh.top4
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t[i] = sh.T[i];
         top_jacobi = sh.top4;
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = sh.T[i];
     spk_apply_reg(X, R, t);
-    double pred = 1.0;
-    for (int iter = 0; iter < 12; ++iter) {
+    for (int iter = 0; iter < 12; ++iter) {   // polish (normally exactly one step)
         spk_gram(X, R, sh);
         double sk[16];
         spk_sym_from(sh.S, sk);
@@ -322,26 +354,17 @@ __device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh) {
                 err = fmax(err, fabs(sk[4 * i + j] - target));
             }
         if (err <= 2e-15) break;
-        // M = 1.5 I - 0.5 S ;  T <- T M ;  X <- X M
         double m[16], tn[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) m[4 * i + j] = (i == j ? 1.5 : 0.0) - 0.5 * sk[4 * i + j];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                tn[4 * i + j] = t[4 * i] * m[j] + t[4 * i + 1] * m[4 + j] + t[4 * i + 2] * m[8 + j] + t[4 * i + 3] * m[12 + j];
+        mm4(t, m, tn);
 #pragma unroll
         for (int i = 0; i < 16; ++i) t[i] = tn[i];
         spk_apply_reg(X, R, m);
-        pred = err * err;           // Newton-Schulz squares the defect (constant < 1)
-        if (pred <= 1e-17) break;   // the step just applied brought it below fp64 resolution: no need to re-measure
+        if (err * err <= 1e-17) break;   // the step just applied squares the defect: below fp64 resolution
     }
-#ifdef SPK_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x == 0) g_spk_stamps[30] = top_jacobi >= 0 ? 100 : 0;
-#endif
     // sum of the Ritz values = trace(T^T S0)   (Jacobi path: S0's eigenvalues were computed directly)
     double tr = 0;
 #pragma unroll
@@ -363,7 +386,7 @@ __device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh) {
 template <bool MAJOR_IS_COL, int BITS>
 __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned short* cnt, int D, int nmajor,
                                                unsigned short* ptr, u32* ent, unsigned short* perm, int* nheavy,
-                                               u32* cw, SpkShared& sh) {
+                                               u32* cw, SpkShared& sh, unsigned short* group_of = nullptr) {
     constexpr int PER = 32 / BITS;                     // counters per word
     constexpr u32 FMASK = (1u << BITS) - 1;
     const int stride = (nmajor + PER - 1) / PER;       // words per wave row
@@ -374,7 +397,13 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
     if (threadIdx.x < 68) sh.bucket[threadIdx.x] = 0;
     __syncthreads();
     u32* myrow = cw + w * stride;
-    for (int i = lo + lane; i < hi; i += 64) {           // pass A: per-chunk group sizes
+    // lane l walks the contiguous sub-chunk [lo + l*q, lo + (l+1)*q): consecutive table entries share their leading
+    // digits (hence often their row or column), so giving them to ONE lane keeps the 64 lanes of an atomic on
+    // different counters (measured: 64-way same-word conflicts otherwise)
+    const int q = chunk / 64;
+    for (int t = 0; t < q; ++t) {                         // pass A: per-chunk group sizes
+        const int i = lo + lane * q + t;
+        if (i >= hi) continue;
         const u32 v = pc[i];
         const int mj = MAJOR_IS_COL ? (int)(v & 0xFFFF) : (int)(v >> 16);
         atomicAdd(&myrow[mj / PER], 1u << (BITS * (mj % PER)));
@@ -434,12 +463,16 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
         const int c = ptr[m + 1] - ptr[m];
         perm[atomicAdd(&sh.bucket[c > 64 ? 64 : c], 1u)] = (unsigned short)m;   // order inside a bucket is irrelevant
     }
-    for (int i = lo + lane; i < hi; i += 64) {           // pass B: placement
+    for (int t = 0; t < q; ++t) {                         // pass B: placement (same walk as pass A)
+        const int i = lo + lane * q + t;
+        if (i >= hi) continue;
         const u32 v = pc[i];
         const int mj = MAJOR_IS_COL ? (int)(v & 0xFFFF) : (int)(v >> 16);
         const int mn = MAJOR_IS_COL ? (int)(v >> 16) : (int)(v & 0xFFFF);
         const u32 old = atomicAdd(&myrow[mj / PER], 1u << (BITS * (mj % PER)));
-        ent[ptr[mj] + ((old >> (BITS * (mj % PER))) & FMASK)] = (u32)mn | ((u32)cnt[i] << 16);
+        const int pos = ptr[mj] + (int)((old >> (BITS * (mj % PER))) & FMASK);
+        ent[pos] = (u32)mn | ((u32)cnt[i] << 16);
+        if (group_of) group_of[pos] = (unsigned short)mj;
     }
     __syncthreads();
 }
@@ -572,10 +605,22 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
     const int* shifts = sh.shifts;
     for (int i = threadIdx.x; i < W; i += SPK_THREADS) bm[i] = 0;
     unsigned long long tr = 0;
+    // cell = sum_t digit_t(key) << dst_t: source / destination shifts are wave-uniform -> scalar registers
+    int ssrc[16], sdst[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int valid = t < nr + nc;
+        ssrc[t] = __builtin_amdgcn_readfirstlane(valid ? shifts[t] : 0);
+        sdst[t] = __builtin_amdgcn_readfirstlane(valid ? (t < nr ? 2 * (nc + nr - 1 - t) : 2 * (nr + nc - 1 - t)) : 0);
+    }
+    const int ntax = nr + nc;
     for (int i = threadIdx.x; i < Di; i += SPK_THREADS) {  // no atomics in this loop: the loads pipeline
-        u32 r, c;
-        spk_rowcol(keys[i], shifts, nr, nc, r, c);
-        pc[i] = (r << (2 * nc)) | c;
+        const u64 key = keys[i];
+        u32 cell = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (t < ntax) cell |= (u32)((key >> ssrc[t]) & 3ull) << sdst[t];
+        pc[i] = cell;
         const u32 v = counts[i];
         cnt[i] = (unsigned short)v;
         tr += (unsigned long long)v * v;
@@ -660,8 +705,20 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
         return;
     }
     u32* cwbuf = reinterpret_cast<u32*>(smem + build_end);
+    // small path: column of every CSC position (for the entry-parallel Gram below); it lives in the W / G area's tail
+    unsigned short* colof = nullptr;
+    if (small) {
+        colof = reinterpret_cast<unsigned short*>(carve_top((size_t)Di * 2));
+        if (need_iter > top || build_end + cw_c > top) {
+            if (threadIdx.x == 0) {
+                scores[sid] = 0.0;
+                status[sid] = 2;
+            }
+            return;
+        }
+    }
     if (bits8)
-        spk_build_list<true, 8>(pc, cnt, Di, Kc, csc_ptr, csc_ent, perm_c, &sh.nheavy_c, cwbuf, sh);
+        spk_build_list<true, 8>(pc, cnt, Di, Kc, csc_ptr, csc_ent, perm_c, &sh.nheavy_c, cwbuf, sh, colof);
     else
         spk_build_list<true, 16>(pc, cnt, Di, Kc, csc_ptr, csc_ent, perm_c, &sh.nheavy_c, cwbuf, sh);
     SSTAMP(2);
@@ -672,31 +729,50 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
     // rounds of a block arg-max over (count, index), deterministic tie-break.
     int top_row[SPK_NB];
     {
-        unsigned long long* slot = reinterpret_cast<unsigned long long*>(sh.red);
+        // each lane keeps the best (count, index) of its strided entries; each wave extracts its 4 best lane
+        // candidates with distinct rows (shuffles only); wave 0 picks the 4 best distinct rows of the 32 candidates.
+        // Candidate = (count << 32) | (0xFFFFFFFF - index): max = largest count, lowest index.  Any 4 strong distinct
+        // rows make a good start block; exact ties / a lane holding two of the top rows only cost a bit of start quality.
+        unsigned long long* slot = reinterpret_cast<unsigned long long*>(sh.red);   // SPK_WAVES * 4 entries
+        int* rows_out = reinterpret_cast<int*>(sh.S);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        unsigned long long mine = 0;
+        for (int i = threadIdx.x; i < Di; i += SPK_THREADS) {
+            const unsigned long long cand = ((unsigned long long)cnt[i] << 32) | (0xFFFFFFFFull - (unsigned)i);
+            mine = cand > mine ? cand : mine;
+        }
+        int myrow = mine ? (int)(pc[(int)(0xFFFFFFFFull - (mine & 0xFFFFFFFFull))] >> 16) : -1;
         for (int k = 0; k < SPK_NB; ++k) {
-            unsigned long long best = 0;  // (count << 32) | (0xFFFFFFFF - index): max picks the largest count, lowest index
-            for (int i = threadIdx.x; i < Di; i += SPK_THREADS) {
-                const int rr = (int)(pc[i] >> 16);
-                bool taken = false;
-                for (int q = 0; q < k; ++q) taken |= (top_row[q] == rr);
-                if (!taken) {
-                    const unsigned long long cand = ((unsigned long long)cnt[i] << 32) | (0xFFFFFFFFull - (unsigned)i);
-                    best = cand > best ? cand : best;
-                }
-            }
+            unsigned long long best = mine;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
                 const unsigned long long o = __shfl_xor(best, d, 64);
                 best = o > best ? o : best;
             }
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = best;
-            __syncthreads();
-            unsigned long long b = 0;
-            for (int i = 0; i < SPK_WAVES; ++i) b = slot[i] > b ? slot[i] : b;
-            top_row[k] = b ? (int)(pc[(int)(0xFFFFFFFFull - (b & 0xFFFFFFFFull))] >> 16) : -1;
-            __syncthreads();
+            const int brow = best ? (int)(pc[(int)(0xFFFFFFFFull - (best & 0xFFFFFFFFull))] >> 16) : -1;
+            if (lane == 0) slot[w * SPK_NB + k] = best;
+            if (myrow == brow) mine = 0;   // this row is taken: drop every lane candidate on it
         }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            unsigned long long c = lane < SPK_WAVES * SPK_NB ? slot[lane] : 0;
+            int crow = c ? (int)(pc[(int)(0xFFFFFFFFull - (c & 0xFFFFFFFFull))] >> 16) : -1;
+            for (int k = 0; k < SPK_NB; ++k) {
+                unsigned long long best = c;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const unsigned long long o = __shfl_xor(best, d, 64);
+                    best = o > best ? o : best;
+                }
+                const int brow = best ? (int)(pc[(int)(0xFFFFFFFFull - (best & 0xFFFFFFFFull))] >> 16) : -1;
+                if (lane == 0) rows_out[k] = brow;
+                if (crow == brow) c = 0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SPK_NB; ++k) top_row[k] = rows_out[k];
+        __syncthreads();
     }
     SSTAMP(4);
     // V and W / G are laid out over the (now dead) staging area
@@ -707,19 +783,18 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
         unsigned long long* G64 = reinterpret_cast<unsigned long long*>(Wb);
         for (int i = threadIdx.x; i < R * R; i += SPK_THREADS) G64[i] = 0;
         __syncthreads();
-        // exact Gram: pairs inside every column; one 4-lane group per column, lanes split the second index
-        const int j = threadIdx.x & 3, g = threadIdx.x >> 2;
-        for (int c = g; c < Kc; c += SPK_THREADS / 4) {
-            const int p0 = csc_ptr[c], p1 = csc_ptr[c + 1];
-            for (int a = p0; a < p1; ++a) {
-                const u32 va = csc_ent[a];
-                const unsigned long long ca = va >> 16;
-                const int ra = va & 0xFFFF;
-                for (int b = a + j; b < p1; b += 4) {
-                    const u32 vb = csc_ent[b];
-                    const int rb = vb & 0xFFFF;   // entries of a column are in table order, not row order
-                    atomicAdd(&G64[min(ra, rb) * R + max(ra, rb)], ca * (unsigned long long)(vb >> 16));
-                }
+        // exact Gram: all pairs (a <= b) inside every column.  One thread per CSC position a, walking the rest of its
+        // column (<= R <= 64 steps); consecutive positions belong to consecutive threads, so a long column is spread
+        // over many lanes.  u64 LDS atomics: integer, hence exact and order independent.
+        for (int a = threadIdx.x; a < Di; a += SPK_THREADS) {
+            const u32 va = csc_ent[a];
+            const unsigned long long ca = va >> 16;
+            const int ra = va & 0xFFFF;
+            const int p1 = csc_ptr[colof[a] + 1];
+            for (int b = a; b < p1; ++b) {
+                const u32 vb = csc_ent[b];
+                const int rb = vb & 0xFFFF;   // entries of a column are in table order, not row order
+                atomicAdd(&G64[min(ra, rb) * R + max(ra, rb)], ca * (unsigned long long)(vb >> 16));
             }
         }
         __syncthreads();
@@ -743,7 +818,6 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
     }
     __syncthreads();
     SSTAMP(5);
-    spk_ritz_orth(V, R, sh);
     SSTAMP(6);
     // ---- iteration ------------------------------------------------------------------------------------------
     double prev_sum = 0, prev_delta = 0, top4 = 0;
