@@ -53,6 +53,8 @@ struct SpkShared {
     double red[SPK_WAVES * 12];
     double S[12];        // 10 unique entries of the symmetric 4 x 4 (row-major upper: 00 01 02 03 11 12 13 22 23 33)
     double T[16];        // 4 x 4 transform applied to the block
+    double Zprev[16];    // S0^-1/2 of the previous product (warm start of the inverse-square-root iteration)
+    int have_z, padz;
     double top4;
     unsigned long long trace;
     int R, Kc, nheavy_c, nheavy_r, flag, pad;
@@ -116,9 +118,9 @@ __device__ __forceinline__ void spk_gram(const double* X, int R, SpkShared& sh) 
     for (int i = 0; i < 10; ++i) s[i] = 0;
     for (int row = threadIdx.x; row < R; row += SPK_THREADS) {
         const double a = X[row * SPK_VP], b = X[row * SPK_VP + 1], c = X[row * SPK_VP + 2], d = X[row * SPK_VP + 3];
-        s[0] += a * a; s[1] += a * b; s[2] += a * c; s[3] += a * d;
-        s[4] += b * b; s[5] += b * c; s[6] += b * d;
-        s[7] += c * c; s[8] += c * d; s[9] += d * d;
+        s[0] = fma(a, a, s[0]); s[1] = fma(a, b, s[1]); s[2] = fma(a, c, s[2]); s[3] = fma(a, d, s[3]);
+        s[4] = fma(b, b, s[4]); s[5] = fma(b, c, s[5]); s[6] = fma(b, d, s[6]);
+        s[7] = fma(c, c, s[7]); s[8] = fma(c, d, s[8]); s[9] = fma(d, d, s[9]);
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -262,7 +264,7 @@ __device__ __forceinline__ void mm4(const double (&a)[16], const double (&b)[16]
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            c[4 * i + j] = a[4 * i] * b[j] + a[4 * i + 1] * b[4 + j] + a[4 * i + 2] * b[8 + j] + a[4 * i + 3] * b[12 + j];
+            c[4 * i + j] = fma(a[4 * i], b[j], fma(a[4 * i + 1], b[4 + j], fma(a[4 * i + 2], b[8 + j], a[4 * i + 3] * b[12 + j])));
 }
 
 // Ritz values + next orthonormal block from Y (held in X), in place.
@@ -275,8 +277,10 @@ __device__ __forceinline__ void mm4(const double (&a)[16], const double (&b)[16]
 //   Taken when Y is well conditioned (column norms within a factor 7, scaled off-diagonals <= 0.25) - true from the
 //   first product on for count flattenings, whose four leading singular values are of one magnitude.
 //   Otherwise (arbitrary blocks / matrices): Jacobi eigen-decomposition of S0, X <- X P D^-1/2, then the same polish.
-__device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh) {
+__device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh, int st0 = -1) {
+    if (st0 >= 0) SSTAMP(st0);
     spk_gram(X, R, sh);
+    if (st0 >= 0) SSTAMP(st0 + 1);
     double s0[16], t[16];
     spk_sym_from(sh.S, s0);
     const double dmax = fmax(fmax(s0[0], s0[5]), fmax(s0[10], s0[15]));
@@ -299,38 +303,58 @@ __device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh) {
     double top_jacobi = -1.0;
     __syncthreads();
     if (all_alive && offmax <= 0.25 && dmin >= 0.02 * dmax) {
-        if (threadIdx.x < 64) {   // wave 0: Z = (c S0)^-1/2
-            double gb = 0;
+        if (threadIdx.x < 64) {   // wave 0: Z = S0^-1/2, all lanes redundantly in registers
+            double z[16], m[16], tmp[16];
+            // Newton iteration Z <- Z (3I - Z S0 Z) / 2 (locally quadratic).  Warm start: once the block has settled in
+            // the invariant subspace, S0 = V^T G^2 V barely changes from one product to the next, so the previous
+            // inverse square root is already accurate to ~1e-5 and two steps finish it.  Cold start: c I with
+            // c = 1 / sqrt(Gershgorin bound) (every eigenvalue of c^2 S0 in (0, 1]).
+            bool warm = sh.have_z != 0;
+            if (warm) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                gb = fmax(gb, fabs(s0[4 * i]) + fabs(s0[4 * i + 1]) + fabs(s0[4 * i + 2]) + fabs(s0[4 * i + 3]));
-            const double c = 1.0 / gb;
-            double a[16], z[16], m[16], tmp[16];
+                for (int i = 0; i < 16; ++i) z[i] = sh.Zprev[i];
+                mm4(z, s0, tmp);
+                mm4(tmp, z, m);
+                double err = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                a[i] = c * s0[i];
-                z[i] = (i % 5 == 0) ? 1.0 : 0.0;
+                for (int i = 0; i < 16; ++i) err = fmax(err, fabs(m[i] - ((i % 5 == 0) ? 1.0 : 0.0)));
+                warm = err < 0.5;
             }
+            if (!warm) {
+                double gb = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    gb = fmax(gb, fabs(s0[4 * i]) + fabs(s0[4 * i + 1]) + fabs(s0[4 * i + 2]) + fabs(s0[4 * i + 3]));
+                const double c = spk_rsqrt(gb);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i] = (i % 5 == 0) ? c : 0.0;
+            }
+            // every pass measures m = Z S0 Z and applies the Newton factor (1.5 I - 0.5 m); the pass whose MEASURED
+            // defect is already <= 1e-8 leaves a defect of ~1e-16 behind (the step squares it), so it is the last one
+            // and doubles as the polish: no second block reduction is needed on this path.
+            double prev_err = 1e300;
             for (int iter = 0; iter < 12; ++iter) {
-                mm4(z, a, m);                      // m = Z A  -> I
+                mm4(z, s0, tmp);
+                mm4(tmp, z, m);                    // m = Z S0 Z -> I
                 double err = 0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     err = fmax(err, fabs(m[i] - ((i % 5 == 0) ? 1.0 : 0.0)));
                     m[i] = ((i % 5 == 0) ? 1.5 : 0.0) - 0.5 * m[i];
                 }
-                if (err <= 1e-15) break;
-                mm4(a, m, tmp);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) a[i] = tmp[i];
-                mm4(m, z, tmp);
+                mm4(z, m, tmp);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) z[i] = tmp[i];
+                if (err <= 1e-8 || err >= prev_err) break;
+                prev_err = err;
             }
-            const double sc = sqrt(c);
             if (threadIdx.x == 0) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sh.T[i] = z[i] * sc;
+                for (int i = 0; i < 16; ++i) {
+                    sh.T[i] = z[i];
+                    sh.Zprev[i] = z[i];
+                }
+                sh.have_z = 1;
             }
         }
         __syncthreads();
@@ -338,10 +362,12 @@ __device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh) {
         spk_jacobi4(sh);   // writes sh.T = P D^-1/2 and sh.top4
         top_jacobi = sh.top4;
     }
+    if (st0 >= 0) SSTAMP(st0 + 2);
 #pragma unroll
     for (int i = 0; i < 16; ++i) t[i] = sh.T[i];
     spk_apply_reg(X, R, t);
-    for (int iter = 0; iter < 12; ++iter) {   // polish (normally exactly one step)
+    if (st0 >= 0) SSTAMP(st0 + 3);
+    for (int iter = 0; iter < 12 && top_jacobi >= 0; ++iter) {   // block polish: robust (Jacobi) path only
         spk_gram(X, R, sh);
         double sk[16];
         spk_sym_from(sh.S, sk);
@@ -365,6 +391,7 @@ __device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh) {
         spk_apply_reg(X, R, m);
         if (err * err <= 1e-17) break;   // the step just applied squares the defect: below fp64 resolution
     }
+    if (st0 >= 0) SSTAMP(st0 + 4);
     // sum of the Ritz values = trace(T^T S0)   (Jacobi path: S0's eigenvalues were computed directly)
     double tr = 0;
 #pragma unroll
@@ -486,6 +513,10 @@ __device__ __forceinline__ double spk_term(const u32* ent, int e, const double* 
     const u32 v = ent[e];
     return (double)(v >> 16) * in[(v & 0xFFFFu) * in_pitch + j];
 }
+__device__ __forceinline__ double spk_acc(double acc, const u32* ent, int e, const double* in, int in_pitch, int j) {
+    const u32 v = ent[e];
+    return fma((double)(v >> 16), in[(v & 0xFFFFu) * in_pitch + j], acc);   // explicit fma: the build has contraction off
+}
 
 __device__ __forceinline__ void spk_spmm(const unsigned short* ptr, const u32* ent, int nmajor,
                                          const unsigned short* perm, int nheavy, const double* in, int in_pitch,
@@ -497,14 +528,14 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptr, const u32* e
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         int e = p0;
         for (; e + 3 < p1; e += 4) {
-            a0 += spk_term(ent, e, in, in_pitch, j);
-            a1 += spk_term(ent, e + 1, in, in_pitch, j);
-            a2 += spk_term(ent, e + 2, in, in_pitch, j);
-            a3 += spk_term(ent, e + 3, in, in_pitch, j);
+            a0 = spk_acc(a0, ent, e, in, in_pitch, j);
+            a1 = spk_acc(a1, ent, e + 1, in, in_pitch, j);
+            a2 = spk_acc(a2, ent, e + 2, in, in_pitch, j);
+            a3 = spk_acc(a3, ent, e + 3, in, in_pitch, j);
         }
-        if (e < p1) a0 += spk_term(ent, e, in, in_pitch, j);
-        if (e + 1 < p1) a1 += spk_term(ent, e + 1, in, in_pitch, j);
-        if (e + 2 < p1) a2 += spk_term(ent, e + 2, in, in_pitch, j);
+        if (e < p1) a0 = spk_acc(a0, ent, e, in, in_pitch, j);
+        if (e + 1 < p1) a1 = spk_acc(a1, ent, e + 1, in, in_pitch, j);
+        if (e + 2 < p1) a2 = spk_acc(a2, ent, e + 2, in, in_pitch, j);
         out[m * out_pitch + j] = (a0 + a1) + (a2 + a3);
     }
 #ifdef SPK_STAMPS
@@ -518,14 +549,14 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptr, const u32* e
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         int e = p0 + sg;
         for (; e + 48 < p1; e += 64) {
-            a0 += spk_term(ent, e, in, in_pitch, j);
-            a1 += spk_term(ent, e + 16, in, in_pitch, j);
-            a2 += spk_term(ent, e + 32, in, in_pitch, j);
-            a3 += spk_term(ent, e + 48, in, in_pitch, j);
+            a0 = spk_acc(a0, ent, e, in, in_pitch, j);
+            a1 = spk_acc(a1, ent, e + 16, in, in_pitch, j);
+            a2 = spk_acc(a2, ent, e + 32, in, in_pitch, j);
+            a3 = spk_acc(a3, ent, e + 48, in, in_pitch, j);
         }
-        if (e < p1) a0 += spk_term(ent, e, in, in_pitch, j);
-        if (e + 16 < p1) a1 += spk_term(ent, e + 16, in, in_pitch, j);
-        if (e + 32 < p1) a2 += spk_term(ent, e + 32, in, in_pitch, j);
+        if (e < p1) a0 = spk_acc(a0, ent, e, in, in_pitch, j);
+        if (e + 16 < p1) a1 = spk_acc(a1, ent, e + 16, in, in_pitch, j);
+        if (e + 32 < p1) a2 = spk_acc(a2, ent, e + 32, in, in_pitch, j);
         double acc = (a0 + a1) + (a2 + a3);
         acc += __shfl_xor(acc, 4, 64);
         acc += __shfl_xor(acc, 8, 64);
@@ -568,7 +599,10 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
         const int t = threadIdx.x < nr + nc ? sp.taxa[threadIdx.x] : 0;
         sh.shifts[threadIdx.x] = 2 * (n - 1 - t);
     }
-    if (threadIdx.x == 0) sh.flag = 0;
+    if (threadIdx.x == 0) {
+        sh.flag = 0;
+        sh.have_z = 0;
+    }
     __syncthreads();  // shifts are read by every wave below
     size_t off = (sizeof(SpkShared) + 15) & ~(size_t)15;
     auto carve = [&](size_t bytes) {
@@ -839,7 +873,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
             spk_spmm(csr_ptr, csr_ent, R, perm_r, sh.nheavy_r, Wb, 4, V, SPK_VP, it == 1 ? 21 : -1);    // Y = C W  (overwrites V)
             if (it == 1) SSTAMP(9);
         }
-        spk_ritz_orth(V, R, sh);
+        spk_ritz_orth(V, R, sh, it == 2 ? 40 : -1);
         if (it == 1) SSTAMP(10);
         top4 = sh.top4;
         if (spk_converged(top4, it, prev_sum, prev_delta)) {

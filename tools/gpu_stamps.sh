@@ -1,7 +1,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 cd splitp_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DEIG_STAMPS -c eigen.hip -o /tmp/eigen_st.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DEIG_STAMPS -c eigen.hip -o /tmp/eigen_st.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsplitp_hip.so api.o flatten.o gram.o /tmp/eigen_st.o subflat.o hist.o
 cd ../..
 python - <<'PY'

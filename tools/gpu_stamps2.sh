@@ -27,5 +27,5 @@ for k in (5, 4, 3):
     st = np.array(out[:12], dtype=np.int64); d = np.diff(st)
     names_ = ["bitmaps+trace", "CSC build", "CSR build", "(carve)", "diag/G", "start block", "ritz_orth(init)", "(loop entry)", "spmm1", "spmm2", "ritz_orth(it1)", "rest of iterations"]
     names2 = ["stage+bitmaps", "CSC build", "CSR build", "start(argmax)", "V init/G", "ritz(init)", "-", "spmm1", "spmm2", "ritz(it1)", "rest"]
-    print(f"k={k}:", "  ".join(f"{a}={b}" for a, b in zip(names2, d)), " total", st[11]-st[0], " | spmm1 light", out[20]-st[7], "heavy", st[8]-out[20], " spmm2 light", out[21]-st[8], "heavy", st[9]-out[21], "nheavy?", out[30])
+    print(f"k={k}:", "  ".join(f"{a}={b}" for a, b in zip(names2, d)), " total", st[11]-st[0], " | spmm1 light", out[20]-st[7], "heavy", st[8]-out[20], " spmm2 light", out[21]-st[8], "heavy", st[9]-out[21], "nheavy?", out[30], "| ritz(it2): gram", out[41]-out[40], "4x4", out[42]-out[41], "apply", out[43]-out[42], "polish", out[44]-out[43])
 PY
