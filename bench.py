@@ -111,20 +111,31 @@ def main():
     code = batch._method_code(sp.Method.flattening, args.route)
     ctx = aligns[0].ctx
     per_rank = args.alignments * n_splits
-    send = torch.zeros(per_rank, dtype=torch.float64, device=dev_t)
-    recv = torch.zeros(world * per_rank, dtype=torch.float64, device=dev_t) if world > 1 else None
-    host = torch.zeros(world * per_rank, dtype=torch.float64).pin_memory()
+    # one device buffer per rank: per_rank scores (f64) followed by per_rank status words (int32, padded to f64)
+    n_stat = (per_rank + 1) // 2
+    send = torch.zeros(per_rank + n_stat, dtype=torch.float64, device=dev_t)
+    recv = torch.zeros(world * (per_rank + n_stat), dtype=torch.float64, device=dev_t) if world > 1 else None
+    host = torch.zeros(world * (per_rank + n_stat), dtype=torch.float64).pin_memory()
+    host_np = host.numpy()
+    status_ptr = send.data_ptr() + per_rank * 8
 
     def step():
         for a, al in enumerate(aligns):
-            batch.score_encoded(al, taxa_arr, a_arr, code, scores_dev_ptr=send.data_ptr() + a * n_splits * 8,
-                                want_host=False)
+            batch.score_encoded_async(al, taxa_arr, a_arr, code, send.data_ptr() + a * n_splits * 8,
+                                      status_ptr + a * n_splits * 4)
         if world > 1:
             dist.all_gather_into_tensor(recv, send)
             host.copy_(recv, non_blocking=True)
         else:
-            host[:per_rank].copy_(send, non_blocking=True)
+            host.copy_(send, non_blocking=True)
         torch.cuda.current_stream().synchronize()   # scores are on the host: the unit of work is complete
+        # hand-back check (this rank's own shard): splits the in-LDS kernel could not take go to the dense route
+        mine = host_np[rank * (per_rank + n_stat):(rank + 1) * (per_rank + n_stat)]
+        st = mine[per_rank:].view(np.int32)[:per_rank]
+        if (st & 2).any():
+            for a, al in enumerate(aligns):
+                batch.finish_async(al, taxa_arr, a_arr, mine[a * n_splits:(a + 1) * n_splits],
+                                   st[a * n_splits:(a + 1) * n_splits])
 
     for _ in range(args.warmup):
         step()
@@ -146,7 +157,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    scores = host.numpy().copy()
+    scores = host_np[:per_rank].copy()
 
     if rank == 0:
         total_splits = world * per_rank * args.steps

@@ -168,6 +168,15 @@ int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* ci, const do
 int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
                     int method, double* scores_host, void* scores_dev, int32_t* status_host);
 
+/* Asynchronous form for pipelines that keep everything on the device (benchmark loop, multi-GPU all-gather):
+ * enqueues the scoring of the splits on the context's stream and returns without any host synchronisation.
+ *   scores_dev[n_splits] (double) and status_dev[n_splits] (int32) are device buffers written by the kernels.
+ * No hand-back is performed: with SP_METHOD_FLATTENING / _SPARSE a split the in-LDS kernel cannot take has
+ * status bit 1 set and an undefined score - the caller re-scores those with SP_METHOD_FLATTENING_DENSE after its
+ * own synchronisation (splitp_amd/batch.py does). */
+int sp_score_splits_async(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
+                          int method, void* scores_dev, void* status_dev);
+
 #ifdef __cplusplus
 }
 #endif

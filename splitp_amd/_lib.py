@@ -28,7 +28,7 @@ SYMBOLS = (
     "sp_alignment_destroy", "sp_alignment_info", "sp_alignment_fetch",
     "sp_flatten_indices", "sp_flatten_reduced_prepare", "sp_flatten_reduced_fetch", "sp_flatten_dense_counts",
     "sp_subflatten", "sp_moment_matrix",
-    "sp_score_matrix_f64", "sp_score_coo_f64", "sp_score_splits",
+    "sp_score_matrix_f64", "sp_score_coo_f64", "sp_score_splits", "sp_score_splits_async",
 )
 
 
@@ -89,6 +89,7 @@ def load():
         "sp_score_matrix_f64": [vp, P(dbl), i64, i64, i64, P(dbl)],
         "sp_score_coo_f64": [vp, P(i64), P(i64), P(dbl), i64, i64, i64, P(dbl)],
         "sp_score_splits": [vp, P(C.c_int32), P(C.c_int32), i64, i32, P(dbl), vp, P(C.c_int32)],
+        "sp_score_splits_async": [vp, P(C.c_int32), P(C.c_int32), i64, i32, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

@@ -79,6 +79,28 @@ def score_encoded(al, split_taxa, split_a, method_code, scores_dev_ptr=None, wan
     return scores, status
 
 
+def score_encoded_async(al, split_taxa, split_a, method_code, scores_dev_ptr, status_dev_ptr):
+    """Enqueue only (no host synchronisation, no hand-back): scores and status land in the given device buffers.
+    Callers check `status & 2` after their own sync and re-score those splits with the dense route
+    (`finish_async`)."""
+    split_taxa = np.ascontiguousarray(split_taxa, dtype=np.int32)
+    split_a = np.ascontiguousarray(split_a, dtype=np.int32)
+    _lib.check(al.ctx._lib.sp_score_splits_async(
+        al.handle, _lib._ptr(split_taxa, C.c_int32), _lib._ptr(split_a, C.c_int32), len(split_a), method_code,
+        C.c_void_p(scores_dev_ptr), C.c_void_p(status_dev_ptr)))
+
+
+def finish_async(al, split_taxa, split_a, scores_host, status_host):
+    """Hand-back for the asynchronous form: re-score on the dense route whatever the in-LDS kernel flagged
+    (status bit 1).  scores_host / status_host are NumPy views of the fetched results, patched in place."""
+    redo = np.nonzero(np.asarray(status_host) & 2)[0]
+    if len(redo):
+        sc, st = score_encoded(al, split_taxa[redo], split_a[redo], _lib.SP_METHOD_FLATTENING_DENSE)
+        scores_host[redo] = sc
+        status_host[redo] = st
+    return len(redo)
+
+
 def gather_scores(local_scores, shards, n_total, group=None, device_tensor=None):
     """All-gather the per-rank score shards and un-permute them into split order.
 

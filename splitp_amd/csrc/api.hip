@@ -561,7 +561,8 @@ __global__ void k_patch_scores(const int* __restrict__ idx, int n, const double*
 // Sparse route + hand-back: splits the in-LDS kernel flags (status bit 1: lists do not fit, or no
 // convergence with the 4-wide block) are re-scored on the dense route and patched in.
 static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device, const int32_t* split_taxa,
-                            const int32_t* split_a, int64_t S, bool strict) {
+                            const int32_t* split_a, int64_t S, bool strict, double* out_scores = nullptr,
+                            int* out_status = nullptr) {
     sp_ctx* ctx = al->ctx;
     const Plan& plan = pc.plan;
     if (!plan_on_device) {
@@ -575,9 +576,11 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
     SP_CHECK(ctx->scores.ensure((size_t)S * 8));
     SP_CHECK(ctx->status.ensure((size_t)S * 4));
     SP_CHECK(launch_sparse_score(ctx, al->keys.as<u64>(), al->counts.as<u32>(), al->D, al->n_taxa,
-                                 ctx->splits.as<SplitDev>(), ctx->gram_items.as<int>(), S, ctx->scores.as<double>(),
-                                 ctx->status.as<int>()));
+                                 ctx->splits.as<SplitDev>(), ctx->gram_items.as<int>(), S,
+                                 out_scores ? out_scores : ctx->scores.as<double>(),
+                                 out_status ? out_status : ctx->status.as<int>()));
     pc.valid = true;
+    if (out_scores) return SP_OK;  // asynchronous form: the caller inspects the status array itself
     std::vector<int> st((size_t)S);
     SP_HIP(hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
@@ -844,5 +847,43 @@ extern "C" int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* c
                           ctx->scores.as<double>(), ctx->status.as<int>()));
     SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
+extern "C" int sp_score_splits_async(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a,
+                                     int64_t n_splits, int method, void* scores_dev, void* status_dev) {
+    SP_REQUIRE(al && split_taxa && split_a && scores_dev && status_dev, SP_EINVAL, "NULL argument");
+    SP_REQUIRE(n_splits >= 0, SP_EINVAL, "n_splits < 0");
+    sp_ctx* ctx = al->ctx;
+    SP_HIP(hipSetDevice(ctx->device));
+    if (n_splits == 0) return SP_OK;
+    SP_REQUIRE(al->D > 0, SP_EINVAL, "empty pattern table");
+    const bool sparse_ok = al->exact && al->max_count < 65536u && al->D <= 65535;
+    const bool want_sparse = method == SP_METHOD_FLATTENING_SPARSE ||
+                             (method == SP_METHOD_FLATTENING && sparse_ok && ctx->gram_mode == 0);
+    if (want_sparse) {
+        SP_REQUIRE(sparse_ok, SP_ELIMIT, "sparse route needs integer counts < 65536 and at most 65535 patterns");
+        if (!ctx->cache) ctx->cache = new PlanCache();
+        PlanCache& pc = *ctx->cache;
+        const size_t nt = (size_t)n_splits * al->n_taxa;
+        const bool hit = pc.valid && pc.nl == -1 && pc.n == al->n_taxa && pc.D == al->D &&
+                         pc.a.size() == (size_t)n_splits && memcmp(pc.a.data(), split_a, n_splits * 4) == 0 &&
+                         memcmp(pc.taxa.data(), split_taxa, nt * 4) == 0;
+        if (!hit) {
+            pc.valid = false;
+            SP_CHECK(plan_splits(al->n_taxa, al->D, split_taxa, split_a, n_splits, true, false, false, pc.plan, 0));
+            build_gram_items(pc.plan);
+            pc.taxa.assign(split_taxa, split_taxa + nt);
+            pc.a.assign(split_a, split_a + n_splits);
+            pc.n = al->n_taxa;
+            pc.D = al->D;
+            pc.nl = -1;
+        }
+        return run_sparse_route(al, pc, hit, split_taxa, split_a, n_splits, false, (double*)scores_dev,
+                                (int*)status_dev);
+    }
+    // other methods: the synchronous entry point with device outputs, then the status
+    SP_CHECK(sp_score_splits(al, split_taxa, split_a, n_splits, method, nullptr, scores_dev, nullptr));
+    SP_HIP(hipMemcpyAsync(status_dev, ctx->status.p, (size_t)n_splits * 4, hipMemcpyDeviceToDevice, ctx->stream));
     return SP_OK;
 }

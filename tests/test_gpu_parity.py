@@ -340,3 +340,58 @@ def test_routes_agree(sp, golden):
         M = O.reduced_flattening_packed(rk, rc.astype(np.float64), 10, [names.index(t) for t in sub[i][0]],
                                         [names.index(t) for t in sub[i][1]])[0]
         assert abs(O.dense_split_score(M) - s_a[i]) <= 1e-9
+
+
+def test_async_entry_and_handback(sp, golden):
+    """sp_score_splits_async writes scores + status to device buffers without a host sync; flagged splits (status
+    bit 1) are the caller's to re-score (batch.finish_async)."""
+    import torch
+    from splitp_amd import batch, _lib
+
+    g = golden("n10_L100k")
+    names = taxa_names(10)
+    splits = [mask_to_split(int(m), 10, names) for m in g["masks"]]
+    dev = sp.DeviceAlignment.from_table(O.unpack_table(g["keys"], g["probs"], 10), taxa=names)
+    taxa_arr, a_arr = batch.encode_splits(splits, dev, 10)
+    sc = torch.zeros(501, dtype=torch.float64, device="cuda")
+    st = torch.zeros(501, dtype=torch.int32, device="cuda")
+    batch.score_encoded_async(dev, taxa_arr, a_arr, _lib.SP_METHOD_FLATTENING, sc.data_ptr(), st.data_ptr())
+    torch.cuda.synchronize()
+    s_h, st_h = sc.cpu().numpy(), st.cpu().numpy()
+    assert batch.finish_async(dev, taxa_arr, a_arr, s_h, st_h) == 0
+    assert np.abs(s_h - g["scores"]).max() <= SCORE_TOL
+    # a gapless table: every split is handed back, finish_async repairs them
+    rng = np.random.default_rng(3)
+    rk = np.unique(rng.integers(0, 4 ** 10, size=3000).astype(np.uint64))
+    rc = rng.integers(1, 40, size=len(rk)).astype(np.int64)
+    flat = sp.DeviceAlignment.from_arrays(rk, None, 10, counts=rc, n_sites=int(rc.sum()), taxa=names)
+    sub_t, sub_a = taxa_arr[::50], a_arr[::50]
+    sc2 = torch.zeros(len(sub_a), dtype=torch.float64, device="cuda")
+    st2 = torch.zeros(len(sub_a), dtype=torch.int32, device="cuda")
+    batch.score_encoded_async(flat, sub_t, sub_a, _lib.SP_METHOD_FLATTENING, sc2.data_ptr(), st2.data_ptr())
+    torch.cuda.synchronize()
+    s2, t2 = sc2.cpu().numpy(), st2.cpu().numpy()
+    n_redo = batch.finish_async(flat, sub_t, sub_a, s2, t2)
+    ref = sp.score_splits(flat, [splits[i] for i in range(0, 501, 50)], route="dense")
+    assert n_redo > 0 and np.abs(s2 - ref).max() <= 1e-9
+
+
+def test_config3_size_subflattening(sp):
+    """BASELINE config 3 size (16 taxa, 1M bp, subflattening route): exact moment identity and oracle spot checks."""
+    from splitp_amd import synthetic as syn
+
+    n, length = 16, 1_000_000
+    sites = syn.simulate_sites(n, length, 0.05, seed=3)
+    keys, counts = syn.pattern_table(sites)
+    names = syn.taxa_names(n)
+    dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=length, taxa=names)
+    splits = list(sp.all_splits(names, size=2))[:40] + list(sp.all_splits(names, size=8))[:2000:50]
+    got = sp.score_splits(dev, splits, method=sp.Method.subflattening)
+    M = O.moment_matrix(keys, counts, n)
+    for i in (0, 17, 39, 41, 60, 79):
+        oa = [names.index(t) for t in splits[i][0]]
+        ob = [names.index(t) for t in splits[i][1]]
+        S = M[np.ix_(O.subflattening_index(oa, n), O.subflattening_index(ob, n))] / float(length)
+        m_gpu = sp.subflattening(splits[i], dev)
+        assert np.array_equal(np.rint(m_gpu * length), np.rint(S * length))
+        assert abs(O.dense_split_score(S) - got[i]) <= SCORE_TOL
