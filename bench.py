@@ -194,7 +194,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                roof["traffic"] = json.load(open(pmc)).get(dom)
+                entry = json.load(open(pmc)).get(dom)
+                roof["traffic"] = entry["bytes_per_launch"] if entry else None   # HBM bytes per launch (rocprofv3 PMC, profiles/)
             except Exception:
                 pass
         out = {

@@ -14,6 +14,7 @@ from .constructions import (flattening, sparse_flattening_with_banned_patterns, 
                             subflattening)
 from .device import DeviceAlignment, get_context  # noqa: F401
 from .enums import FlatFormat, Method  # noqa: F401
+from .inference import erickson_SVD  # noqa: F401
 from .matrix import frobenius_norm, is_sparse  # noqa: F401
 from .phylogenetics import split_score  # noqa: F401
 from .splits import all_splits  # noqa: F401

@@ -725,8 +725,12 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
     unsigned short* perm_c = reinterpret_cast<unsigned short*>(carve_top((size_t)Kc * 2));
     unsigned short* perm_r = reinterpret_cast<unsigned short*>(carve_top((size_t)R * 2));
     const size_t build_end = reinterpret_cast<unsigned char*>(bm) - smem;
-    const size_t need_iter = off_after_lists + (size_t)Rp * SPK_VP * 8 + 16 +
-                             (small ? (size_t)R * R * 8 : (size_t)Kc * 4 * 8);
+    // W row pitch: 5 doubles when LDS allows it (rows start on 32 different bank offsets instead of 8: the gathers
+    // of Y = C W hit random rows), 4 otherwise
+    size_t top_probe = top;
+    const size_t base_iter = off_after_lists + (size_t)Rp * SPK_VP * 8 + 16;
+    const int wp = (!small && base_iter + (size_t)Kc * 5 * 8 <= top_probe) ? 5 : 4;
+    const size_t need_iter = base_iter + (small ? (size_t)R * R * 8 : (size_t)Kc * wp * 8);
     // counters: SPK_WAVES rows of 16-bit (8-bit when a group cannot exceed 255 entries) fields
     const bool bits8 = R <= 255 && small;
     const size_t cw_c = (size_t)SPK_WAVES * ((Kc + (bits8 ? 3 : 1)) / (bits8 ? 4 : 2)) * 4;
@@ -868,9 +872,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
             __syncthreads();
         } else {
             if (it == 1) SSTAMP(7);
-            spk_spmm(csc_ptr, csc_ent, Kc, perm_c, sh.nheavy_c, V, SPK_VP, Wb, 4, it == 1 ? 20 : -1);   // W = C^T V
+            spk_spmm(csc_ptr, csc_ent, Kc, perm_c, sh.nheavy_c, V, SPK_VP, Wb, wp, it == 1 ? 20 : -1);   // W = C^T V
             if (it == 1) SSTAMP(8);
-            spk_spmm(csr_ptr, csr_ent, R, perm_r, sh.nheavy_r, Wb, 4, V, SPK_VP, it == 1 ? 21 : -1);    // Y = C W  (overwrites V)
+            spk_spmm(csr_ptr, csr_ent, R, perm_r, sh.nheavy_r, Wb, wp, V, SPK_VP, it == 1 ? 21 : -1);    // Y = C W  (overwrites V)
             if (it == 1) SSTAMP(9);
         }
         spk_ritz_orth(V, R, sh, it == 2 ? 40 : -1);

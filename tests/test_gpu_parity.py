@@ -395,3 +395,24 @@ def test_config3_size_subflattening(sp):
         m_gpu = sp.subflattening(splits[i], dev)
         assert np.array_equal(np.rint(m_gpu * length), np.rint(S * length))
         assert abs(O.dense_split_score(S) - got[i]) <= SCORE_TOL
+
+
+def test_erickson_svd_matches_reference(sp, golden):
+    """The in-tree caller of the path (reference splitp/phylogenetics.py:99-171), every round one batched device call:
+    same chosen splits, in the same order, as the real reference on the 10-taxon 10k-bp golden alignment."""
+    import json, os
+    from tests.conftest import GOLDEN
+
+    g = golden("n10_L10k")
+    table = O.unpack_table(g["keys"], g["probs"], 10)
+    want = json.load(open(os.path.join(GOLDEN, "erickson_n10_L10k.json")))
+    for method in ("flattening", "subflattening"):
+        got = sp.erickson_SVD(table, method=sp.Method[method])
+        exp = [tuple(tuple(side) for side in s) for s in want[method]]
+        # the first n-3 rounds are decided by real score differences and must match exactly; the last round only
+        # re-selects one of the bipartitions already chosen, and which one is a tie between A|B and B|A scored as
+        # transposes of each other (equal in exact arithmetic, ~1e-16 apart in floating point in BOTH implementations)
+        assert got[:-1] == exp[:-1], (method, got, exp)
+        assert len(got) == len(exp) == 8 and got[-1] in got[:-1]
+    with pytest.raises(NotImplementedError):
+        sp.erickson_SVD(table, method=sp.Method.mutual_information)

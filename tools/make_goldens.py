@@ -198,6 +198,26 @@ def main():
         np.savez_compressed(os.path.join(OUT, "n16_L4k.npz"), **out)
         print("n16_L4k done, D =", len(table), "splits", len(splits))
 
+    # ------------------------------------------------- erickson_SVD (caller of the path)
+    if want("erickson"):
+        import json
+        g = np.load(os.path.join(OUT, "n10_L10k.npz"))
+        table = {}
+        for k, v in zip(g["keys"].tolist(), g["probs"].tolist()):
+            table["".join("ACGT"[(k >> (2 * (9 - t))) & 3] for t in range(10))] = v
+        from splitp.phylogenetics import erickson_SVD
+        import splitp as sp_ref
+        res = {}
+        t0 = time.time()
+        res["flattening"] = erickson_SVD(table, method=sp_ref.Method.flattening)
+        print("erickson flattening", time.time() - t0)
+        t0 = time.time()
+        res["subflattening"] = erickson_SVD(table, method=sp_ref.Method.subflattening)
+        print("erickson subflattening", time.time() - t0)
+        with open(os.path.join(OUT, "erickson_n10_L10k.json"), "w") as f:
+            json.dump({k: [[list(map(str, side)) for side in s] for s in v] for k, v in res.items()}, f)
+        print("erickson done", res["flattening"])
+
     # --------------------------------------------------------- degenerate cases
     if want("degenerate"):
         out = dict(versions=versions)
