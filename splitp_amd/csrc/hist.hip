@@ -26,10 +26,11 @@
 #define HIST_THREADS 256
 #define HIST_PER_THREAD 8
 #define HIST_TILE (HIST_THREADS * HIST_PER_THREAD)  // sites per workgroup pass
-#define HIST_SLOTS 4096                             // LDS table slots (= 2 * HIST_TILE): 48 KiB
+#define HIST_SLOTS 8192                             // LDS table slots (4 * HIST_TILE): 64-96 KiB
 
+template <typename KT>
 __global__ __launch_bounds__(256) void k_pack_sites(const uint8_t* __restrict__ seqs, int n, int64_t L, int64_t stride,
-                                                    u64* __restrict__ keys) {
+                                                    KT* __restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= L) return;
     u64 k = 0;
@@ -46,50 +47,90 @@ __global__ __launch_bounds__(256) void k_pack_sites(const uint8_t* __restrict__ 
         // 0x61-0x7A; characters 0x41-0x5A are unchanged).  Bytes 0x01-0x1A / 0x21-0x3A cannot alias A,C,G,T.
         k = (k << 2) | d;
     }
-    keys[i] = ok ? k : ~0ull;
+    keys[i] = ok ? (KT)k : (KT)~(KT)0;
 }
 
-__global__ __launch_bounds__(HIST_THREADS) void k_hist_lds(const u64* __restrict__ keys, int64_t L,
+// KT = u32 (n <= 15: half the HBM traffic of the pass) or u64; the all-ones key is the "invalid site" sentinel.
+template <typename KT>
+__global__ __launch_bounds__(HIST_THREADS) void k_hist_lds(const KT* __restrict__ keys, int64_t L, int n,
                                                            u32* __restrict__ bins, u32* __restrict__ n_valid) {
-    __shared__ u64 t_key[HIST_SLOTS];
+    __shared__ KT t_key[HIST_SLOTS];
     __shared__ u32 t_cnt[HIST_SLOTS];
-    u32 valid = 0;
-    for (int64_t tile = (int64_t)blockIdx.x * HIST_TILE; tile < L; tile += (int64_t)gridDim.x * HIST_TILE) {
-        for (int i = threadIdx.x; i < HIST_SLOTS; i += HIST_THREADS) {
-            t_key[i] = ~0ull;
-            t_cnt[i] = 0;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int j = 0; j < HIST_PER_THREAD; ++j) {
-            const int64_t i = tile + (int64_t)j * HIST_THREADS + threadIdx.x;  // coalesced
-            if (i >= L) break;
-            const u64 k = keys[i];
-            if (k == ~0ull) continue;
-            ++valid;
-            u32 h = (u32)((k * 0x9E3779B97F4A7C15ull) >> 52) & (HIST_SLOTS - 1);
-            while (true) {
-                const u64 cur = ((volatile u64*)t_key)[h];
-                if (cur == k) break;
-                if (cur == ~0ull) {
-                    const u64 old = atomicCAS(&t_key[h], ~0ull, k);
-                    if (old == ~0ull || old == k) break;
-                }
-                h = (h + 1) & (HIST_SLOTS - 1);
-            }
-            atomicAdd(&t_cnt[h], 1u);
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < HIST_SLOTS; i += HIST_THREADS) {
-            const u32 c = t_cnt[i];
-            if (c) atomicAdd(&bins[t_key[i]], c);
-        }
-        __syncthreads();
+    __shared__ u32 n_used;
+    const KT SENT = (KT)~(KT)0;
+    // the four constant patterns AAAA.., CCCC.., GGGG.., TTTT..: at short branch lengths each holds ~10 % of the sites.
+    // They are counted per wave with a ballot + popcount (no LDS traffic at all) and flushed with one atomic per wave.
+    const KT c1 = (KT)((n >= 32 ? ~0ull : ((1ull << (2 * n)) - 1)) / 3ull);
+    u32 cc0 = 0, cc1 = 0, cc2 = 0, cc3 = 0, valid = 0;
+    for (int i = threadIdx.x; i < HIST_SLOTS; i += HIST_THREADS) {
+        t_key[i] = SENT;
+        t_cnt[i] = 0;
     }
-    // number of usable sites (fasta.py:57)
+    if (threadIdx.x == 0) n_used = 0;
+    __syncthreads();
+    for (int64_t tile = (int64_t)blockIdx.x * HIST_TILE; tile < L; tile += (int64_t)gridDim.x * HIST_TILE) {
+        KT kk[HIST_PER_THREAD];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) valid += __shfl_xor(valid, d, 64);
-    if ((threadIdx.x & 63) == 0 && valid) atomicAdd(n_valid, valid);
+        for (int j = 0; j < HIST_PER_THREAD; ++j) {       // all loads first (coalesced), then the LDS work
+            const int64_t i = tile + (int64_t)j * HIST_THREADS + threadIdx.x;
+            kk[j] = i < L ? keys[i] : SENT;
+        }
+#pragma unroll
+        for (int j = 0; j < HIST_PER_THREAD; ++j) {
+            const KT k = kk[j];
+            const bool ok = k != SENT;
+            const bool is0 = ok && k == (KT)0, is1 = ok && k == c1, is2 = ok && k == (KT)(2 * c1),
+                       is3 = ok && k == (KT)(3 * c1);
+            valid += __popcll(__ballot(ok));
+            cc0 += __popcll(__ballot(is0));
+            cc1 += __popcll(__ballot(is1));
+            cc2 += __popcll(__ballot(is2));
+            cc3 += __popcll(__ballot(is3));
+            if (ok && !(is0 | is1 | is2 | is3)) {
+                u32 h = (u32)(((u64)k * 0x9E3779B97F4A7C15ull) >> 52) & (HIST_SLOTS - 1);
+                while (true) {
+                    const KT cur = ((volatile KT*)t_key)[h];
+                    if (cur == k) break;
+                    if (cur == SENT) {
+                        const KT old = atomicCAS(&t_key[h], SENT, k);
+                        if (old == SENT) {
+                            atomicAdd(&n_used, 1u);
+                            break;
+                        }
+                        if (old == k) break;
+                    }
+                    h = (h + 1) & (HIST_SLOTS - 1);
+                }
+                atomicAdd(&t_cnt[h], 1u);
+            }
+        }
+        __syncthreads();
+        // the table persists across tiles (no per-tile reset); it is flushed to the bins in HBM once it is half full,
+        // so that the next tile (at most HIST_TILE new keys) always fits
+        if (n_used > HIST_SLOTS / 4) {   // load factor stays <= 0.5 through the next tile (short probe sequences)
+            for (int i = threadIdx.x; i < HIST_SLOTS; i += HIST_THREADS) {
+                const u32 c = t_cnt[i];
+                if (c) atomicAdd(&bins[t_key[i]], c);
+                t_key[i] = SENT;
+                t_cnt[i] = 0;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) n_used = 0;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HIST_SLOTS; i += HIST_THREADS) {
+        const u32 c = t_cnt[i];
+        if (c) atomicAdd(&bins[t_key[i]], c);
+    }
+    if ((threadIdx.x & 63) == 0) {   // every lane of a wave holds the same wave totals
+        if (cc0) atomicAdd(&bins[0], cc0);
+        if (cc1) atomicAdd(&bins[(u64)c1], cc1);
+        if (cc2) atomicAdd(&bins[(u64)(KT)(2 * c1)], cc2);
+        if (cc3) atomicAdd(&bins[(u64)(KT)(3 * c1)], cc3);
+        if (valid) atomicAdd(n_valid, valid);   // number of usable sites (fasta.py:57)
+    }
 }
 
 #define SCAN_BLOCK_ELEMS 4096  // bins per block in the count / write passes
@@ -186,7 +227,8 @@ __global__ void k_counts_to_weights(const u32* __restrict__ counts, int64_t D, d
     if (i < D) w[i] = (double)counts[i] / N;  // counts[k] / float(L): simulation.py:54, fasta.py:66-70
 }
 
-static int build_from_device_keys(sp_ctx* ctx, const u64* dkeys, int64_t L, int n_taxa, sp_alignment** out) {
+static int build_from_device_keys(sp_ctx* ctx, const void* dkeys, bool keys32, int64_t L, int n_taxa,
+                                  sp_alignment** out) {
     SP_REQUIRE(n_taxa <= 16, SP_ELIMIT,
                "device histogram uses a direct 4^n bin array and supports n_taxa <= 16 (got %d); pass a "
                "de-duplicated table to sp_alignment_create instead", n_taxa);
@@ -213,7 +255,12 @@ static int build_from_device_keys(sp_ctx* ctx, const u64* dkeys, int64_t L, int 
             return SP_EHIP;
         }
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((L + HIST_TILE - 1) / HIST_TILE, ctx->n_cu * 2));
-        hipLaunchKernelGGL(k_hist_lds, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, dkeys, L, bins.as<u32>(), n_valid);
+        if (keys32)   // 32-bit site words (n <= 15): half the traffic of the pass (4 L bytes)
+            hipLaunchKernelGGL(k_hist_lds<u32>, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, (const u32*)dkeys, L,
+                               n_taxa, bins.as<u32>(), n_valid);
+        else
+            hipLaunchKernelGGL(k_hist_lds<u64>, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, (const u64*)dkeys, L,
+                               n_taxa, bins.as<u32>(), n_valid);
         hipLaunchKernelGGL(k_bins_count, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, bins.as<u32>(), nbins,
                            blk.as<u32>());
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, blk.as<u32>(), nblocks, off.as<u64>());
@@ -271,9 +318,24 @@ extern "C" int sp_alignment_from_site_keys(sp_ctx* ctx, const uint64_t* site_key
     SP_REQUIRE(ctx && out && (site_keys || L == 0), SP_EINVAL, "NULL argument");
     SP_REQUIRE(n_taxa >= 2 && n_taxa <= 32 && L >= 0, SP_EINVAL, "bad n_taxa / L");
     SP_HIP(hipSetDevice(ctx->device));
-    SP_CHECK(ctx->misc.ensure((size_t)std::max<int64_t>(L, 1) * 8));
-    if (L > 0) SP_HIP(hipMemcpyAsync(ctx->misc.p, site_keys, (size_t)L * 8, hipMemcpyHostToDevice, ctx->stream));
-    return build_from_device_keys(ctx, ctx->misc.as<u64>(), L, n_taxa, out);
+    const bool keys32 = n_taxa <= 15;
+    SP_CHECK(ctx->misc.ensure((size_t)std::max<int64_t>(L, 1) * (keys32 ? 4 : 8)));
+    if (L > 0) {
+        if (keys32) {   // narrow on the host: halves the PCIe transfer and the HBM traffic of the histogram pass
+            std::vector<u32> k32((size_t)L);
+            const u64 lim = (1ull << (2 * n_taxa)) - 1;
+            for (int64_t i = 0; i < L; ++i) {
+                SP_REQUIRE(site_keys[i] <= lim || site_keys[i] == ~0ull, SP_EINVAL,
+                           "site key %llu does not fit %d taxa", (unsigned long long)site_keys[i], n_taxa);
+                k32[i] = site_keys[i] == ~0ull ? 0xFFFFFFFFu : (u32)site_keys[i];
+            }
+            SP_HIP(hipMemcpyAsync(ctx->misc.p, k32.data(), (size_t)L * 4, hipMemcpyHostToDevice, ctx->stream));
+            SP_HIP(hipStreamSynchronize(ctx->stream));   // k32 is a host temporary
+        } else {
+            SP_HIP(hipMemcpyAsync(ctx->misc.p, site_keys, (size_t)L * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    return build_from_device_keys(ctx, ctx->misc.p, keys32, L, n_taxa, out);
 }
 
 extern "C" int sp_alignment_from_sequences(sp_ctx* ctx, const uint8_t* seqs, int n_taxa, int64_t L, int64_t stride,
@@ -287,9 +349,13 @@ extern "C" int sp_alignment_from_sequences(sp_ctx* ctx, const uint8_t* seqs, int
         SP_HIP(hipMemcpy2DAsync(ctx->misc2.p, (size_t)L, seqs, (size_t)stride, (size_t)L, (size_t)n_taxa,
                                 hipMemcpyHostToDevice, ctx->stream));
         PhaseScope ps(ctx, SP_PHASE_HIST);
-        hipLaunchKernelGGL(k_pack_sites, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
-                           ctx->misc2.as<uint8_t>(), n_taxa, L, L, ctx->misc.as<u64>());
+        if (n_taxa <= 15)
+            hipLaunchKernelGGL(k_pack_sites<u32>, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->misc2.as<uint8_t>(), n_taxa, L, L, ctx->misc.as<u32>());
+        else
+            hipLaunchKernelGGL(k_pack_sites<u64>, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->misc2.as<uint8_t>(), n_taxa, L, L, ctx->misc.as<u64>());
         SP_HIP(hipGetLastError());
     }
-    return build_from_device_keys(ctx, ctx->misc.as<u64>(), L, n_taxa, out);
+    return build_from_device_keys(ctx, ctx->misc.p, n_taxa <= 15, L, n_taxa, out);
 }
