@@ -4,11 +4,14 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = one pass of the hot path over one batch: for each of this rank's alignments (resident in
-HBM as a pattern table) score ALL 501 candidate splits - reindex, scatter into the compact count
-matrices, fp64-MFMA Gram, top-4 eigen, score - then bring the scores to the host (and, for N > 1,
-all-gather every rank's scores over RCCL first).  Weak scaling: every rank scores its own
-alignment(s); value = (splits scored by all ranks) / (max over ranks of the timed region).
+One step = one pass of the hot path over one batch: score ALL 501 candidate splits of this rank's alignment
+(resident in HBM as a pattern table) with the flattening + fp64 split score - default route: one launch of the in-LDS
+sparse kernel - then (N > 1) all-gather every rank's scores over RCCL and copy the scores to pinned host memory.
+Steps are issued round-robin on `--lanes` HIP streams (default 3) so the tail of one step's launch, its all-gather
+and its D2H copy overlap the next step's kernel; a lane is reused only after its previous step's scores are on the
+host and its hand-back flags were checked.  All K steps complete inside the timed region (barrier + device sync on
+both sides).  Weak scaling: every rank scores its own alignment(s); value = (splits scored by all ranks) / (max over
+ranks of the timed region).
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the dominant
 kernel (per-kernel time from HIP events recorded on the launch stream inside the timed region) and
@@ -21,6 +24,11 @@ import sys
 import time
 
 import numpy as np
+
+# Lanes (below) keep several steps in flight on separate HIP streams next to RCCL's own stream; with the default of 4
+# hardware queues two of those streams can share a queue and serialise, so ask the HIP runtime for 8 (read at HIP
+# initialisation, hence before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -64,9 +72,13 @@ def cpu_baseline(table, splits, budget_s=15.0, min_splits=24):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--alignments", type=int, default=1, help="alignments scored per rank per step")
+    ap.add_argument("--lanes", type=int, default=3, help="steps in flight (one HIP stream + buffers each)")
+    ap.add_argument("--debug-timeline", action="store_true", help="print host-side retire/launch times of the last steps")
+    ap.add_argument("--spinup", type=float, default=1.0, help="seconds of untimed load before the warmup steps")
+    ap.add_argument("--no-hipri", action="store_true", help="RCCL stream at normal priority (diagnostic)")
     ap.add_argument("--route", default="auto", choices=["auto", "dense", "sparse"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -80,12 +92,14 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:   # launched by torch.distributed.run (also with 1 rank)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = not args.no_hipri   # the all-gather competes with queued scoring workgroups
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
     else:
         torch.cuda.set_device(0)
     dev_t = torch.device("cuda", torch.cuda.current_device())
@@ -111,53 +125,107 @@ def main():
     code = batch._method_code(sp.Method.flattening, args.route)
     ctx = aligns[0].ctx
     per_rank = args.alignments * n_splits
-    # one device buffer per rank: per_rank scores (f64) followed by per_rank status words (int32, padded to f64)
+    # Each lane owns a HIP stream and its own device / pinned-host buffers: per_rank scores (f64) followed by
+    # per_rank status words (int32, padded to f64).  Step i runs on lane i % lanes, so the scatter of one step's
+    # last workgroups, its all-gather and its D2H copy overlap the next step's kernel (two steps in flight at most
+    # per lane pair); a lane is reused only after its previous step's scores are on the host and checked.
     n_stat = (per_rank + 1) // 2
-    send = torch.zeros(per_rank + n_stat, dtype=torch.float64, device=dev_t)
-    recv = torch.zeros(world * (per_rank + n_stat), dtype=torch.float64, device=dev_t) if world > 1 else None
-    host = torch.zeros(world * (per_rank + n_stat), dtype=torch.float64).pin_memory()
-    host_np = host.numpy()
-    status_ptr = send.data_ptr() + per_rank * 8
+    width = per_rank + n_stat
 
-    def step():
-        for a, al in enumerate(aligns):
-            batch.score_encoded_async(al, taxa_arr, a_arr, code, send.data_ptr() + a * n_splits * 8,
-                                      status_ptr + a * n_splits * 4)
-        if world > 1:
-            dist.all_gather_into_tensor(recv, send)
-            host.copy_(recv, non_blocking=True)
-        else:
-            host.copy_(send, non_blocking=True)
-        torch.cuda.current_stream().synchronize()   # scores are on the host: the unit of work is complete
-        # hand-back check (this rank's own shard): splits the in-LDS kernel could not take go to the dense route
-        mine = host_np[rank * (per_rank + n_stat):(rank + 1) * (per_rank + n_stat)]
+    class Lane:
+        def __init__(self):
+            self.stream = torch.cuda.Stream(device=dev_t)
+            self.send = torch.zeros(width, dtype=torch.float64, device=dev_t)
+            self.recv = torch.zeros(world * width, dtype=torch.float64, device=dev_t) if dist is not None else None
+            self.host = torch.zeros(world * width, dtype=torch.float64).pin_memory()
+            self.host_np = self.host.numpy()
+            self.done = torch.cuda.Event()
+            self.busy = False
+
+    lanes = [Lane() for _ in range(max(1, args.lanes))]
+
+    def launch(lane):
+        with torch.cuda.stream(lane.stream):
+            ctx.sync_stream_with_torch(ordered=False)
+            sc_ptr = lane.send.data_ptr()
+            st_ptr = sc_ptr + per_rank * 8
+            if args.route == "auto" and len(aligns) > 1:
+                batch.score_encoded_multi_async(aligns, taxa_arr, a_arr, sc_ptr, st_ptr)
+            else:
+                for a, al in enumerate(aligns):
+                    batch.score_encoded_async(al, taxa_arr, a_arr, code, sc_ptr + a * n_splits * 8,
+                                              st_ptr + a * n_splits * 4)
+            if dist is not None:
+                dist.all_gather_into_tensor(lane.recv, lane.send)
+                lane.host.copy_(lane.recv, non_blocking=True)
+            else:
+                lane.host.copy_(lane.send, non_blocking=True)
+            lane.done.record()
+        lane.busy = True
+
+    def retire(lane):
+        """Wait until the lane's scores are on the host (the unit of work is complete), then do the hand-back check
+        on this rank's own shard: splits the in-LDS kernel could not take go to the dense route."""
+        if not lane.busy:
+            return
+        lane.done.synchronize()
+        lane.busy = False
+        mine = lane.host_np[rank * width:(rank + 1) * width]
         st = mine[per_rank:].view(np.int32)[:per_rank]
         if (st & 2).any():
-            for a, al in enumerate(aligns):
-                batch.finish_async(al, taxa_arr, a_arr, mine[a * n_splits:(a + 1) * n_splits],
-                                   st[a * n_splits:(a + 1) * n_splits])
+            torch.cuda.synchronize()   # the dense route re-plans into the context's pools: no other lane in flight
+            with torch.cuda.stream(lane.stream):
+                ctx.sync_stream_with_torch()
+                for a, al in enumerate(aligns):
+                    batch.finish_async(al, taxa_arr, a_arr, mine[a * n_splits:(a + 1) * n_splits],
+                                       st[a * n_splits:(a + 1) * n_splits])
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    timeline = []
+
+    def run(n_steps):
+        for i in range(n_steps):
+            lane = lanes[i % len(lanes)]
+            if args.debug_timeline:
+                ta = time.perf_counter()
+                retire(lane)
+                tb = time.perf_counter()
+                launch(lane)
+                timeline.append((ta, tb, time.perf_counter()))
+                continue
+            retire(lane)
+            launch(lane)
+        for lane in lanes:
+            retire(lane)
+
+    # untimed spin-up: a fresh box needs a few hundred ms of load before clocks, queues and the RCCL channel settle
+    # (a 60 ms measurement taken cold is bimodal); then the W warmup steps the contract asks for
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup:
+        run(50)
+    run(args.warmup)
     ctx.enable_timing(True)
     ctx.reset_timing()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if world > 1:
+    run(args.steps)
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if args.debug_timeline and rank == 0:
+        base = timeline[-24][0]
+        for ta, tb, tc in timeline[-24:]:
+            print(f"retire {1e6 * (ta - base):9.1f} -> {1e6 * (tb - base):9.1f}  launch -> {1e6 * (tc - base):9.1f}", file=sys.stderr)
     phases = ctx.phase_times()
     ctx.enable_timing(False)
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    scores = host_np[:per_rank].copy()
+    scores = lanes[(args.steps - 1) % len(lanes)].host_np[:per_rank].copy()
 
     if rank == 0:
         total_splits = world * per_rank * args.steps
@@ -189,7 +257,18 @@ def main():
                             "sparse route never materialises the 4^a x 4^b matrix (it keeps the D non-zeros in LDS), so "
                             "its real HBM traffic is ~3 orders of magnitude below this figure and the kernel is bound by "
                             "LDS latency, not HBM (DESIGN.md section 5)"}
+        # lanes overlap launches: the event-bracketed duration of one launch spans its neighbours' workgroups too, so
+        # the aggregate rate (bytes of all launches / timed region) is reported next to the per-launch one
+        in_flight = ph[dom][0] / (elapsed * 1e3)
         roof["launch_ms"] = dom_ms
+        roof["launches_in_flight"] = in_flight
+        if in_flight > 1.0:
+            roof["achieved_per_launch"] = roof["achieved"]
+            roof["achieved"] = roof["achieved"] * in_flight
+            roof["frac"] = roof["achieved"] / roof["peak"]
+            roof["note"] += ("  With %d lanes %.2f launches are in flight on average: `achieved` is the aggregate over "
+                             "concurrent launches (= bytes per launch x launches / timed region), `achieved_per_launch` "
+                             "uses the event-bracketed launch duration `launch_ms`." % (len(lanes), in_flight))
         roof["phase_ms_per_step"] = {k: round(v[0] / args.steps, 5) for k, v in ph.items()}
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
@@ -206,7 +285,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 10-taxon balanced tree (branch 0.05, JC), 100k bp, all 501 "
                                    "splits, flattening + fp64 split score, scores copied to host every step",
                        "route": args.route,
-                       "alignments_per_rank_per_step": args.alignments, "splits_per_alignment": n_splits,
+                       "alignments_per_rank_per_step": args.alignments, "lanes": len(lanes), "splits_per_alignment": n_splits,
                        "patterns": int(len(tables[0][0])), "parallelism": f"alignment-sharded x{world}, all_gather of scores"
                        if world > 1 else "single GPU"},
             "roofline": roof,
@@ -222,7 +301,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -64,6 +64,10 @@ int sp_device_count(void);
 int sp_ctx_create(int device, void* stream, sp_ctx** out);
 int sp_ctx_destroy(sp_ctx* ctx);
 int sp_ctx_set_stream(sp_ctx* ctx, void* stream);
+/* Retarget the context to another stream WITHOUT draining or ordering against the previous one ("lanes": several
+ * scoring steps in flight on different streams).  Safe only between sp_score_splits_async / _multi_async calls whose
+ * split list is unchanged: those read the cached plan and write only the caller's buffers. */
+int sp_ctx_set_stream_unordered(sp_ctx* ctx, void* hip_stream);
 int sp_ctx_synchronize(sp_ctx* ctx);
 /* Gram-kernel selection of the dense flattening route: 0 = auto (exact integer Gram on the int8 matrix
  * cores, count limbs of 7 bits, when the alignment holds counts < 128^3; fp64 MFMA otherwise),
@@ -176,6 +180,12 @@ int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, const int32_t* 
  * own synchronisation (splitp_amd/batch.py does). */
 int sp_score_splits_async(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
                           int method, void* scores_dev, void* status_dev);
+
+/* Several alignments (same taxa, same candidate-split list - e.g. the replicates of a simulation study, BASELINE
+ * config 5) in ONE launch of the in-LDS kernel; asynchronous like sp_score_splits_async.  scores_dev / status_dev
+ * hold n_al * n_splits entries, alignment-major. */
+int sp_score_splits_multi_async(sp_alignment* const* als, int n_al, const int32_t* split_taxa, const int32_t* split_a,
+                                int64_t n_splits, void* scores_dev, void* status_dev);
 
 #ifdef __cplusplus
 }

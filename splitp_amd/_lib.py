@@ -22,13 +22,14 @@ PHASE_NAMES = ("reindex", "scatter", "gram", "eigen", "moment", "subscore", "his
 # every symbol include/splitp_hip.h declares
 SYMBOLS = (
     "sp_abi_version", "sp_last_error", "sp_device_count",
-    "sp_ctx_create", "sp_ctx_destroy", "sp_ctx_set_stream", "sp_ctx_synchronize", "sp_ctx_set_gram_mode",
+    "sp_ctx_create", "sp_ctx_destroy", "sp_ctx_set_stream", "sp_ctx_set_stream_unordered", "sp_ctx_synchronize", "sp_ctx_set_gram_mode",
     "sp_ctx_enable_timing", "sp_ctx_reset_timing", "sp_ctx_phase_times",
     "sp_alignment_create", "sp_alignment_from_sequences", "sp_alignment_from_site_keys",
     "sp_alignment_destroy", "sp_alignment_info", "sp_alignment_fetch",
     "sp_flatten_indices", "sp_flatten_reduced_prepare", "sp_flatten_reduced_fetch", "sp_flatten_dense_counts",
     "sp_subflatten", "sp_moment_matrix",
     "sp_score_matrix_f64", "sp_score_coo_f64", "sp_score_splits", "sp_score_splits_async",
+    "sp_score_splits_multi_async",
 )
 
 
@@ -69,6 +70,7 @@ def load():
         "sp_ctx_create": [i32, vp, P(vp)],
         "sp_ctx_destroy": [vp],
         "sp_ctx_set_stream": [vp, vp],
+        "sp_ctx_set_stream_unordered": [vp, vp],
         "sp_ctx_synchronize": [vp],
         "sp_ctx_set_gram_mode": [vp, i32],
         "sp_ctx_enable_timing": [vp, i32],
@@ -90,6 +92,7 @@ def load():
         "sp_score_coo_f64": [vp, P(i64), P(i64), P(dbl), i64, i64, i64, P(dbl)],
         "sp_score_splits": [vp, P(C.c_int32), P(C.c_int32), i64, i32, P(dbl), vp, P(C.c_int32)],
         "sp_score_splits_async": [vp, P(C.c_int32), P(C.c_int32), i64, i32, vp, vp],
+        "sp_score_splits_multi_async": [P(vp), i32, P(C.c_int32), P(C.c_int32), i64, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

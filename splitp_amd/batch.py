@@ -90,6 +90,16 @@ def score_encoded_async(al, split_taxa, split_a, method_code, scores_dev_ptr, st
         C.c_void_p(scores_dev_ptr), C.c_void_p(status_dev_ptr)))
 
 
+def score_encoded_multi_async(als, split_taxa, split_a, scores_dev_ptr, status_dev_ptr):
+    """Several alignments (same taxa / split list) in one launch of the in-LDS kernel; results alignment-major."""
+    split_taxa = np.ascontiguousarray(split_taxa, dtype=np.int32)
+    split_a = np.ascontiguousarray(split_a, dtype=np.int32)
+    arr = (C.c_void_p * len(als))(*[a.handle.value for a in als])
+    _lib.check(als[0].ctx._lib.sp_score_splits_multi_async(
+        arr, len(als), _lib._ptr(split_taxa, C.c_int32), _lib._ptr(split_a, C.c_int32), len(split_a),
+        C.c_void_p(scores_dev_ptr), C.c_void_p(status_dev_ptr)))
+
+
 def finish_async(al, split_taxa, split_a, scores_host, status_host):
     """Hand-back for the asynchronous form: re-score on the dense route whatever the in-LDS kernel flagged
     (status bit 1).  scores_host / status_host are NumPy views of the fetched results, patched in place."""

@@ -131,8 +131,9 @@ extern "C" int sp_ctx_destroy(sp_ctx* c) {
             (void)hipEventDestroy(pr.second);
         }
     for (auto e : c->timer.pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&c->splits, &c->bitmaps, &c->coords, &c->dims, &c->mats,  &c->grams,
-                      &c->eigws,  &c->scores,  &c->status, &c->misc, &c->misc2, &c->gram_items};
+    if (c->upload_ev) (void)hipEventDestroy(c->upload_ev);
+    DevBuf* bufs[] = {&c->splits, &c->bitmaps, &c->coords, &c->dims, &c->mats,  &c->grams,  &c->eigws,
+                      &c->scores, &c->status,  &c->misc,   &c->misc2, &c->gram_items, &c->aldescs};
     delete c->cache;
     for (auto* b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -151,6 +152,20 @@ extern "C" int sp_ctx_set_stream(sp_ctx* c, void* stream) {
         SP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
+    return SP_OK;
+}
+
+// Lanes: retarget the context WITHOUT draining or ordering against the previous stream.  Only the asynchronous
+// scoring entry points with an unchanged split list are safe to interleave this way - they read the cached plan and
+// write nothing but the caller's buffers (uploads are fenced by ctx->upload_ev).
+extern "C" int sp_ctx_set_stream_unordered(sp_ctx* c, void* stream) {
+    SP_REQUIRE(c && stream, SP_EINVAL, "sp_ctx_set_stream_unordered: NULL argument");
+    if (c->own_stream) {
+        SP_HIP(hipStreamSynchronize(c->stream));
+        (void)hipStreamDestroy(c->stream);
+    }
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+    c->own_stream = false;
     return SP_OK;
 }
 
@@ -558,6 +573,28 @@ __global__ void k_patch_scores(const int* __restrict__ idx, int n, const double*
     }
 }
 
+// The sparse route may be driven from several streams (sp_ctx_set_stream between calls) as long as the split list
+// does not change: uploads are recorded in ctx->upload_ev and every launch waits on it, so a launch on stream B
+// never reads a plan that stream A is still uploading.
+static int mark_upload(sp_ctx* ctx) {
+    if (!ctx->upload_ev) SP_HIP(hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming));
+    SP_HIP(hipEventRecord(ctx->upload_ev, ctx->stream));
+    return SP_OK;
+}
+
+static int upload_aldescs(sp_ctx* ctx, sp_alignment* const* als, int n_al) {
+    std::vector<AlDesc> d((size_t)n_al);
+    for (int i = 0; i < n_al; ++i) d[i] = AlDesc{als[i]->keys.as<u64>(), als[i]->counts.as<u32>(), als[i]->D};
+    if (ctx->aldescs_host.size() == d.size() && ctx->aldescs.p &&
+        memcmp(ctx->aldescs_host.data(), d.data(), d.size() * sizeof(AlDesc)) == 0)
+        return SP_OK;  // same alignments as last call: the device copy is current
+    SP_CHECK(ctx->aldescs.ensure(d.size() * sizeof(AlDesc)));
+    ctx->aldescs_host = d;
+    SP_HIP(hipMemcpyAsync(ctx->aldescs.p, ctx->aldescs_host.data(), d.size() * sizeof(AlDesc), hipMemcpyHostToDevice,
+                          ctx->stream));
+    return mark_upload(ctx);
+}
+
 // Sparse route + hand-back: splits the in-LDS kernel flags (status bit 1: lists do not fit, or no
 // convergence with the 4-wide block) are re-scored on the dense route and patched in.
 static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device, const int32_t* split_taxa,
@@ -572,10 +609,12 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
         SP_CHECK(ctx->gram_items.ensure((size_t)S * sizeof(int)));
         SP_HIP(hipMemcpyAsync(ctx->gram_items.p, plan.order.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice,
                               ctx->stream));
+        SP_CHECK(mark_upload(ctx));
     }
     SP_CHECK(ctx->scores.ensure((size_t)S * 8));
     SP_CHECK(ctx->status.ensure((size_t)S * 4));
-    SP_CHECK(launch_sparse_score(ctx, al->keys.as<u64>(), al->counts.as<u32>(), al->D, al->n_taxa,
+    SP_CHECK(upload_aldescs(ctx, &al, 1));
+    SP_CHECK(launch_sparse_score(ctx, ctx->aldescs.as<AlDesc>(), 1, al->n_taxa,
                                  ctx->splits.as<SplitDev>(), ctx->gram_items.as<int>(), S,
                                  out_scores ? out_scores : ctx->scores.as<double>(),
                                  out_status ? out_status : ctx->status.as<int>()));
@@ -885,5 +924,54 @@ extern "C" int sp_score_splits_async(sp_alignment* al, const int32_t* split_taxa
     // other methods: the synchronous entry point with device outputs, then the status
     SP_CHECK(sp_score_splits(al, split_taxa, split_a, n_splits, method, nullptr, scores_dev, nullptr));
     SP_HIP(hipMemcpyAsync(status_dev, ctx->status.p, (size_t)n_splits * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return SP_OK;
+}
+
+// Several alignments (same taxa, same split list) in ONE launch of the in-LDS kernel: n_al * n_splits workgroups,
+// heaviest splits first across all alignments.  scores_dev / status_dev hold n_al * n_splits entries, alignment-major.
+extern "C" int sp_score_splits_multi_async(sp_alignment* const* als, int n_al, const int32_t* split_taxa,
+                                           const int32_t* split_a, int64_t n_splits, void* scores_dev,
+                                           void* status_dev) {
+    SP_REQUIRE(als && n_al >= 1 && split_taxa && split_a && scores_dev && status_dev, SP_EINVAL, "NULL argument");
+    sp_alignment* al0 = als[0];
+    SP_REQUIRE(al0, SP_EINVAL, "NULL alignment");
+    sp_ctx* ctx = al0->ctx;
+    SP_HIP(hipSetDevice(ctx->device));
+    if (n_splits == 0) return SP_OK;
+    int64_t dmax = 0;
+    for (int i = 0; i < n_al; ++i) {
+        SP_REQUIRE(als[i] && als[i]->ctx == ctx && als[i]->n_taxa == al0->n_taxa, SP_EINVAL,
+                   "alignments of one multi call must share the context and the number of taxa");
+        SP_REQUIRE(als[i]->exact && als[i]->max_count < 65536u && als[i]->D <= 65535 && als[i]->D > 0, SP_ELIMIT,
+                   "multi-alignment scoring uses the sparse route: integer counts < 65536, 1..65535 patterns");
+        dmax = std::max(dmax, als[i]->D);
+    }
+    if (!ctx->cache) ctx->cache = new PlanCache();
+    PlanCache& pc = *ctx->cache;
+    const size_t nt = (size_t)n_splits * al0->n_taxa;
+    const bool hit = pc.valid && pc.nl == -1 && pc.n == al0->n_taxa && pc.D == dmax &&
+                     pc.a.size() == (size_t)n_splits && memcmp(pc.a.data(), split_a, n_splits * 4) == 0 &&
+                     memcmp(pc.taxa.data(), split_taxa, nt * 4) == 0;
+    if (!hit) {
+        pc.valid = false;
+        SP_CHECK(plan_splits(al0->n_taxa, dmax, split_taxa, split_a, n_splits, true, false, false, pc.plan, 0));
+        build_gram_items(pc.plan);
+        pc.taxa.assign(split_taxa, split_taxa + nt);
+        pc.a.assign(split_a, split_a + n_splits);
+        pc.n = al0->n_taxa;
+        pc.D = dmax;
+        pc.nl = -1;
+        SP_CHECK(ctx->splits.ensure((size_t)n_splits * sizeof(SplitDev)));
+        SP_HIP(hipMemcpyAsync(ctx->splits.p, pc.plan.splits.data(), (size_t)n_splits * sizeof(SplitDev),
+                              hipMemcpyHostToDevice, ctx->stream));
+        SP_CHECK(ctx->gram_items.ensure((size_t)n_splits * sizeof(int)));
+        SP_HIP(hipMemcpyAsync(ctx->gram_items.p, pc.plan.order.data(), (size_t)n_splits * sizeof(int),
+                              hipMemcpyHostToDevice, ctx->stream));
+        SP_CHECK(mark_upload(ctx));
+    }
+    SP_CHECK(upload_aldescs(ctx, als, n_al));
+    SP_CHECK(launch_sparse_score(ctx, ctx->aldescs.as<AlDesc>(), n_al, al0->n_taxa, ctx->splits.as<SplitDev>(),
+                                 ctx->gram_items.as<int>(), n_splits, (double*)scores_dev, (int*)status_dev));
+    pc.valid = true;
     return SP_OK;
 }

@@ -55,6 +55,13 @@ struct PhaseTimer {
 };
 
 struct PlanCache;
+// One alignment as the batched kernels see it (sparse route scores several alignments in one launch).
+struct AlDesc {
+    const u64* keys;
+    const u32* counts;
+    int64_t D;
+};
+
 struct sp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -75,6 +82,9 @@ struct sp_ctx {
     DevBuf misc;       // API scratch
     DevBuf misc2;
     DevBuf gram_items; // GramItem[]: Gram tiles, then the row-block items
+    DevBuf aldescs;    // AlDesc[] of the current multi-alignment call
+    std::vector<AlDesc> aldescs_host;
+    hipEvent_t upload_ev = nullptr;  // last plan / descriptor upload of the sparse route (other streams wait on it)
     PlanCache* cache = nullptr;
     int n_cu = 256;
 };
@@ -167,8 +177,8 @@ int launch_zero_scatter_i8(sp_ctx* ctx, int nl, const SplitDev* splits_dev, cons
                            int64_t D, const int2* dims, const u32* rr, const u32* cc, const u32* vals, uint8_t* mats);
 int launch_gram_i8(sp_ctx* ctx, int nl, bool g_i32, const SplitDev* splits_dev, const GramItem* items_dev,
                    int64_t n_items, const int2* dims, const uint8_t* mats, void* grams);
-int launch_sparse_score(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, int n_taxa,
-                        const SplitDev* splits_dev, const int* order_dev, int64_t S, double* scores, int* status);
+int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,
+                        const int* order_dev, int64_t S, double* scores, int* status);
 template <typename T>
 int launch_gram(sp_ctx* ctx, const SplitDev* splits_dev, const GramItem* items_dev, int64_t n_items, const int2* dims,
                 const T* mats, double* grams);

@@ -585,14 +585,22 @@ __device__ __forceinline__ bool spk_converged(double s4, int it, double& prev_su
 // status: bit 0 = iteration cap hit (score written but flagged), bit 1 = not handled here (re-score on the
 // dense route), bits 8.. = number of operator applications.
 
-__global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restrict__ keys,
-                                                              const u32* __restrict__ counts, int64_t D, int n,
+// grid = n_al * S workgroups: block b scores split order[b / n_al] of alignment b % n_al (heaviest splits of every
+// alignment first); score / status index = alignment * S + split.
+__global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __restrict__ als, int n_al, int n,
                                                               const SplitDev* __restrict__ splits,
-                                                              const int* __restrict__ order,
-                                                              double* __restrict__ scores, int* __restrict__ status) {
+                                                              const int* __restrict__ order, int S,
+                                                              double* __restrict__ scores_all,
+                                                              int* __restrict__ status_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SpkShared& sh = *reinterpret_cast<SpkShared*>(smem);
-    const int sid = order[blockIdx.x];
+    const int ai = blockIdx.x % n_al;
+    const int sid = order[blockIdx.x / n_al];
+    const u64* __restrict__ keys = als[ai].keys;
+    const u32* __restrict__ counts = als[ai].counts;
+    const int64_t D = als[ai].D;
+    double* __restrict__ scores = scores_all + (int64_t)ai * S;
+    int* __restrict__ status = status_all + (int64_t)ai * S;
     const SplitDev& sp = splits[sid];
     const int nr = sp.nr, nc = sp.nc, rw = sp.rw, cw = sp.cw;
     if (threadIdx.x < 32) {
@@ -898,9 +906,10 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const u64* __restr
     }
 }
 
-int launch_sparse_score(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, int n_taxa,
-                        const SplitDev* splits_dev, const int* order_dev, int64_t S, double* scores, int* status) {
+int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,
+                        const int* order_dev, int64_t S, double* scores, int* status) {
     if (S == 0) return SP_OK;
+    if (ctx->upload_ev) SP_HIP(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
     PhaseScope ps(ctx, SP_PHASE_SPARSE);
     static bool attr = false;
     if (!attr) {
@@ -908,8 +917,8 @@ int launch_sparse_score(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_BYTES));
         attr = true;
     }
-    hipLaunchKernelGGL(k_sparse_score, dim3((unsigned)S), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream, keys, counts, D,
-                       n_taxa, splits_dev, order_dev, scores, status);
+    hipLaunchKernelGGL(k_sparse_score, dim3((unsigned)(S * n_al)), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream, als_dev,
+                       n_al, n_taxa, splits_dev, order_dev, (int)S, scores, status);
     SP_HIP(hipGetLastError());
     return SP_OK;
 }

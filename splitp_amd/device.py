@@ -41,12 +41,17 @@ class Context:
             pass
         return None
 
-    def sync_stream_with_torch(self):
+    def sync_stream_with_torch(self, ordered=True):
+        """Adopt torch's current stream.  ordered=False skips the drain of the previous stream (lanes: several
+        asynchronous scoring steps in flight, see sp_ctx_set_stream_unordered)."""
         s = self._torch_stream(self.device)
         cur = None if s is None else s.value
         old = None if self._stream is None else self._stream.value
         if cur != old:
-            _lib.check(self._lib.sp_ctx_set_stream(self.handle, s))
+            if ordered or s is None:
+                _lib.check(self._lib.sp_ctx_set_stream(self.handle, s))
+            else:
+                _lib.check(self._lib.sp_ctx_set_stream_unordered(self.handle, s))
             self._stream = s
 
     def synchronize(self):

@@ -376,6 +376,40 @@ def test_async_entry_and_handback(sp, golden):
     assert n_redo > 0 and np.abs(s2 - ref).max() <= 1e-9
 
 
+def test_multi_alignment_launch_matches_single(sp, golden):
+    """sp_score_splits_multi_async: three alignments of different pattern counts in one launch give bit-identical
+    scores to three single-alignment calls, and match the golden / oracle scores."""
+    import torch
+    from splitp_amd import batch, _lib
+    from splitp_amd import synthetic as syn
+
+    names = taxa_names(10)
+    g = golden("n10_L100k")
+    splits = [mask_to_split(int(m), 10, names) for m in g["masks"]]
+    devs = [sp.DeviceAlignment.from_table(O.unpack_table(g["keys"], g["probs"], 10), taxa=names)]
+    tables = []
+    for seed, length in ((11, 20_000), (12, 60_000)):
+        keys, counts = syn.pattern_table(syn.simulate_sites(10, length, 0.05, seed=seed))
+        devs.append(sp.DeviceAlignment.from_arrays(keys, None, 10, counts=counts, n_sites=length, taxa=names))
+        tables.append(syn.table_as_dict(keys, counts, 10, total=length))
+    taxa_arr, a_arr = batch.encode_splits(splits, devs[0], 10)
+    sc = torch.zeros(3 * 501, dtype=torch.float64, device="cuda")
+    st = torch.zeros(3 * 501, dtype=torch.int32, device="cuda")
+    batch.score_encoded_multi_async(devs, taxa_arr, a_arr, sc.data_ptr(), st.data_ptr())
+    torch.cuda.synchronize()
+    multi = sc.cpu().numpy().reshape(3, 501)
+    assert (st.cpu().numpy() & 2).sum() == 0
+    for i, dev in enumerate(devs):
+        one = torch.zeros(501, dtype=torch.float64, device="cuda")
+        st1 = torch.zeros(501, dtype=torch.int32, device="cuda")
+        batch.score_encoded_async(dev, taxa_arr, a_arr, _lib.SP_METHOD_FLATTENING_SPARSE, one.data_ptr(), st1.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(one.cpu().numpy(), multi[i])
+    assert np.abs(multi[0] - g["scores"]).max() <= SCORE_TOL
+    for i in (0, 137, 500):
+        assert abs(O.split_score(O.flattening(splits[i], tables[1], "reduced")) - multi[2][i]) <= SCORE_TOL
+
+
 def test_config3_size_subflattening(sp):
     """BASELINE config 3 size (16 taxa, 1M bp, subflattening route): exact moment identity and oracle spot checks."""
     from splitp_amd import synthetic as syn
