@@ -8,8 +8,9 @@
 // iteration on the implicit Gram operator:
 //       W = C^T V          (sparse, CSC: one 4-lane group per column, whole waves for heavy columns)
 //       Y = C W            (sparse, CSR)
-//       S = Y^T Y = V^T G^2 V,  S = P D P^T (4 x 4 Jacobi),  V <- Y P D^-1/2,  Newton-Schulz polish
-//       sum_i sqrt(D_i) -> sum of the 4 largest singular values^2 of C (converged when it stops moving)
+//   after EACH half product the Gram matrix of the fresh block (v_mfma_f64_4x4x4) gives a Ritz sum - its trace, the
+//   input block being orthonormal - and the Cholesky factor that re-orthonormalises the block (Cholesky-QR);
+//   the sums converge to the sum of the 4 largest squared singular values of C by (sigma_5 / sigma_4)^2 per half product
 //   score = sqrt(max(0, 1 - top4 / trace)),  trace = sum of count^2 (exact integer).
 // Block width 4: on these matrices lambda_5..lambda_16 are of one magnitude, so guard vectors 5-8 buy almost
 // nothing (rate lambda_5/lambda_4 ~ 2e-3 vs lambda_9/lambda_4), while a 4-wide block halves every LDS array.
@@ -50,11 +51,8 @@ extern "C" int sp_debug_spk_stamps(long long* out) {
 #endif
 
 struct SpkShared {
-    double red[SPK_WAVES * 12];
-    double S[12];        // 10 unique entries of the symmetric 4 x 4 (row-major upper: 00 01 02 03 11 12 13 22 23 33)
-    double T[16];        // 4 x 4 transform applied to the block
-    double Zprev[16];    // S0^-1/2 of the previous product (warm start of the inverse-square-root iteration)
-    int have_z, padz;
+    double red[SPK_WAVES * 16];
+    double S[16];        // X^T X of the current block (full symmetric 4 x 4, row-major)
     double top4;
     unsigned long long trace;
     int R, Kc, nheavy_c, nheavy_r, flag, pad;
@@ -111,294 +109,73 @@ __device__ __forceinline__ u32 bm_rank(const u64* bm, const u32* pf, u32 k) {
     return pf[k >> 6] + __popcll(bm[k >> 6] & ((1ull << (k & 63)) - 1));
 }
 
-// Sum the 10 unique entries of X^T X (X: R x 4 block, pitch SPK_VP) into sh.S.  Fixed reduction tree.
-__device__ __forceinline__ void spk_gram(const double* X, int R, SpkShared& sh) {
-    double s[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) s[i] = 0;
-    for (int row = threadIdx.x; row < R; row += SPK_THREADS) {
-        const double a = X[row * SPK_VP], b = X[row * SPK_VP + 1], c = X[row * SPK_VP + 2], d = X[row * SPK_VP + 3];
-        s[0] = fma(a, a, s[0]); s[1] = fma(a, b, s[1]); s[2] = fma(a, c, s[2]); s[3] = fma(a, d, s[3]);
-        s[4] = fma(b, b, s[4]); s[5] = fma(b, c, s[5]); s[6] = fma(b, d, s[6]);
-        s[7] = fma(c, c, s[7]); s[8] = fma(c, d, s[8]); s[9] = fma(d, d, s[9]);
-    }
+// S = X^T X of the rows x 4 block X (row pitch `pitch` doubles) on the matrix cores: one v_mfma_f64_4x4x4 (4 blocks of
+// 4 x 4 x 4) consumes 16 rows; lane l supplies X[base + l/4][l%4] as BOTH operands (A[i][k] of block b sits in lane
+// i + 4b + 16k, B[k][j] in lane j + 4b + 16k - probed, tools/mfma_f64_4x4_probe.hip), D[i][j] of block b comes back in
+// lane j + 4b + 16i.  Blocks are summed with two shuffles, waves through LDS in a fixed order.  Ends with a barrier.
+__device__ __forceinline__ void spk_gram(const double* X, int rows, int pitch, SpkShared& sh) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s[i] += __shfl_xor(s[i], d, 64);
+    const int c = lane & 3, rl = lane >> 2;
+    double acc = 0.0;
+    for (int base = w * 16; base < rows; base += SPK_WAVES * 16) {
+        const int row = base + rl;
+        const double x = row < rows ? X[row * pitch + c] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(x, x, acc, 0, 0, 0);
     }
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 8, 64);
+    if ((lane & 12) == 0) sh.red[w * 16 + (lane >> 4) * 4 + (lane & 3)] = acc;
     __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 10; ++i) sh.red[w * 12 + i] = s[i];
-    }
-    __syncthreads();
-    if (threadIdx.x < 10) {
+    if (threadIdx.x < 16) {
         double t = 0;
-        for (int i = 0; i < SPK_WAVES; ++i) t += sh.red[i * 12 + threadIdx.x];
+        for (int i = 0; i < SPK_WAVES; ++i) t += sh.red[i * 16 + threadIdx.x];
         sh.S[threadIdx.x] = t;
     }
     __syncthreads();
 }
 
-// X <- X * T (T 4 x 4 row-major in sh.T), row-wise.  Ends with a barrier.
-__device__ __forceinline__ void spk_apply(double* X, int R, const SpkShared& sh) {
-    double t[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t[i] = sh.T[i];
-    for (int row = threadIdx.x; row < R; row += SPK_THREADS) {
-        const double a = X[row * SPK_VP], b = X[row * SPK_VP + 1], c = X[row * SPK_VP + 2], d = X[row * SPK_VP + 3];
-        X[row * SPK_VP + 0] = a * t[0] + b * t[4] + c * t[8] + d * t[12];
-        X[row * SPK_VP + 1] = a * t[1] + b * t[5] + c * t[9] + d * t[13];
-        X[row * SPK_VP + 2] = a * t[2] + b * t[6] + c * t[10] + d * t[14];
-        X[row * SPK_VP + 3] = a * t[3] + b * t[7] + c * t[11] + d * t[15];
+// Cholesky-QR step: S = L L^T (sh.S, every thread redundantly in registers), X <- X L^-T by forward substitution per
+// row, so that X^T X = I.  A pivot below 1e-28 of the largest diagonal marks a dead direction (rank < 4): its column
+// becomes zero and stays zero.  Returns min pivot / max pivot (conditioning indicator).  Ends with a barrier.
+__device__ __forceinline__ double spk_chol_apply(double* X, int rows, int pitch, const SpkShared& sh) {
+    const double s00 = sh.S[0], s10 = sh.S[4], s20 = sh.S[8], s30 = sh.S[12];
+    const double s11 = sh.S[5], s21 = sh.S[9], s31 = sh.S[13], s22 = sh.S[10], s32 = sh.S[14], s33 = sh.S[15];
+    const double dmax = fmax(fmax(s00, s11), fmax(s22, s33));
+    const double tiny = 1e-28 * dmax;
+    double pmin = dmax;
+    const double d0 = s00;
+    const double i0 = d0 > tiny ? spk_rsqrt(d0) : 0.0;
+    const double l10 = s10 * i0, l20 = s20 * i0, l30 = s30 * i0;
+    const double d1 = fma(-l10, l10, s11);
+    const double i1 = d1 > tiny ? spk_rsqrt(d1) : 0.0;
+    const double l21 = fma(-l20, l10, s21) * i1, l31 = fma(-l30, l10, s31) * i1;
+    const double d2 = fma(-l21, l21, fma(-l20, l20, s22));
+    const double i2 = d2 > tiny ? spk_rsqrt(d2) : 0.0;
+    const double l32 = fma(-l31, l21, fma(-l30, l20, s32)) * i2;
+    const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33)));
+    const double i3 = d3 > tiny ? spk_rsqrt(d3) : 0.0;
+    pmin = fmin(fmin(d0 > tiny ? d0 : dmax, d1 > tiny ? d1 : dmax), fmin(d2 > tiny ? d2 : dmax, d3 > tiny ? d3 : dmax));
+    for (int row = threadIdx.x; row < rows; row += SPK_THREADS) {
+        double* x = X + row * pitch;
+        const double v0 = x[0] * i0;
+        const double v1 = fma(-l10, v0, x[1]) * i1;
+        const double v2 = fma(-l21, v1, fma(-l20, v0, x[2])) * i2;
+        const double v3 = fma(-l32, v2, fma(-l31, v1, fma(-l30, v0, x[3]))) * i3;
+        x[0] = v0; x[1] = v1; x[2] = v2; x[3] = v3;
     }
     __syncthreads();
+    return dmax > 0 ? pmin / dmax : 1.0;
 }
 
-// 4 x 4 symmetric Jacobi in registers (cyclic order), executed by wave 0 (all lanes redundantly):
-// S (sh.S) = P D P^T.  Writes T = P D^-1/2 (dead directions zeroed) and sh.top4 = sum sqrt(D_i).
-__device__ __forceinline__ void spk_jacobi4(SpkShared& sh) {
-    if (threadIdx.x < 64) {
-        double a[4][4], p[4][4];
-        a[0][0] = sh.S[0]; a[0][1] = sh.S[1]; a[0][2] = sh.S[2]; a[0][3] = sh.S[3];
-        a[1][1] = sh.S[4]; a[1][2] = sh.S[5]; a[1][3] = sh.S[6];
-        a[2][2] = sh.S[7]; a[2][3] = sh.S[8]; a[3][3] = sh.S[9];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < i) a[i][j] = a[j][i];
-                p[i][j] = i == j ? 1.0 : 0.0;
-            }
-        for (int sweep = 0; sweep < 12; ++sweep) {
-            double rel = 0;
-            const double dmx = fmax(fmax(fabs(a[0][0]), fabs(a[1][1])), fmax(fabs(a[2][2]), fabs(a[3][3])));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = i + 1; j < 4; ++j) {
-                    const double v = a[i][j], dd = fabs(a[i][i] * a[j][j]);
-                    if (v * v > 1e-40 * dmx * dmx) rel = fmax(rel, dd > 0 ? v * v / dd : 1.0);
-                }
-            if (!(rel > 1e-22)) break;
-#pragma unroll
-            for (int ip = 0; ip < 3; ++ip)
-#pragma unroll
-                for (int iq = ip + 1; iq < 4; ++iq) {
-                    const double app = a[ip][ip], aqq = a[iq][iq], apq = a[ip][iq];
-                    double c = 1.0, s = 0.0;
-                    if (apq != 0.0 && apq * apq > 1e-40 * fabs(app * aqq)) {
-                        // angle in f32 (cheap); c = rsqrt(1 + t^2), s = t c in fp64: orthogonal to fp64 accuracy for
-                        // any t, an inexact angle only leaves a ~1e-7 |apq| residue for the next sweep
-                        const float num = (float)(aqq - app), den = 2.0f * (float)apq;
-                        float tf;
-                        if (fabsf(num) > 1e18f * fabsf(den)) {
-                            tf = den / (2.0f * num);
-                        } else {
-                            const float tau = num / den;
-                            tf = (tau >= 0.f ? 1.0f : -1.0f) / (fabsf(tau) + sqrtf(1.0f + tau * tau));
-                        }
-                        const double t = (double)tf;
-                        c = spk_rsqrt(1.0 + t * t);
-                        s = t * c;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {  // columns p, q of A and P
-                        const double akp = a[k][ip], akq = a[k][iq];
-                        a[k][ip] = c * akp - s * akq;
-                        a[k][iq] = s * akp + c * akq;
-                        const double pkp = p[k][ip], pkq = p[k][iq];
-                        p[k][ip] = c * pkp - s * pkq;
-                        p[k][iq] = s * pkp + c * pkq;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {  // rows p, q of A
-                        const double apk = a[ip][k], aqk = a[iq][k];
-                        a[ip][k] = c * apk - s * aqk;
-                        a[iq][k] = s * apk + c * aqk;
-                    }
-                }
-        }
-        const double dmax = fmax(fmax(a[0][0], a[1][1]), fmax(a[2][2], a[3][3]));
-        double top = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double dj = a[j][j];
-            const bool alive = dj > 1e-28 * dmax && dj > 0;
-            const double rj = alive ? spk_rsqrt(dj) : 0.0;
-            top += alive ? sqrt(dj) : 0.0;
-            if (threadIdx.x == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sh.T[i * 4 + j] = p[i][j] * rj;
-            }
-        }
-        if (threadIdx.x == 0) sh.top4 = top;
+// Orthonormalise the block in place (its Gram matrix is already in sh.S).  One Cholesky-QR pass leaves
+// |X^T X - I| ~ eps * cond(S); count flattenings have four leading singular values of one magnitude (cond < 100), so
+// one pass is enough; an ill-conditioned block (pivot ratio < 0.05) gets up to two more passes (CholeskyQR2/3).
+__device__ __forceinline__ void spk_orth(double* X, int rows, int pitch, SpkShared& sh) {
+    double ratio = spk_chol_apply(X, rows, pitch, sh);
+    for (int pass = 0; pass < 2 && ratio < 0.05; ++pass) {
+        spk_gram(X, rows, pitch, sh);
+        ratio = spk_chol_apply(X, rows, pitch, sh);
     }
-    __syncthreads();
-}
-
-// 4 x 4 helpers on row-major arrays (every thread computes them redundantly from LDS broadcasts: no serial
-// single-wave section, no extra barriers)
-__device__ __forceinline__ void spk_sym_from(const double* S10, double (&s)[16]) {
-    s[0] = S10[0]; s[1] = S10[1]; s[2] = S10[2]; s[3] = S10[3];
-    s[4] = S10[1]; s[5] = S10[4]; s[6] = S10[5]; s[7] = S10[6];
-    s[8] = S10[2]; s[9] = S10[5]; s[10] = S10[7]; s[11] = S10[8];
-    s[12] = S10[3]; s[13] = S10[6]; s[14] = S10[8]; s[15] = S10[9];
-}
-__device__ __forceinline__ void spk_apply_reg(double* X, int R, const double (&t)[16]) {
-    for (int row = threadIdx.x; row < R; row += SPK_THREADS) {
-        const double a = X[row * SPK_VP], b = X[row * SPK_VP + 1], c = X[row * SPK_VP + 2], d = X[row * SPK_VP + 3];
-        X[row * SPK_VP + 0] = a * t[0] + b * t[4] + c * t[8] + d * t[12];
-        X[row * SPK_VP + 1] = a * t[1] + b * t[5] + c * t[9] + d * t[13];
-        X[row * SPK_VP + 2] = a * t[2] + b * t[6] + c * t[10] + d * t[14];
-        X[row * SPK_VP + 3] = a * t[3] + b * t[7] + c * t[11] + d * t[15];
-    }
-    __syncthreads();
-}
-
-// 4 x 4 matrix product c = a b (row-major), registers
-__device__ __forceinline__ void mm4(const double (&a)[16], const double (&b)[16], double (&c)[16]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            c[4 * i + j] = fma(a[4 * i], b[j], fma(a[4 * i + 1], b[4 + j], fma(a[4 * i + 2], b[8 + j], a[4 * i + 3] * b[12 + j])));
-}
-
-// Ritz values + next orthonormal block from Y (held in X), in place.
-//   Polar decomposition Y = U H:  U = Y (Y^T Y)^-1/2 is orthonormal and H = (Y^T Y)^1/2, so trace(H) =
-//   sum_i sqrt(eig_i(Y^T Y)) is exactly the sum of the four Ritz values and U is the next block.
-//   S0 = Y^T Y (one block reduction);  Z = S0^-1/2 by the coupled Newton-Schulz iteration on the 4 x 4 matrix itself
-//   (registers of wave 0: A <- A (3I - Z A)/2, Z <- (3I - Z A) Z / 2 from A = c S0, Z = I with c = 1 / Gershgorin
-//   bound, quadratic);  X <- X Z sqrt(c);  one Newton-Schulz polish step on the block removes the rounding of the 4 x 4
-//   solve;  trace(H) = trace(T^T S0) with T the total transform.
-//   Taken when Y is well conditioned (column norms within a factor 7, scaled off-diagonals <= 0.25) - true from the
-//   first product on for count flattenings, whose four leading singular values are of one magnitude.
-//   Otherwise (arbitrary blocks / matrices): Jacobi eigen-decomposition of S0, X <- X P D^-1/2, then the same polish.
-__device__ __forceinline__ void spk_ritz_orth(double* X, int R, SpkShared& sh, int st0 = -1) {
-    if (st0 >= 0) SSTAMP(st0);
-    spk_gram(X, R, sh);
-    if (st0 >= 0) SSTAMP(st0 + 1);
-    double s0[16], t[16];
-    spk_sym_from(sh.S, s0);
-    const double dmax = fmax(fmax(s0[0], s0[5]), fmax(s0[10], s0[15]));
-    double d[4];
-    bool alive[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        alive[i] = s0[5 * i] > 1e-28 * dmax && s0[5 * i] > 0;
-        d[i] = alive[i] ? spk_rsqrt(s0[5 * i]) : 0.0;
-    }
-    double offmax = 0, dmin = dmax;
-    bool all_alive = true;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        all_alive = all_alive && alive[i];
-        dmin = fmin(dmin, s0[5 * i]);
-#pragma unroll
-        for (int j = i + 1; j < 4; ++j) offmax = fmax(offmax, fabs(s0[4 * i + j]) * d[i] * d[j]);
-    }
-    double top_jacobi = -1.0;
-    __syncthreads();
-    if (all_alive && offmax <= 0.25 && dmin >= 0.02 * dmax) {
-        if (threadIdx.x < 64) {   // wave 0: Z = S0^-1/2, all lanes redundantly in registers
-            double z[16], m[16], tmp[16];
-            // Newton iteration Z <- Z (3I - Z S0 Z) / 2 (locally quadratic).  Warm start: once the block has settled in
-            // the invariant subspace, S0 = V^T G^2 V barely changes from one product to the next, so the previous
-            // inverse square root is already accurate to ~1e-5 and two steps finish it.  Cold start: c I with
-            // c = 1 / sqrt(Gershgorin bound) (every eigenvalue of c^2 S0 in (0, 1]).
-            bool warm = sh.have_z != 0;
-            if (warm) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) z[i] = sh.Zprev[i];
-                mm4(z, s0, tmp);
-                mm4(tmp, z, m);
-                double err = 0;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) err = fmax(err, fabs(m[i] - ((i % 5 == 0) ? 1.0 : 0.0)));
-                warm = err < 0.5;
-            }
-            if (!warm) {
-                double gb = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    gb = fmax(gb, fabs(s0[4 * i]) + fabs(s0[4 * i + 1]) + fabs(s0[4 * i + 2]) + fabs(s0[4 * i + 3]));
-                const double c = spk_rsqrt(gb);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) z[i] = (i % 5 == 0) ? c : 0.0;
-            }
-            // every pass measures m = Z S0 Z and applies the Newton factor (1.5 I - 0.5 m); the pass whose MEASURED
-            // defect is already <= 1e-8 leaves a defect of ~1e-16 behind (the step squares it), so it is the last one
-            // and doubles as the polish: no second block reduction is needed on this path.
-            double prev_err = 1e300;
-            for (int iter = 0; iter < 12; ++iter) {
-                mm4(z, s0, tmp);
-                mm4(tmp, z, m);                    // m = Z S0 Z -> I
-                double err = 0;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    err = fmax(err, fabs(m[i] - ((i % 5 == 0) ? 1.0 : 0.0)));
-                    m[i] = ((i % 5 == 0) ? 1.5 : 0.0) - 0.5 * m[i];
-                }
-                mm4(z, m, tmp);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) z[i] = tmp[i];
-                if (err <= 1e-8 || err >= prev_err) break;
-                prev_err = err;
-            }
-            if (threadIdx.x == 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    sh.T[i] = z[i];
-                    sh.Zprev[i] = z[i];
-                }
-                sh.have_z = 1;
-            }
-        }
-        __syncthreads();
-    } else {
-        spk_jacobi4(sh);   // writes sh.T = P D^-1/2 and sh.top4
-        top_jacobi = sh.top4;
-    }
-    if (st0 >= 0) SSTAMP(st0 + 2);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t[i] = sh.T[i];
-    spk_apply_reg(X, R, t);
-    if (st0 >= 0) SSTAMP(st0 + 3);
-    for (int iter = 0; iter < 12 && top_jacobi >= 0; ++iter) {   // block polish: robust (Jacobi) path only
-        spk_gram(X, R, sh);
-        double sk[16];
-        spk_sym_from(sh.S, sk);
-        double err = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double target = (i == j && alive[i] && sk[5 * i] > 0.25) ? 1.0 : 0.0;
-                err = fmax(err, fabs(sk[4 * i + j] - target));
-            }
-        if (err <= 2e-15) break;
-        double m[16], tn[16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) m[4 * i + j] = (i == j ? 1.5 : 0.0) - 0.5 * sk[4 * i + j];
-        mm4(t, m, tn);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t[i] = tn[i];
-        spk_apply_reg(X, R, m);
-        if (err * err <= 1e-17) break;   // the step just applied squares the defect: below fp64 resolution
-    }
-    if (st0 >= 0) SSTAMP(st0 + 4);
-    // sum of the Ritz values = trace(T^T S0)   (Jacobi path: S0's eigenvalues were computed directly)
-    double tr = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) tr += t[i] * s0[i];
-    __syncthreads();
-    if (threadIdx.x == 0) sh.top4 = top_jacobi >= 0 ? top_jacobi : tr;
-    __syncthreads();
 }
 
 // Build one list grouped by `major` (CSC: compact column, CSR: compact row) as a STABLE counting sort of the
@@ -575,7 +352,8 @@ __device__ __forceinline__ bool spk_converged(double s4, int it, double& prev_su
         ratio = fmin(fmax(ratio, 0.0), 0.9999);
         const double tail = delta * ratio / (1.0 - ratio);
         // (the Ritz sum itself carries ~2e-15 of rounding noise: a change below 2e-14 is at the floor)
-        if (it >= 3 && (delta <= 2e-14 * s4 || tail <= 1e-14 * s4)) conv = true;
+        // tolerance: the score is sqrt(1 - s4 / trace); 1e-13 relative in s4 is < 1e-11 in any score >= 0.005
+        if (it >= 3 && (delta <= 2e-14 * s4 || tail <= 1e-13 * s4)) conv = true;
     }
     prev_delta = delta;
     prev_sum = s4;
@@ -607,10 +385,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         const int t = threadIdx.x < nr + nc ? sp.taxa[threadIdx.x] : 0;
         sh.shifts[threadIdx.x] = 2 * (n - 1 - t);
     }
-    if (threadIdx.x == 0) {
-        sh.flag = 0;
-        sh.have_z = 0;
-    }
+    if (threadIdx.x == 0) sh.flag = 0;
     __syncthreads();  // shifts are read by every wave below
     size_t off = (sizeof(SpkShared) + 15) & ~(size_t)15;
     auto carve = [&](size_t bytes) {
@@ -865,32 +640,61 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     __syncthreads();
     SSTAMP(5);
     SSTAMP(6);
-    // ---- iteration ------------------------------------------------------------------------------------------
+    // ---- iteration: alternate half products, one Ritz sum per half product -------------------------------------
+    //   h odd :  W = C^T V  (V orthonormal)  ->  trace(W^T W) = trace(V^T C C^T V) = Ritz sum of C C^T on span(V)
+    //   h even:  Y = C W    (W orthonormal)  ->  trace(Y^T Y) = Ritz sum of C^T C on span(W)
+    // Both are Rayleigh-Ritz sums of the same four squared singular values, each better than the last by
+    // (sigma_5 / sigma_4)^2; the block is re-orthonormalised by one Cholesky-QR step on the Gram matrix that has just
+    // been formed (no eigen-decomposition, no polar factor).  Small row side: dense G instead of the two sparse halves.
     double prev_sum = 0, prev_delta = 0, top4 = 0;
     int it = 0, conv = 0;
-    for (it = 1; it <= SPK_MAXIT; ++it) {
-        if (small) {
-            // Y = G V densely (R <= 64): thread (row, j); Y staged in registers, then written over V
+    spk_gram(V, R, SPK_VP, sh);
+    spk_orth(V, R, SPK_VP, sh);
+    if (small) {
+        for (it = 1; it <= SPK_MAXIT; ++it) {
+            // Y = G V densely (R <= 64): thread (row, j); Ritz sum = trace(V^T Y); Y staged in registers, written over V
             const int row = threadIdx.x >> 2, j = threadIdx.x & 3;
-            double acc = 0;
-            if (row < R)
-                for (int k = 0; k < R; ++k) acc += Wb[row * R + k] * V[k * SPK_VP + j];
+            double acc = 0, part = 0;
+            if (row < R) {
+                for (int k = 0; k < R; ++k) acc = fma(Wb[row * R + k], V[k * SPK_VP + j], acc);
+                part = acc * V[row * SPK_VP + j];
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
             __syncthreads();
             if (row < R) V[row * SPK_VP + j] = acc;
+            if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = part;
             __syncthreads();
-        } else {
-            if (it == 1) SSTAMP(7);
-            spk_spmm(csc_ptr, csc_ent, Kc, perm_c, sh.nheavy_c, V, SPK_VP, Wb, wp, it == 1 ? 20 : -1);   // W = C^T V
-            if (it == 1) SSTAMP(8);
-            spk_spmm(csr_ptr, csr_ent, R, perm_r, sh.nheavy_r, Wb, wp, V, SPK_VP, it == 1 ? 21 : -1);    // Y = C W  (overwrites V)
-            if (it == 1) SSTAMP(9);
+            top4 = ((sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3])) + ((sh.red[4] + sh.red[5]) + (sh.red[6] + sh.red[7]));
+            if (spk_converged(top4, it, prev_sum, prev_delta)) {
+                conv = 1;
+                break;
+            }
+            spk_gram(V, R, SPK_VP, sh);
+            spk_orth(V, R, SPK_VP, sh);
         }
-        spk_ritz_orth(V, R, sh, it == 2 ? 40 : -1);
-        if (it == 1) SSTAMP(10);
-        top4 = sh.top4;
-        if (spk_converged(top4, it, prev_sum, prev_delta)) {
-            conv = 1;
-            break;
+    } else {
+        SSTAMP(7);
+        for (it = 1; it <= 2 * SPK_MAXIT; ++it) {
+            double* X;
+            int rows, pitch;
+            if (it & 1) {
+                spk_spmm(csc_ptr, csc_ent, Kc, perm_c, sh.nheavy_c, V, SPK_VP, Wb, wp, it == 1 ? 20 : -1);   // W = C^T V
+                X = Wb; rows = Kc; pitch = wp;
+            } else {
+                spk_spmm(csr_ptr, csr_ent, R, perm_r, sh.nheavy_r, Wb, wp, V, SPK_VP, it == 2 ? 21 : -1);    // Y = C W
+                X = V; rows = R; pitch = SPK_VP;
+            }
+            if (it <= 2) SSTAMP(7 + it);
+            spk_gram(X, rows, pitch, sh);
+            if (it == 2) SSTAMP(40);
+            top4 = (sh.S[0] + sh.S[5]) + (sh.S[10] + sh.S[15]);
+            if (spk_converged(top4, it, prev_sum, prev_delta)) {
+                conv = 1;
+                break;
+            }
+            spk_orth(X, rows, pitch, sh);
+            if (it == 2) SSTAMP(41);
         }
     }
     SSTAMP(11);

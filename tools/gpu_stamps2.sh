@@ -24,8 +24,8 @@ for k in (5, 4, 3):
         batch.score_encoded(dev, taxa_arr, a_arr, 3)
     out = (C.c_longlong * 64)()
     lib.sp_debug_spk_stamps(out)
-    st = np.array(out[:12], dtype=np.int64); d = np.diff(st)
-    names_ = ["bitmaps+trace", "CSC build", "CSR build", "(carve)", "diag/G", "start block", "ritz_orth(init)", "(loop entry)", "spmm1", "spmm2", "ritz_orth(it1)", "rest of iterations"]
-    names2 = ["stage+bitmaps", "CSC build", "CSR build", "start(argmax)", "V init/G", "ritz(init)", "-", "spmm1", "spmm2", "ritz(it1)", "rest"]
-    print(f"k={k}:", "  ".join(f"{a}={b}" for a, b in zip(names2, d)), " total", st[11]-st[0], " | spmm1 light", out[20]-st[7], "heavy", st[8]-out[20], " spmm2 light", out[21]-st[8], "heavy", st[9]-out[21], "nheavy?", out[30], "| ritz(it2): gram", out[41]-out[40], "4x4", out[42]-out[41], "apply", out[43]-out[42], "polish", out[44]-out[43])
+    o = np.array(out[:], dtype=np.int64)
+    print(f"k={k}: stage+bitmaps={o[1]-o[0]} CSC={o[2]-o[1]} CSR={o[3]-o[2]} start={o[4]-o[3]} Vinit/G={o[5]-o[4]} orth0={o[7]-o[6]} "
+          f"spmm1={o[8]-o[7]} (light {o[20]-o[7]}) gram+orth1={o[21]-o[8] if False else 0} spmm2..={o[9]-o[8]} gram2={o[40]-o[9]} orth2={o[41]-o[40]} "
+          f"rest={o[11]-o[41]} total={o[11]-o[0]}")
 PY
