@@ -268,6 +268,8 @@ extern "C" int sp_alignment_destroy(sp_alignment* al) {
     al->keys.release();
     al->weights.release();
     al->counts.release();
+    al->keys32.release();
+    al->spk_meta.release();
     al->moments.release();
     delete al;
     return SP_OK;
@@ -584,7 +586,19 @@ static int mark_upload(sp_ctx* ctx) {
 
 static int upload_aldescs(sp_ctx* ctx, sp_alignment* const* als, int n_al) {
     std::vector<AlDesc> d((size_t)n_al);
-    for (int i = 0; i < n_al; ++i) d[i] = AlDesc{als[i]->keys.as<u64>(), als[i]->counts.as<u32>(), als[i]->D};
+    for (int i = 0; i < n_al; ++i) {
+        sp_alignment* al = als[i];
+        if (!al->spk_ready) {   // one-time, on the stream: 32-bit keys, trace, largest counts
+            SP_REQUIRE(al->n_taxa <= 16, SP_ELIMIT, "sparse route: at most 16 taxa");
+            SP_CHECK(al->keys32.ensure((size_t)std::max<int64_t>(al->D, 1) * 4));
+            SP_CHECK(al->spk_meta.ensure(sizeof(SpkMeta)));
+            SP_CHECK(launch_sparse_meta(ctx, al->keys.as<u64>(), al->counts.as<u32>(), al->D, al->keys32.as<u32>(),
+                                        al->spk_meta.as<SpkMeta>()));
+            SP_CHECK(mark_upload(ctx));
+            al->spk_ready = true;
+        }
+        d[i] = AlDesc{al->keys32.as<u32>(), al->counts.as<u32>(), al->spk_meta.as<SpkMeta>(), al->D};
+    }
     if (ctx->aldescs_host.size() == d.size() && ctx->aldescs.p &&
         memcmp(ctx->aldescs_host.data(), d.data(), d.size() * sizeof(AlDesc)) == 0)
         return SP_OK;  // same alignments as last call: the device copy is current
@@ -693,7 +707,7 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
         if (!ctx->cache) ctx->cache = new PlanCache();
         PlanCache& pc = *ctx->cache;
         const size_t nt = (size_t)n_splits * al->n_taxa;
-        const bool sparse_ok = al->exact && al->max_count < 65536u && al->D <= 65535;
+        const bool sparse_ok = al->exact && al->max_count < 65536u && al->D <= 65535 && al->n_taxa <= 16;
         SP_REQUIRE(method != SP_METHOD_FLATTENING_SPARSE || sparse_ok, SP_ELIMIT,
                    "sparse route needs integer counts < 65536 and at most 65535 patterns");
         const bool use_sparse = method == SP_METHOD_FLATTENING_SPARSE ||
@@ -897,7 +911,7 @@ extern "C" int sp_score_splits_async(sp_alignment* al, const int32_t* split_taxa
     SP_HIP(hipSetDevice(ctx->device));
     if (n_splits == 0) return SP_OK;
     SP_REQUIRE(al->D > 0, SP_EINVAL, "empty pattern table");
-    const bool sparse_ok = al->exact && al->max_count < 65536u && al->D <= 65535;
+    const bool sparse_ok = al->exact && al->max_count < 65536u && al->D <= 65535 && al->n_taxa <= 16;
     const bool want_sparse = method == SP_METHOD_FLATTENING_SPARSE ||
                              (method == SP_METHOD_FLATTENING && sparse_ok && ctx->gram_mode == 0);
     if (want_sparse) {
@@ -942,7 +956,7 @@ extern "C" int sp_score_splits_multi_async(sp_alignment* const* als, int n_al, c
     for (int i = 0; i < n_al; ++i) {
         SP_REQUIRE(als[i] && als[i]->ctx == ctx && als[i]->n_taxa == al0->n_taxa, SP_EINVAL,
                    "alignments of one multi call must share the context and the number of taxa");
-        SP_REQUIRE(als[i]->exact && als[i]->max_count < 65536u && als[i]->D <= 65535 && als[i]->D > 0, SP_ELIMIT,
+        SP_REQUIRE(als[i]->exact && als[i]->max_count < 65536u && als[i]->D <= 65535 && als[i]->D > 0 && als[i]->n_taxa <= 16, SP_ELIMIT,
                    "multi-alignment scoring uses the sparse route: integer counts < 65536, 1..65535 patterns");
         dmax = std::max(dmax, als[i]->D);
     }

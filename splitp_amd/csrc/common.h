@@ -56,9 +56,18 @@ struct PhaseTimer {
 
 struct PlanCache;
 // One alignment as the batched kernels see it (sparse route scores several alignments in one launch).
+#define SPK_NTOP 16
+// split-independent facts about a pattern table, computed once per alignment on the device (k_sparse_meta)
+struct SpkMeta {
+    unsigned long long trace;   // sum of count^2 (exact)
+    u32 top[SPK_NTOP];          // indices of the SPK_NTOP largest counts, descending (ties: lowest index first)
+    u32 ntop;                   // min(SPK_NTOP, D)
+    u32 pad;
+};
 struct AlDesc {
-    const u64* keys;
+    const u32* keys32;          // pattern keys narrowed to 32 bits (n_taxa <= 16)
     const u32* counts;
+    const SpkMeta* meta;
     int64_t D;
 };
 
@@ -98,6 +107,9 @@ struct sp_alignment {
     DevBuf keys;     // u64[D]
     DevBuf weights;  // double[D]
     DevBuf counts;   // u32[D]   (exact only)
+    DevBuf keys32;   // u32[D]   sparse route: keys narrowed to 32 bits (n_taxa <= 16), filled on first use
+    DevBuf spk_meta; // SpkMeta  sparse route: trace + largest counts, filled on first use
+    bool spk_ready = false;
     double sumsq_w = 0;  // sum of weights^2 (host-computed, informational)
     uint32_t max_count = 0;  // largest count (exact only): decides the number of 7-bit limbs of the int8 Gram
     // cached signed second-moment matrix (subflattening path)
@@ -177,6 +189,7 @@ int launch_zero_scatter_i8(sp_ctx* ctx, int nl, const SplitDev* splits_dev, cons
                            int64_t D, const int2* dims, const u32* rr, const u32* cc, const u32* vals, uint8_t* mats);
 int launch_gram_i8(sp_ctx* ctx, int nl, bool g_i32, const SplitDev* splits_dev, const GramItem* items_dev,
                    int64_t n_items, const int2* dims, const uint8_t* mats, void* grams);
+int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta);
 int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,
                         const int* order_dev, int64_t S, double* scores, int* status);
 template <typename T>

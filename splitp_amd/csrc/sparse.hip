@@ -28,21 +28,25 @@
 #define SPK_WAVES 8
 #define SPK_NB 4
 #define SPK_VP 5            // row pitch of V / Y in doubles
-#ifndef SPK_HEAVY
-#define SPK_HEAVY 48
+#ifndef SPK_TEAM_MAX
+#define SPK_TEAM_MAX 32     // a column / row with more entries than this is shared by the 4 teams of a 16-lane row
 #endif
-//        // a column / row with more entries than this is handled by a whole wave
+#define SPK_ROW_MAX 256     // ... and with more than this by the 16 teams of a wave
 #define SPK_MAXIT 40
 #define SPK_LDS_BYTES 163840
 #define SPK_SMALL_R 64
 
 #ifdef SPK_STAMPS
 __device__ long long g_spk_stamps[64];
+__device__ int g_spk_stamp_block = 0;
 #define SSTAMP(i)                                                                              \
     do {                                                                                       \
         __syncthreads();                                                                       \
-        if (threadIdx.x == 0 && blockIdx.x == 0) g_spk_stamps[i] = __builtin_amdgcn_s_memtime(); \
+        if (threadIdx.x == 0 && (int)blockIdx.x == g_spk_stamp_block) g_spk_stamps[i] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+extern "C" int sp_debug_spk_stamp_block(int b) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_spk_stamp_block), &b, sizeof(int)) == hipSuccess ? 0 : 2;
+}
 extern "C" int sp_debug_spk_stamps(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spk_stamps), sizeof(long long) * 64) == hipSuccess ? 0 : 2;
 }
@@ -55,7 +59,7 @@ struct SpkShared {
     double S[16];        // X^T X of the current block (full symmetric 4 x 4, row-major)
     double top4;
     unsigned long long trace;
-    int R, Kc, nheavy_c, nheavy_r, flag, pad;
+    int R, Kc, nw_c, nr_c, nq_c, nw_r, nr_r, nq_r, used_c, used_r, flag, pad;   // nw_* / nr_*: groups handled by a whole wave / by a 16-lane row
     int shifts[32];
     unsigned int scan[SPK_WAVES + 1];
     unsigned int bucket[68];
@@ -185,12 +189,29 @@ __device__ __forceinline__ void spk_orth(double* X, int rows, int pitch, SpkShar
 // the wave's own LDS atomic add: lanes of one ds_add_rtn instruction that hit the same word are resolved by the LDS in
 // a fixed order, and no other wave touches that counter row, so the layout - and with it every later summation
 // order - is reproducible run to run (checked by the bitwise-repeat tests).  No occupancy bitmaps, no chunking.
-//   ptr[nmajor + 1] (u16), ent[D] (u32 = minor | count << 16), perm[nmajor] = groups sorted by size (descending, so
-//   that the 16 four-lane groups of a wave work on groups of similar length); *nheavy = #groups > SPK_HEAVY.
-template <bool MAJOR_IS_COL, int BITS>
+//   perm[nmajor] = groups by size class / descending size, ptrp[nmajor + 1] = entry offsets in THAT order (the entries
+//   of perm[idx] are ent[ptrp[idx] .. ptrp[idx + 1])), ent[D] (u32 = minor | count << 16), ptr[nmajor] = start of
+//   group m (build-time only); *nwave / *nrow = number of groups in the whole-wave / 16-lane-row size classes.
+// size class of a group: 0 empty, 1..4 = 1, 2, 3-4, 5-8 entries (one batch of 1 / 2 / 4 / 8), 5..7 = 2 / 3 / 4 batches of 8,
+// 8 = one 16-lane row per group (> SPK_TEAM_MAX entries), 9 = one wave per group (> SPK_ROW_MAX entries)
+#define SPK_NCLASS 10
+__device__ __forceinline__ int spk_class(int c) {
+    if (c > SPK_ROW_MAX) return 9;
+    if (c > SPK_TEAM_MAX) return 8;
+    if (c > 8) return 4 + ((c + 7) >> 3) - 1;   // 9..16 -> 5, 17..24 -> 6, 25..32 -> 7
+    return c > 4 ? 4 : (c > 2 ? 3 : c);
+}
+
+template <bool MAJOR_IS_COL, int BITS, bool PERMUTE>
 __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned short* cnt, int D, int nmajor,
-                                               unsigned short* ptr, u32* ent, unsigned short* perm, int* nheavy,
-                                               u32* cw, SpkShared& sh, unsigned short* group_of = nullptr) {
+                                               unsigned short* ptr, unsigned short* ptrp, u32* ent,
+                                               unsigned short* perm, int* nwave, int* nrow, int* nquad, int* used, u32* cw,
+                                               SpkShared& sh, unsigned short* end_of = nullptr, int stamp0 = -1) {
+#ifdef SPK_STAMPS
+#define BSTAMP(k) do { if (stamp0 >= 0) SSTAMP(stamp0 + (k)); } while (0)
+#else
+#define BSTAMP(k)
+#endif
     constexpr int PER = 32 / BITS;                     // counters per word
     constexpr u32 FMASK = (1u << BITS) - 1;
     const int stride = (nmajor + PER - 1) / PER;       // words per wave row
@@ -204,6 +225,7 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
     // lane l walks the contiguous sub-chunk [lo + l*q, lo + (l+1)*q): consecutive table entries share their leading
     // digits (hence often their row or column), so giving them to ONE lane keeps the 64 lanes of an atomic on
     // different counters (measured: 64-way same-word conflicts otherwise)
+    // (plain loops: the kernel is VALU-issue bound here, a batched / predicated form measured slower)
     const int q = chunk / 64;
     for (int t = 0; t < q; ++t) {                         // pass A: per-chunk group sizes
         const int i = lo + lane * q + t;
@@ -213,60 +235,122 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
         atomicAdd(&myrow[mj / PER], 1u << (BITS * (mj % PER)));
     }
     __syncthreads();
+    BSTAMP(0);
     // exclusive prefix over the chunks, one thread per packed word (PER groups); totals -> ptr
     for (int q = threadIdx.x; q < stride; q += SPK_THREADS) {
         u32 run[PER];
 #pragma unroll
         for (int f = 0; f < PER; ++f) run[f] = 0;
+        u32 words[SPK_WAVES];
+#pragma unroll
+        for (int ww = 0; ww < SPK_WAVES; ++ww) words[ww] = cw[ww * stride + q];
+#pragma unroll
         for (int ww = 0; ww < SPK_WAVES; ++ww) {
-            const u32 word = cw[ww * stride + q];
             u32 outw = 0;
 #pragma unroll
             for (int f = 0; f < PER; ++f) {
                 outw |= run[f] << (BITS * f);
-                run[f] += (word >> (BITS * f)) & FMASK;
+                run[f] += (words[ww] >> (BITS * f)) & FMASK;
             }
             cw[ww * stride + q] = outw;
         }
 #pragma unroll
         for (int f = 0; f < PER; ++f)
-            if (q * PER + f < nmajor) ptr[q * PER + f] = (unsigned short)run[f];
+            if (q * PER + f < nmajor) ptr[q * PER + f] = (unsigned short)run[f];   // group size, for now
     }
     __syncthreads();
-    {   // exclusive scan of the group sizes -> ptr ; size buckets for the permutation
+    BSTAMP(1);
+    if (PERMUTE) {
+        // Size classes (spk_class), largest first: whole-wave groups, 16-lane-row groups, single-team groups by number of
+        // 8- (then 4-, 2-, 1-) entry batches, empty groups last.  Counting sort with wave-aggregated counters: one ballot
+        // per class, lane c of the wave adds the class-c population with ONE atomic (per-lane atomics on a handful of
+        // hot counters serialise: measured 11 k cycles).  The order INSIDE a class depends on which wave gets there
+        // first; that only moves groups around - every group is still summed in table order, so results do not change.
+        const int rounds = (nmajor + SPK_THREADS - 1) / SPK_THREADS;
+        for (int r = 0; r < rounds; ++r) {
+            const int m = r * SPK_THREADS + threadIdx.x;
+            const int cls = m < nmajor ? spk_class(ptr[m]) : -1;
+            u32 mine = 0;
+#pragma unroll
+            for (int k = 0; k < SPK_NCLASS; ++k) {
+                const u64 b = __ballot(cls == k);
+                if (lane == k) mine = (u32)__popcll(b);
+            }
+            if (lane < SPK_NCLASS && mine) atomicAdd(&sh.bucket[lane], mine);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u32 run = 0;
+            for (int k = SPK_NCLASS - 1; k >= 0; --k) {
+                const u32 c = sh.bucket[k];
+                sh.bucket[k] = run;
+                run += c;
+                if (k == SPK_NCLASS - 1) *nwave = (int)run;
+                if (k == SPK_NCLASS - 2) *nrow = (int)run - *nwave;
+                if (k == 5) *nquad = (int)run;   // (minus the wave / row groups, below)
+                if (k == 1 && used) *used = (int)run;   // everything but the empty groups
+            }
+            *nquad -= *nwave + *nrow;
+        }
+        __syncthreads();
+        for (int r = 0; r < rounds; ++r) {
+            const int m = r * SPK_THREADS + threadIdx.x;
+            const int cls = m < nmajor ? spk_class(ptr[m]) : -1;
+            u32 mine = 0;
+            u64 mymask = 0;
+#pragma unroll
+            for (int k = 0; k < SPK_NCLASS; ++k) {
+                const u64 b = __ballot(cls == k);
+                if (lane == k) mine = (u32)__popcll(b);
+                if (cls == k) mymask = b;
+            }
+            u32 base = 0;
+            if (lane < SPK_NCLASS && mine) base = atomicAdd(&sh.bucket[lane], mine);
+            base = __shfl(base, cls < 0 ? 0 : cls, 64);
+            if (cls >= 0) perm[base + __popcll(mymask & ((1ull << lane) - 1))] = (unsigned short)m;
+        }
+        __syncthreads();
+        BSTAMP(2);
+        {   // entries are laid out in permutation order: ptrp[idx] .. ptrp[idx + 1] = entries of group perm[idx] ...
+            const int per = (nmajor + SPK_THREADS - 1) / SPK_THREADS;
+            const int l0 = min(nmajor, (int)threadIdx.x * per), h0 = min(nmajor, l0 + per);
+            u32 sum = 0;
+            for (int i = l0; i < h0; ++i) sum += ptr[perm[i]];
+            u32 tot;
+            u32 run = spk_scan(sum, sh, tot);
+            for (int i = l0; i < h0; ++i) {
+                ptrp[i] = (unsigned short)run;
+                run += ptr[perm[i]];
+            }
+            if (threadIdx.x == 0) ptrp[nmajor] = (unsigned short)tot;
+            __syncthreads();
+            // ... and ptr[m] becomes the start of group m in that layout (placement below)
+            for (int i = threadIdx.x; i < nmajor; i += SPK_THREADS) ptr[perm[i]] = ptrp[i];
+            __syncthreads();
+        }
+    } else {   // group order = index order: ptr = exclusive scan of the sizes (small path: no products on the list)
         const int per = (nmajor + SPK_THREADS - 1) / SPK_THREADS;
         const int l0 = min(nmajor, (int)threadIdx.x * per), h0 = min(nmajor, l0 + per);
-        u32 sum = 0;
+        u32 sum = 0, nz = 0;
         for (int i = l0; i < h0; ++i) {
-            const u32 c = ptr[i];
-            sum += c;
-            atomicAdd(&sh.bucket[c > 64 ? 64 : c], 1u);
+            sum += ptr[i];
+            nz += ptr[i] != 0;
         }
-        u32 tot;
+        u32 tot, tot_nz;
+        spk_scan(nz, sh, tot_nz);
         u32 run = spk_scan(sum, sh, tot);
         for (int i = l0; i < h0; ++i) {
             const u32 c = ptr[i];
             ptr[i] = (unsigned short)run;
             run += c;
         }
-        if (threadIdx.x == 0) ptr[nmajor] = (unsigned short)tot;
+        if (threadIdx.x == 0) {
+            ptr[nmajor] = (unsigned short)tot;
+            if (used) *used = (int)tot_nz;
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {   // descending bucket offsets; groups above SPK_HEAVY come first
-        u32 run = 0, heavy = 0;
-        for (int bkt = 64; bkt >= 0; --bkt) {
-            const u32 c = sh.bucket[bkt];
-            sh.bucket[bkt] = run;
-            run += c;
-            if (bkt > SPK_HEAVY) heavy = run;
-        }
-        *nheavy = (int)heavy;
-    }
-    __syncthreads();
-    for (int m = threadIdx.x; m < nmajor; m += SPK_THREADS) {
-        const int c = ptr[m + 1] - ptr[m];
-        perm[atomicAdd(&sh.bucket[c > 64 ? 64 : c], 1u)] = (unsigned short)m;   // order inside a bucket is irrelevant
-    }
+    BSTAMP(3);
     for (int t = 0; t < q; ++t) {                         // pass B: placement (same walk as pass A)
         const int i = lo + lane * q + t;
         if (i >= hi) continue;
@@ -276,70 +360,140 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
         const u32 old = atomicAdd(&myrow[mj / PER], 1u << (BITS * (mj % PER)));
         const int pos = ptr[mj] + (int)((old >> (BITS * (mj % PER))) & FMASK);
         ent[pos] = (u32)mn | ((u32)cnt[i] << 16);
-        if (group_of) group_of[pos] = (unsigned short)mj;
+        if (!PERMUTE && end_of) end_of[pos] = ptr[mj + 1];
     }
     __syncthreads();
 }
 
 // out[m][0..3] = sum over the entries e of major group m of count_e * in[minor_e][0..3].
-// Light groups: one 4-lane group each; heavy groups (> SPK_HEAVY entries, listed in heavy[]): one wave each,
-// 16 sub-groups striding the entries, fixed shuffle-tree reduction.  Four independent accumulation chains per
-// lane keep four LDS round trips in flight (the loop is pure LDS latency otherwise); they are combined in a
-// fixed order, so the result is reproducible.  Ends with a barrier.
-__device__ __forceinline__ double spk_term(const u32* ent, int e, const double* in, int in_pitch, int j) {
-    const u32 v = ent[e];
-    return (double)(v >> 16) * in[(v & 0xFFFFu) * in_pitch + j];
+// One LANE handles an entry for all four columns: one entry word, one address, one count conversion and four gathers
+// (two ds_read2_b64) per entry - a quarter of the VALU work of a lane-per-column layout, same LDS traffic.  Groups are
+// laid out by size class (spk_build_list / spk_class):
+//   one wave per group   (> SPK_ROW_MAX entries)   idx <  nwave
+//   one 16-lane row      (> SPK_TEAM_MAX)          idx <  nwave + nrow
+//   one quad             (9 .. SPK_TEAM_MAX)       idx <  nwave + nrow + nquad
+//   one lane             (<= 8, sorted 5-8, 3-4, 2, 1, 0 entries)
+// Partial sums of a quad / row are combined with DPP (no LDS traffic), rows of a wave with two shuffles; every order is
+// fixed, so the result is reproducible run to run.  Ends with a barrier.
+template <int CTRL>
+__device__ __forceinline__ double spk_dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double spk_acc(double acc, const u32* ent, int e, const double* in, int in_pitch, int j) {
-    const u32 v = ent[e];
-    return fma((double)(v >> 16), in[(v & 0xFFFFu) * in_pitch + j], acc);   // explicit fma: the build has contraction off
+#ifndef SPK_UW
+#define SPK_UW 8            // entries per batch of the wide classes
+#endif
+#define SPK_DPP_QUAD_XOR1 0xB1   // quad_perm [1,0,3,2]
+#define SPK_DPP_QUAD_XOR2 0x4E   // quad_perm [2,3,0,1]
+#define SPK_DPP_ROW_SHR4 0x114
+#define SPK_DPP_ROW_SHR8 0x118
+
+// a[0..3] += count * in[minor][0..3] over entries start, start + step, ... < p1, U entries per batch.  PRED = false:
+// the caller guarantees (p1 - start) / step is a multiple of U (no tail).
+template <int U, bool PRED>
+__device__ __forceinline__ void spk_lane_sum(const u32* ent, int start, int step, int p1, const char* in,
+                                             int pitch_bytes, double (&a)[4]) {
+    for (int e = start; e < p1; e += U * step) {
+        u32 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ent[e + u * step];   // may run into the next group / the padding: masked below
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (PRED) v[u] = (e + u * step < p1) ? v[u] : 0u;     // 0 = count 0 of row 0
+        double x[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double* row = reinterpret_cast<const double*>(in + (v[u] & 0xFFFFu) * pitch_bytes);
+            x[u][0] = row[0]; x[u][1] = row[1]; x[u][2] = row[2]; x[u][3] = row[3];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double c = (double)(v[u] >> 16);
+            a[0] = fma(c, x[u][0], a[0]);
+            a[1] = fma(c, x[u][1], a[1]);
+            a[2] = fma(c, x[u][2], a[2]);
+            a[3] = fma(c, x[u][3], a[3]);
+        }
+    }
 }
 
-__device__ __forceinline__ void spk_spmm(const unsigned short* ptr, const u32* ent, int nmajor,
-                                         const unsigned short* perm, int nheavy, const double* in, int in_pitch,
-                                         double* out, int out_pitch, int stamp_at = -1) {
-    const int j = threadIdx.x & 3, g = threadIdx.x >> 2;
-    for (int idx = nheavy + g; idx < nmajor; idx += SPK_THREADS / 4) {
-        const int m = perm[idx];
-        const int p0 = ptr[m], p1 = ptr[m + 1];
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        int e = p0;
-        for (; e + 3 < p1; e += 4) {
-            a0 = spk_acc(a0, ent, e, in, in_pitch, j);
-            a1 = spk_acc(a1, ent, e + 1, in, in_pitch, j);
-            a2 = spk_acc(a2, ent, e + 2, in, in_pitch, j);
-            a3 = spk_acc(a3, ent, e + 3, in, in_pitch, j);
+__device__ __forceinline__ void spk_store4(double* out, const double (&a)[4]) {
+    out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; out[3] = a[3];
+}
+
+__device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* ent, int nmajor,
+                                         const unsigned short* perm, int nwave, int nrow, int nquad, const double* in_d,
+                                         int in_pitch, double* out, int out_pitch, int stamp_at = -1) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const char* in = reinterpret_cast<const char*>(in_d);
+    const int pb = in_pitch * 8;
+    for (int idx = w; idx < nwave; idx += SPK_WAVES) {                      // one wave per group
+        const int p0 = ptrp[idx], p1 = ptrp[idx + 1], m = perm[idx];
+        double a[4] = {0, 0, 0, 0};
+        spk_lane_sum<SPK_UW, true>(ent, p0 + lane, 64, p1, in, pb, a);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            a[c] += spk_dpp<SPK_DPP_QUAD_XOR1>(a[c]);
+            a[c] += spk_dpp<SPK_DPP_QUAD_XOR2>(a[c]);
+            a[c] += spk_dpp<SPK_DPP_ROW_SHR4>(a[c]);
+            a[c] += spk_dpp<SPK_DPP_ROW_SHR8>(a[c]);     // lanes 12..15 of every row: sum over the row
+            a[c] += __shfl_xor(a[c], 16, 64);
+            a[c] += __shfl_xor(a[c], 32, 64);
         }
-        if (e < p1) a0 = spk_acc(a0, ent, e, in, in_pitch, j);
-        if (e + 1 < p1) a1 = spk_acc(a1, ent, e + 1, in, in_pitch, j);
-        if (e + 2 < p1) a2 = spk_acc(a2, ent, e + 2, in, in_pitch, j);
-        out[m * out_pitch + j] = (a0 + a1) + (a2 + a3);
+        if (lane == 63) spk_store4(out + m * out_pitch, a);
+    }
+#ifdef SPK_STAMPS
+    if (stamp_at >= 0) SSTAMP(stamp_at + 10);
+#endif
+    {                                                                       // one 16-lane row per group
+        const int row = threadIdx.x >> 4, t = threadIdx.x & 15;
+        for (int idx = nwave + row; idx < nwave + nrow; idx += SPK_THREADS / 16) {
+            const int p0 = ptrp[idx], p1 = ptrp[idx + 1], m = perm[idx];
+            double a[4] = {0, 0, 0, 0};
+            spk_lane_sum<SPK_UW, true>(ent, p0 + t, 16, p1, in, pb, a);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                a[c] += spk_dpp<SPK_DPP_QUAD_XOR1>(a[c]);
+                a[c] += spk_dpp<SPK_DPP_QUAD_XOR2>(a[c]);
+                a[c] += spk_dpp<SPK_DPP_ROW_SHR4>(a[c]);
+                a[c] += spk_dpp<SPK_DPP_ROW_SHR8>(a[c]);
+            }
+            if (t == 15) spk_store4(out + m * out_pitch, a);
+        }
+    }
+    {                                                                       // one quad per group (9 .. 32 entries)
+        const int quad = threadIdx.x >> 2, t = threadIdx.x & 3;
+        const int q0 = nwave + nrow;
+        for (int idx = q0 + quad; idx < q0 + nquad; idx += SPK_THREADS / 4) {
+            const int p0 = ptrp[idx], p1 = ptrp[idx + 1], m = perm[idx];
+            double a[4] = {0, 0, 0, 0};
+            spk_lane_sum<SPK_UW, true>(ent, p0 + t, 4, p1, in, pb, a);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                a[c] += spk_dpp<SPK_DPP_QUAD_XOR1>(a[c]);
+                a[c] += spk_dpp<SPK_DPP_QUAD_XOR2>(a[c]);
+            }
+            if (t == 0) spk_store4(out + m * out_pitch, a);
+        }
     }
 #ifdef SPK_STAMPS
     if (stamp_at >= 0) SSTAMP(stamp_at);
 #endif
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int sg = lane >> 2;
-    for (int h = w; h < nheavy; h += SPK_WAVES) {
-        const int m = perm[h];
-        const int p0 = ptr[m], p1 = ptr[m + 1];
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        int e = p0 + sg;
-        for (; e + 48 < p1; e += 64) {
-            a0 = spk_acc(a0, ent, e, in, in_pitch, j);
-            a1 = spk_acc(a1, ent, e + 16, in, in_pitch, j);
-            a2 = spk_acc(a2, ent, e + 32, in, in_pitch, j);
-            a3 = spk_acc(a3, ent, e + 48, in, in_pitch, j);
-        }
-        if (e < p1) a0 = spk_acc(a0, ent, e, in, in_pitch, j);
-        if (e + 16 < p1) a1 = spk_acc(a1, ent, e + 16, in, in_pitch, j);
-        if (e + 32 < p1) a2 = spk_acc(a2, ent, e + 32, in, in_pitch, j);
-        double acc = (a0 + a1) + (a2 + a3);
-        acc += __shfl_xor(acc, 4, 64);
-        acc += __shfl_xor(acc, 8, 64);
-        acc += __shfl_xor(acc, 16, 64);
-        acc += __shfl_xor(acc, 32, 64);
-        if (lane < 4) out[m * out_pitch + j] = acc;
+    for (int idx = nwave + nrow + nquad + (int)threadIdx.x; idx < nmajor; idx += SPK_THREADS) {   // one lane per group
+        const int p0 = ptrp[idx], p1 = ptrp[idx + 1], m = perm[idx], len = p1 - p0;
+        double a[4] = {0, 0, 0, 0};
+        // the classes are sorted, so the lanes of a wave hold groups of (nearly) one size
+        if (__ballot(len > 4))
+            spk_lane_sum<SPK_UW, true>(ent, p0, 1, p1, in, pb, a);
+        else if (__ballot(len > 2))
+            spk_lane_sum<4, true>(ent, p0, 1, p1, in, pb, a);
+        else if (__ballot(len != 1) == 0)
+            spk_lane_sum<1, false>(ent, p0, 1, p1, in, pb, a);
+        else
+            spk_lane_sum<2, true>(ent, p0, 1, p1, in, pb, a);
+        spk_store4(out + m * out_pitch, a);
     }
     __syncthreads();
 }
@@ -374,8 +528,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     SpkShared& sh = *reinterpret_cast<SpkShared*>(smem);
     const int ai = blockIdx.x % n_al;
     const int sid = order[blockIdx.x / n_al];
-    const u64* __restrict__ keys = als[ai].keys;
+    const u32* __restrict__ keys = als[ai].keys32;
     const u32* __restrict__ counts = als[ai].counts;
+    const SpkMeta* __restrict__ meta = als[ai].meta;
     const int64_t D = als[ai].D;
     double* __restrict__ scores = scores_all + (int64_t)ai * S;
     int* __restrict__ status = status_all + (int64_t)ai * S;
@@ -393,15 +548,22 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         off = (off + bytes + 15) & ~(size_t)15;
         return p;
     };
-    // ---- stage the table in LDS once: cell[i] = (row key << 2 nc) | col key, cnt[i] = count -----------------------
+    // ---- stage the table in LDS once: pc[i] = row id << 16 | col id, cnt[i] = count --------------------------------
     // (every later pass reads LDS; a pass over global memory costs D / 512 serialised load latencies)
-    const int W = rw + cw;
+    // A side of at most 5 taxa keeps its raw base-4 id (<= 1024 ids: the V / W rows of unused ids stay zero); a longer
+    // side is compacted to the ids in use with a presence bitmap + popcount ranks.
+#ifndef SPK_RAW_MAX
+#define SPK_RAW_MAX 5
+#endif
+    const bool raw_r = nr <= SPK_RAW_MAX, raw_c = nc <= SPK_RAW_MAX;
+    const int rwl = raw_r ? 0 : rw, cwl = raw_c ? 0 : cw;   // bitmap words in use
+    const int W = rwl + cwl;
     const int Di = (int)D;
-    // a-priori bounds min(4^side, D) on the compact sizes (the actual R, Kc are known only after ranking)
-    const int kc_cap = (int)min((long long)D, nc >= 8 ? (long long)D : (1ll << (2 * nc)));
-    const int r_cap = (int)min((long long)D, nr >= 8 ? (long long)D : (1ll << (2 * nr)));
+    // a-priori bounds on the matrix sizes (the actual sizes of compacted sides are known only after ranking)
+    const int kc_cap = raw_c ? (1 << (2 * nc)) : (int)min((long long)D, nc >= 8 ? (long long)D : (1ll << (2 * nc)));
+    const int r_cap = raw_r ? (1 << (2 * nr)) : (int)min((long long)D, nr >= 8 ? (long long)D : (1ll << (2 * nr)));
     const bool small_sure = r_cap <= SPK_SMALL_R;   // then no CSR list is needed
-    const size_t need_build = off + (size_t)D * (small_sure ? 4 : 8) + (size_t)D * 6 + (size_t)W * 12 + 256;
+    const size_t need_build = off + (size_t)(D + 8) * (small_sure ? 4 : 8) + (size_t)D * 6 + (size_t)W * 12 + 256;
     if (D > 65535 || n > 16 || need_build + 2048 > SPK_LDS_BYTES) {
         if (threadIdx.x == 0) {
             scores[sid] = 0.0;
@@ -409,11 +571,16 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         }
         return;
     }
+    (void)kc_cap;
     SSTAMP(0);
-    // region A (persistent): CSC list, CSR list, pointers, heavy lists.  Region B: staging + bitmaps while
-    // building, then V and W (or G).  Sizes that depend on R / Kc are carved after the ranks are known.
-    u32* csc_ent = reinterpret_cast<u32*>(carve((size_t)D * 4));
-    u32* csr_ent = small_sure ? nullptr : reinterpret_cast<u32*>(carve((size_t)D * 4));
+    // region A (persistent): CSC list, CSR list.  Region B: staging + bitmaps while building, then V and W (or G).
+    // Sizes that depend on R / Kc are carved after the ranks are known.
+    u32* csc_ent = reinterpret_cast<u32*>(carve((size_t)(D + 8) * 4));   // + 8: the unpredicated tail reads of the products
+    u32* csr_ent = small_sure ? nullptr : reinterpret_cast<u32*>(carve((size_t)(D + 8) * 4));
+    if (threadIdx.x < 8) {
+        csc_ent[D + threadIdx.x] = 0;
+        if (csr_ent) csr_ent[D + threadIdx.x] = 0;
+    }
     const size_t off_after_lists = off;
     u32* pc = reinterpret_cast<u32*>(carve((size_t)D * 4));
     unsigned short* cnt = reinterpret_cast<unsigned short*>(carve((size_t)D * 2));
@@ -421,7 +588,6 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     u32* pf = reinterpret_cast<u32*>(carve((size_t)W * 4));
     const int* shifts = sh.shifts;
     for (int i = threadIdx.x; i < W; i += SPK_THREADS) bm[i] = 0;
-    unsigned long long tr = 0;
     // cell = sum_t digit_t(key) << dst_t: source / destination shifts are wave-uniform -> scalar registers
     int ssrc[16], sdst[16];
 #pragma unroll
@@ -431,38 +597,43 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         sdst[t] = __builtin_amdgcn_readfirstlane(valid ? (t < nr ? 2 * (nc + nr - 1 - t) : 2 * (nr + nc - 1 - t)) : 0);
     }
     const int ntax = nr + nc;
-    for (int i = threadIdx.x; i < Di; i += SPK_THREADS) {  // no atomics in this loop: the loads pipeline
-        const u64 key = keys[i];
-        u32 cell = 0;
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-            if (t < ntax) cell |= (u32)((key >> ssrc[t]) & 3ull) << sdst[t];
-        pc[i] = cell;
-        const u32 v = counts[i];
-        cnt[i] = (unsigned short)v;
-        tr += (unsigned long long)v * v;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) tr += __shfl_xor(tr, d, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long*>(sh.red)[threadIdx.x >> 6] = tr;
     const u32 cmask = (nc >= 16) ? 0xFFFFFFFFu : ((1u << (2 * nc)) - 1);
-    for (int i = threadIdx.x; i < Di; i += SPK_THREADS) {
-        const u32 cell = pc[i];
-        const u32 r = cell >> (2 * nc), c = cell & cmask;
-        const u64 rb = 1ull << (r & 63), cb = 1ull << (c & 63);
-        if (!(*(volatile u64*)(bm + (r >> 6)) & rb)) atomicOr(bm + (r >> 6), rb);
-        if (!(*(volatile u64*)(bm + rw + (c >> 6)) & cb)) atomicOr(bm + rw + (c >> 6), cb);
+    const bool both_raw = raw_r && raw_c;
+    __syncthreads();   // bitmaps are zero
+    for (int base = 0; base < Di; base += SPK_THREADS * 8) {   // 8 global loads in flight per thread
+        u32 key[8], cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * SPK_THREADS + (int)threadIdx.x;
+            key[u] = i < Di ? keys[i] : 0u;
+            cv[u] = i < Di ? counts[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * SPK_THREADS + (int)threadIdx.x;
+            if (i >= Di) continue;
+            u32 cell = 0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (t < ntax) cell |= ((key[u] >> ssrc[t]) & 3u) << sdst[t];
+            const u32 r = cell >> (2 * nc), c = cell & cmask;
+            pc[i] = both_raw ? ((r << 16) | c) : cell;
+            cnt[i] = (unsigned short)cv[u];
+            if (!raw_r) {   // presence bits (a plain read first saves most of the atomics)
+                const u64 rb = 1ull << (r & 63);
+                if (!(*(volatile u64*)(bm + (r >> 6)) & rb)) atomicOr(bm + (r >> 6), rb);
+            }
+            if (!raw_c) {
+                const u64 cb = 1ull << (c & 63);
+                if (!(*(volatile u64*)(bm + rwl + (c >> 6)) & cb)) atomicOr(bm + rwl + (c >> 6), cb);
+            }
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int i = 0; i < SPK_WAVES; ++i) t += reinterpret_cast<unsigned long long*>(sh.red)[i];
-        sh.trace = t;
-    }
-    int dimsRC[2];
+    int dimsRC[2] = {1 << (2 * (raw_r ? nr : 0)), 1 << (2 * (raw_c ? nc : 0))};
     for (int which = 0; which < 2; ++which) {
-        const int base = which ? rw : 0, cntw = which ? cw : rw;
+        if (which ? raw_c : raw_r) continue;
+        const int base = which ? rwl : 0, cntw = which ? cwl : rwl;
         const int per = (cntw + SPK_THREADS - 1) / SPK_THREADS;
         const int lo = min(cntw, (int)threadIdx.x * per), hi = min(cntw, lo + per);
         u32 s = 0;
@@ -477,36 +648,55 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     }
     __syncthreads();
     SSTAMP(1);
-    const int R = dimsRC[0], Kc = dimsRC[1];
-    const double trace = (double)sh.trace;
-    if (R <= 4 || !(trace > 0)) {
-        // min(shape) <= 4: the reference computes 1 - x/x = 0 exactly; all-zero table: 0/0 = nan
+    const int R = dimsRC[0], Kc = dimsRC[1];   // matrix sizes (ids), >= the rows / columns in use on raw sides
+    const double trace = (double)meta->trace;
+    // min(shape) <= 4: the reference's SVD returns at most 4 values, so it computes 1 - x/x = 0 exactly; an all-zero
+    // table gives 0/0 = nan.  (raw sides: the number of ids in use is known after the lists are built, checked there)
+    auto degenerate = [&](int used_r, int used_c) {
+        if (used_r > 4 && used_c > 4 && trace > 0) return false;
         if (threadIdx.x == 0) {
             scores[sid] = trace > 0 ? 0.0 : __builtin_nan("");
             status[sid] = 0;
         }
-        return;
+        return true;
+    };
+    if (degenerate(raw_r ? 5 : R, raw_c ? 5 : Kc)) return;
+    if (!both_raw) {   // compact coordinates in place: pc[i] = rr << 16 | cc (8 look-ups in flight per thread)
+        for (int base = 0; base < Di; base += SPK_THREADS * 8) {
+            u32 cell[8], rr[8], cc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * SPK_THREADS + (int)threadIdx.x;
+                cell[u] = i < Di ? pc[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const u32 r = cell[u] >> (2 * nc), c = cell[u] & cmask;
+                rr[u] = raw_r ? r : bm_rank(bm, pf, r);
+                cc[u] = raw_c ? c : bm_rank(bm + rwl, pf + rwl, c);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * SPK_THREADS + (int)threadIdx.x;
+                if (i < Di) pc[i] = (rr[u] << 16) | cc[u];
+            }
+        }
+        __syncthreads();
     }
-    // compact coordinates in place: pc[i] = rr << 16 | cc
-    for (int i = threadIdx.x; i < Di; i += SPK_THREADS) {
-        const u32 cell = pc[i];
-        const u32 r = cell >> (2 * nc), c = cell & cmask;
-        pc[i] = (bm_rank(bm, pf, r) << 16) | bm_rank(bm + rw, pf + rw, c);
-    }
-    __syncthreads();
     const bool small = small_sure;   // (R <= 64 with a larger bound simply takes the general path)
     const int Rp = (R + 3) & ~3;
-    // pointer + permutation arrays (now that R and Kc are known) are carved top-down from the end of LDS; the
-    // key bitmaps are dead: the counting-sort counters start where they were
+    // group descriptors + permutations (now that R and Kc are known) are carved top-down from the end of LDS; the key
+    // bitmaps are dead: the counting-sort counters start where they were
     size_t top = SPK_LDS_BYTES;
     auto carve_top = [&](size_t bytes) {
         top = (top - bytes) & ~(size_t)15;
         return smem + top;
     };
-    unsigned short* csc_ptr = reinterpret_cast<unsigned short*>(carve_top((size_t)(Kc + 1) * 2));
-    unsigned short* csr_ptr = reinterpret_cast<unsigned short*>(carve_top((size_t)(R + 1) * 2));
-    unsigned short* perm_c = reinterpret_cast<unsigned short*>(carve_top((size_t)Kc * 2));
-    unsigned short* perm_r = reinterpret_cast<unsigned short*>(carve_top((size_t)R * 2));
+    unsigned short* desc_c = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)(Kc + 1) * 2));
+    unsigned short* desc_r = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)(R + 1) * 2));
+    unsigned short* perm_c = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)Kc * 2));
+    unsigned short* perm_r = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)R * 2));
+    unsigned short* csc_ptr = small ? reinterpret_cast<unsigned short*>(carve_top((size_t)(Kc + 1) * 2)) : nullptr;
     const size_t build_end = reinterpret_cast<unsigned char*>(bm) - smem;
     // W row pitch: 5 doubles when LDS allows it (rows start on 32 different bank offsets instead of 8: the gathers
     // of Y = C W hit random rows), 4 otherwise
@@ -515,10 +705,13 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     const int wp = (!small && base_iter + (size_t)Kc * 5 * 8 <= top_probe) ? 5 : 4;
     const size_t need_iter = base_iter + (small ? (size_t)R * R * 8 : (size_t)Kc * wp * 8);
     // counters: SPK_WAVES rows of 16-bit (8-bit when a group cannot exceed 255 entries) fields
-    const bool bits8 = R <= 255 && small;
+    const bool bits8 = small;   // a column has at most R <= 64 entries
     const size_t cw_c = (size_t)SPK_WAVES * ((Kc + (bits8 ? 3 : 1)) / (bits8 ? 4 : 2)) * 4;
     const size_t cw_r = small ? 0 : (size_t)SPK_WAVES * ((R + 1) / 2) * 4;
-    if (need_iter > top || build_end + (cw_c > cw_r ? cw_c : cw_r) > top || Kc > 65535) {
+    // build-time start of every group (general path): columns - in the not yet written CSR list; rows - right behind
+    // the row counters
+    const size_t grp_r_bytes = small ? 0 : (((size_t)R + 1) * 2 + 15) & ~(size_t)15;
+    if (need_iter > top || build_end + cw_c > top || build_end + cw_r + grp_r_bytes + 16 > top || Kc > 65535) {
         if (threadIdx.x == 0) {
             scores[sid] = 0.0;
             status[sid] = 2;
@@ -526,7 +719,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         return;
     }
     u32* cwbuf = reinterpret_cast<u32*>(smem + build_end);
-    // small path: column of every CSC position (for the entry-parallel Gram below); it lives in the W / G area's tail
+    unsigned short* grp_c = reinterpret_cast<unsigned short*>(csr_ent);
+    unsigned short* grp_r = reinterpret_cast<unsigned short*>(smem + ((build_end + cw_r + 15) & ~(size_t)15));
+    // small path: end of the column of every CSC position (for the entry-parallel Gram below); it lives in the G area's tail
     unsigned short* colof = nullptr;
     if (small) {
         colof = reinterpret_cast<unsigned short*>(carve_top((size_t)Di * 2));
@@ -538,56 +733,50 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             return;
         }
     }
-    if (bits8)
-        spk_build_list<true, 8>(pc, cnt, Di, Kc, csc_ptr, csc_ent, perm_c, &sh.nheavy_c, cwbuf, sh, colof);
+    if (small)
+        spk_build_list<true, 8, false>(pc, cnt, Di, Kc, csc_ptr, nullptr, csc_ent, nullptr, nullptr, nullptr, nullptr, &sh.used_c,
+                                       cwbuf, sh, colof);
     else
-        spk_build_list<true, 16>(pc, cnt, Di, Kc, csc_ptr, csc_ent, perm_c, &sh.nheavy_c, cwbuf, sh);
+        spk_build_list<true, 16, true>(pc, cnt, Di, Kc, grp_c, desc_c, csc_ent, perm_c, &sh.nw_c, &sh.nr_c, &sh.nq_c, &sh.used_c,
+                                       cwbuf, sh, nullptr, 50);
     SSTAMP(2);
-    if (!small) spk_build_list<false, 16>(pc, cnt, Di, R, csr_ptr, csr_ent, perm_r, &sh.nheavy_r, cwbuf, sh);
+    if (!small)
+        spk_build_list<false, 16, true>(pc, cnt, Di, R, grp_r, desc_r, csr_ent, perm_r, &sh.nw_r, &sh.nr_r, &sh.nq_r, &sh.used_r,
+                                        cwbuf, sh);
     SSTAMP(3);
+    // ids in use on raw sides (small path: the used rows are the non-zero diagonal entries of G, checked below)
+    if (degenerate(small ? 5 : sh.used_r, sh.used_c)) return;
     // ---- start block: unit vectors on the rows of the 4 largest counts (distinct rows) ----------------------------
     // (the dominant singular vectors of a count flattening sit on the few very frequent patterns); chosen by four
     // rounds of a block arg-max over (count, index), deterministic tie-break.
     int top_row[SPK_NB];
     {
-        // each lane keeps the best (count, index) of its strided entries; each wave extracts its 4 best lane
-        // candidates with distinct rows (shuffles only); wave 0 picks the 4 best distinct rows of the 32 candidates.
-        // Candidate = (count << 32) | (0xFFFFFFFF - index): max = largest count, lowest index.  Any 4 strong distinct
-        // rows make a good start block; exact ties / a lane holding two of the top rows only cost a bit of start quality.
-        unsigned long long* slot = reinterpret_cast<unsigned long long*>(sh.red);   // SPK_WAVES * 4 entries
+        // rows of the SPK_NTOP most frequent patterns (found once per alignment, k_sparse_meta); the first 4 distinct
+        // rows among them, missing ones (fewer than 4 distinct) filled with the lowest unused row ids.  Any 4 strong
+        // distinct rows make a good start block; the hash noise below covers the directions they miss.
         int* rows_out = reinterpret_cast<int*>(sh.S);
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        unsigned long long mine = 0;
-        for (int i = threadIdx.x; i < Di; i += SPK_THREADS) {
-            const unsigned long long cand = ((unsigned long long)cnt[i] << 32) | (0xFFFFFFFFull - (unsigned)i);
-            mine = cand > mine ? cand : mine;
-        }
-        int myrow = mine ? (int)(pc[(int)(0xFFFFFFFFull - (mine & 0xFFFFFFFFull))] >> 16) : -1;
-        for (int k = 0; k < SPK_NB; ++k) {
-            unsigned long long best = mine;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const unsigned long long o = __shfl_xor(best, d, 64);
-                best = o > best ? o : best;
-            }
-            const int brow = best ? (int)(pc[(int)(0xFFFFFFFFull - (best & 0xFFFFFFFFull))] >> 16) : -1;
-            if (lane == 0) slot[w * SPK_NB + k] = best;
-            if (myrow == brow) mine = 0;   // this row is taken: drop every lane candidate on it
-        }
-        __syncthreads();
         if (threadIdx.x < 64) {
-            unsigned long long c = lane < SPK_WAVES * SPK_NB ? slot[lane] : 0;
-            int crow = c ? (int)(pc[(int)(0xFFFFFFFFull - (c & 0xFFFFFFFFull))] >> 16) : -1;
-            for (int k = 0; k < SPK_NB; ++k) {
-                unsigned long long best = c;
+            const int lane = threadIdx.x;
+            const int ntop = (int)meta->ntop;
+            int myrow = -1;
+            if (lane < ntop) myrow = (int)(pc[meta->top[lane]] >> 16);
+            u64 active = __ballot(myrow >= 0);
+            int got = 0, chosen[SPK_NB] = {-1, -1, -1, -1};
+            for (int k = 0; k < SPK_NB && active; ++k) {
+                const int first = __builtin_ctzll(active);
+                const int r = __shfl(myrow, first, 64);
+                chosen[k] = r;
+                ++got;
+                active &= ~__ballot(myrow == r);
+            }
+            for (int r = 0; got < SPK_NB && r < R; ++r) {
+                bool used = false;
+                for (int k = 0; k < got; ++k) used = used || chosen[k] == r;
+                if (!used) chosen[got++] = r;
+            }
+            if (lane == 0) {
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) {
-                    const unsigned long long o = __shfl_xor(best, d, 64);
-                    best = o > best ? o : best;
-                }
-                const int brow = best ? (int)(pc[(int)(0xFFFFFFFFull - (best & 0xFFFFFFFFull))] >> 16) : -1;
-                if (lane == 0) rows_out[k] = brow;
-                if (crow == brow) c = 0;
+                for (int k = 0; k < SPK_NB; ++k) rows_out[k] = chosen[k];
             }
         }
         __syncthreads();
@@ -611,7 +800,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             const u32 va = csc_ent[a];
             const unsigned long long ca = va >> 16;
             const int ra = va & 0xFFFF;
-            const int p1 = csc_ptr[colof[a] + 1];
+            const int p1 = colof[a];   // end of the column of position a
             for (int b = a; b < p1; ++b) {
                 const u32 vb = csc_ent[b];
                 const int rb = vb & 0xFFFF;   // entries of a column are in table order, not row order
@@ -629,7 +818,12 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             const int r = i / R, c = i % R;
             if (r > c) Wb[r * R + c] = Wb[c * R + r];
         }
+        if (threadIdx.x < 64) {   // rows in use = non-zero diagonal entries (R <= 64)
+            const u64 nzd = __ballot((int)threadIdx.x < R && Wb[threadIdx.x * R + threadIdx.x] != 0.0);
+            if (threadIdx.x == 0) sh.used_r = (int)__popcll(nzd);
+        }
         __syncthreads();
+        if (degenerate(sh.used_r, 5)) return;
     }
     for (int e = threadIdx.x; e < Rp * SPK_VP; e += SPK_THREADS) V[e] = 0.0;
     __syncthreads();
@@ -679,10 +873,10 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             double* X;
             int rows, pitch;
             if (it & 1) {
-                spk_spmm(csc_ptr, csc_ent, Kc, perm_c, sh.nheavy_c, V, SPK_VP, Wb, wp, it == 1 ? 20 : -1);   // W = C^T V
+                spk_spmm(desc_c, csc_ent, Kc, perm_c, sh.nw_c, sh.nr_c, sh.nq_c, V, SPK_VP, Wb, wp, it == 1 ? 20 : -1);   // W = C^T V
                 X = Wb; rows = Kc; pitch = wp;
             } else {
-                spk_spmm(csr_ptr, csr_ent, R, perm_r, sh.nheavy_r, Wb, wp, V, SPK_VP, it == 2 ? 21 : -1);    // Y = C W
+                spk_spmm(desc_r, csr_ent, R, perm_r, sh.nw_r, sh.nr_r, sh.nq_r, Wb, wp, V, SPK_VP, it == 2 ? 21 : -1);    // Y = C W
                 X = V; rows = R; pitch = SPK_VP;
             }
             if (it <= 2) SSTAMP(7 + it);
@@ -708,6 +902,63 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             status[sid] = 2 | (it << 8);  // no spectral gap behind the 4th value: let the 16-wide dense route do it
         }
     }
+}
+
+// Once per alignment: keys narrowed to 32 bits, trace = sum count^2, the SPK_NTOP largest counts (descending, ties by
+// lowest index).  One 1024-thread block; D <= 65535.
+__global__ __launch_bounds__(1024) void k_sparse_meta(const u64* __restrict__ keys, const u32* __restrict__ counts, int D,
+                                                      u32* __restrict__ keys32, SpkMeta* __restrict__ meta) {
+    __shared__ unsigned long long red[16];
+    __shared__ unsigned long long winner;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long tr = 0;
+    for (int i = threadIdx.x; i < D; i += 1024) {
+        keys32[i] = (u32)keys[i];
+        const unsigned long long c = counts[i];
+        tr += c * c;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tr += __shfl_xor(tr, d, 64);
+    if (lane == 0) red[w] = tr;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        meta->trace = t;
+        meta->ntop = (u32)(D < SPK_NTOP ? D : SPK_NTOP);
+        meta->pad = 0;
+    }
+    unsigned long long bound = ~0ull;   // candidates = (count << 32) | (0xFFFFFFFF - index): extracted in descending order
+    for (int k = 0; k < SPK_NTOP; ++k) {
+        unsigned long long best = 0;
+        for (int i = threadIdx.x; i < D; i += 1024) {
+            const unsigned long long cand = ((unsigned long long)counts[i] << 32) | (0xFFFFFFFFull - (unsigned)i);
+            if (cand < bound && cand > best) best = cand;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(best, d, 64);
+            best = o > best ? o : best;
+        }
+        __syncthreads();
+        if (lane == 0) red[w] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long b = 0;
+            for (int i = 0; i < 16; ++i) b = red[i] > b ? red[i] : b;
+            winner = b;
+            meta->top[k] = b ? (u32)(0xFFFFFFFFull - (b & 0xFFFFFFFFull)) : 0u;
+        }
+        __syncthreads();
+        bound = winner ? winner : 0;   // 0: table exhausted (k >= D), the remaining slots are not used (ntop)
+        if (!bound) bound = 0;
+    }
+}
+
+int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta) {
+    hipLaunchKernelGGL(k_sparse_meta, dim3(1), dim3(1024), 0, ctx->stream, keys, counts, (int)D, keys32, meta);
+    SP_HIP(hipGetLastError());
+    return SP_OK;
 }
 
 int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,

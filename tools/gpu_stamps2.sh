@@ -17,15 +17,23 @@ dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=L, ta
 splits = list(sp.all_splits(names))
 lib = dev.ctx._lib
 lib.sp_debug_spk_stamps.argtypes = [C.POINTER(C.c_longlong)]
+import torch
 for k in (5, 4, 3):
     sub = [s for s in splits if min(len(s[0]), len(s[1])) == k]
     taxa_arr, a_arr = batch.encode_splits(sub, dev, n)
-    for rep in range(2):
-        batch.score_encoded(dev, taxa_arr, a_arr, 3)
-    out = (C.c_longlong * 64)()
-    lib.sp_debug_spk_stamps(out)
-    o = np.array(out[:], dtype=np.int64)
-    print(f"k={k}: stage+bitmaps={o[1]-o[0]} CSC={o[2]-o[1]} CSR={o[3]-o[2]} start={o[4]-o[3]} Vinit/G={o[5]-o[4]} orth0={o[7]-o[6]} "
-          f"spmm1={o[8]-o[7]} (light {o[20]-o[7]}) gram+orth1={o[21]-o[8] if False else 0} spmm2..={o[9]-o[8]} gram2={o[40]-o[9]} orth2={o[41]-o[40]} "
-          f"rest={o[11]-o[41]} total={o[11]-o[0]}")
+    nrep = 8
+    sc = torch.zeros(nrep * len(sub), dtype=torch.float64, device="cuda")
+    st = torch.zeros(nrep * len(sub), dtype=torch.int32, device="cuda")
+    for blk in (0, nrep * len(sub) - 1):
+        lib.sp_debug_spk_stamp_block(blk)
+        for rep in range(2):
+            batch.score_encoded_multi_async([dev] * nrep, taxa_arr, a_arr, sc.data_ptr(), st.data_ptr())
+            torch.cuda.synchronize()
+        out = (C.c_longlong * 64)()
+        lib.sp_debug_spk_stamps(out)
+        o = np.array(out[:], dtype=np.int64)
+        print(f"k={k} block {blk}: stage+bitmaps={o[1]-o[0]} CSC={o[2]-o[1]} CSR={o[3]-o[2]} start={o[4]-o[3]} Vinit/G={o[5]-o[4]} orth0={o[7]-o[6]} "
+              f"spmm1={o[8]-o[7]} spmm2+go={o[9]-o[8]} gram2={o[40]-o[9]} orth2={o[41]-o[40]} "
+              f"rest={o[11]-o[41]} total={o[11]-o[0]}")
+        print(f"     CSC build: rank+passA={o[50]-o[1]} prefix={o[51]-o[50]} buckets+perm={o[52]-o[51]} scan+ptr={o[53]-o[52]} passB={o[2]-o[53]} | spmm1: wave={o[30]-o[7]} row={o[20]-o[30]} team={o[8]-o[20]}")
 PY
