@@ -31,7 +31,9 @@
 #ifndef SPK_TEAM_MAX
 #define SPK_TEAM_MAX 32     // a column / row with more entries than this is shared by the 4 teams of a 16-lane row
 #endif
-#define SPK_ROW_MAX 256     // ... and with more than this by the 16 teams of a wave
+#ifndef SPK_ROW_MAX
+#define SPK_ROW_MAX 64      // ... and with more than this by the 64 lanes of a wave
+#endif
 #define SPK_MAXIT 40
 #define SPK_LDS_BYTES 163840
 #define SPK_SMALL_R 64
@@ -216,17 +218,20 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
     constexpr u32 FMASK = (1u << BITS) - 1;
     const int stride = (nmajor + PER - 1) / PER;       // words per wave row
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int chunk = ((D + SPK_WAVES * 64 - 1) / (SPK_WAVES * 64)) * 64;
+    // entries per lane: ODD, so that the 64 lanes of a load (stride q words) spread over all LDS banks - an even q puts
+    // them on 2 .. 16 banks (q = 16: a 32-way conflict on every load of both passes)
+    const int q = ((D + SPK_WAVES * 64 - 1) / (SPK_WAVES * 64)) | 1;
+    const int chunk = q * 64;
     const int lo = min(D, w * chunk), hi = min(D, lo + chunk);
     for (int i = threadIdx.x; i < SPK_WAVES * stride; i += SPK_THREADS) cw[i] = 0;
     if (threadIdx.x < 68) sh.bucket[threadIdx.x] = 0;
     __syncthreads();
+    BSTAMP(5);
     u32* myrow = cw + w * stride;
     // lane l walks the contiguous sub-chunk [lo + l*q, lo + (l+1)*q): consecutive table entries share their leading
     // digits (hence often their row or column), so giving them to ONE lane keeps the 64 lanes of an atomic on
     // different counters (measured: 64-way same-word conflicts otherwise)
     // (plain loops: the kernel is VALU-issue bound here, a batched / predicated form measured slower)
-    const int q = chunk / 64;
     for (int t = 0; t < q; ++t) {                         // pass A: per-chunk group sizes
         const int i = lo + lane * q + t;
         if (i >= hi) continue;
@@ -360,7 +365,7 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
         const u32 old = atomicAdd(&myrow[mj / PER], 1u << (BITS * (mj % PER)));
         const int pos = ptr[mj] + (int)((old >> (BITS * (mj % PER))) & FMASK);
         ent[pos] = (u32)mn | ((u32)cnt[i] << 16);
-        if (!PERMUTE && end_of) end_of[pos] = ptr[mj + 1];
+        if (!PERMUTE && end_of) end_of[pos] = (unsigned short)mj;   // small path: group of every position
     }
     __syncthreads();
 }
@@ -383,7 +388,7 @@ __device__ __forceinline__ double spk_dpp(double x) {
     return __hiloint2double(hi, lo);
 }
 #ifndef SPK_UW
-#define SPK_UW 8            // entries per batch of the wide classes
+#define SPK_UW 4            // entries per batch of the wide classes
 #endif
 #define SPK_DPP_QUAD_XOR1 0xB1   // quad_perm [1,0,3,2]
 #define SPK_DPP_QUAD_XOR2 0x4E   // quad_perm [2,3,0,1]
@@ -432,7 +437,10 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
     for (int idx = w; idx < nwave; idx += SPK_WAVES) {                      // one wave per group
         const int p0 = ptrp[idx], p1 = ptrp[idx + 1], m = perm[idx];
         double a[4] = {0, 0, 0, 0};
-        spk_lane_sum<SPK_UW, true>(ent, p0 + lane, 64, p1, in, pb, a);
+        if (p1 - p0 <= 128)   // (uniform: one group per wave)
+            spk_lane_sum<2, true>(ent, p0 + lane, 64, p1, in, pb, a);
+        else
+            spk_lane_sum<4, true>(ent, p0 + lane, 64, p1, in, pb, a);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             a[c] += spk_dpp<SPK_DPP_QUAD_XOR1>(a[c]);
@@ -463,6 +471,9 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
             if (t == 15) spk_store4(out + m * out_pitch, a);
         }
     }
+#ifdef SPK_STAMPS
+    if (stamp_at >= 0) SSTAMP(stamp_at + 12);
+#endif
     {                                                                       // one quad per group (9 .. 32 entries)
         const int quad = threadIdx.x >> 2, t = threadIdx.x & 3;
         const int q0 = nwave + nrow;
@@ -790,32 +801,66 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     double* V = reinterpret_cast<double*>(carve((size_t)Rp * SPK_VP * 8));
     double* Wb = reinterpret_cast<double*>(smem + off);   // large: W (Kc x 4);  small: G (R x R)
     if (small) {
+        // exact Gram G = C C^T: all pairs of entries inside every column, accumulated with integer LDS atomics (exact,
+        // order independent).  One thread per CSC position i of a column of n entries takes the pairs (i, i + d mod n),
+        // d = 0 .. n/2 - every unordered pair once, every thread of a column the same number of steps (walking the
+        // rest of the column instead leaves half of the lanes of a long column idle).  32-bit atomics when every entry
+        // fits (G[r][r'] <= trace), 64-bit otherwise.
+        const bool g32 = meta->trace < (1ull << 32);
+        u32* G32 = reinterpret_cast<u32*>(Wb);
         unsigned long long* G64 = reinterpret_cast<unsigned long long*>(Wb);
-        for (int i = threadIdx.x; i < R * R; i += SPK_THREADS) G64[i] = 0;
+        const int gwords = g32 ? R * R : 2 * R * R;
+        for (int i = threadIdx.x; i < gwords; i += SPK_THREADS) G32[i] = 0;
         __syncthreads();
-        // exact Gram: all pairs (a <= b) inside every column.  One thread per CSC position a, walking the rest of its
-        // column (<= R <= 64 steps); consecutive positions belong to consecutive threads, so a long column is spread
-        // over many lanes.  u64 LDS atomics: integer, hence exact and order independent.
+        SSTAMP(44);
         for (int a = threadIdx.x; a < Di; a += SPK_THREADS) {
+            const int col = colof[a];
+            const int p0 = csc_ptr[col], n = csc_ptr[col + 1] - p0, i = a - p0, half = n >> 1;
             const u32 va = csc_ent[a];
-            const unsigned long long ca = va >> 16;
+            const u32 ca = va >> 16;
             const int ra = va & 0xFFFF;
-            const int p1 = colof[a];   // end of the column of position a
-            for (int b = a; b < p1; ++b) {
-                const u32 vb = csc_ent[b];
-                const int rb = vb & 0xFFFF;   // entries of a column are in table order, not row order
-                atomicAdd(&G64[min(ra, rb) * R + max(ra, rb)], ca * (unsigned long long)(vb >> 16));
+            const int steps = ((n & 1) == 0 && i >= half) ? half : half + 1;   // even n: the pair (i, i + n/2) belongs to i < n/2
+            for (int d0 = 0; d0 < steps; d0 += 4) {   // 4 partners per step: the loads, then the atomics, back to back
+                u32 vb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int j = i + d0 + u;
+                    j = j >= n ? j - n : j;
+                    j = j >= n ? j - n : j;   // (d0 + u may overshoot by up to 3 past a wrap)
+                    vb[u] = csc_ent[p0 + j];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (d0 + u >= steps) break;
+                    const int rb = vb[u] & 0xFFFF;
+                    const int cell = min(ra, rb) * R + max(ra, rb);
+                    if (g32)
+                        atomicAdd(&G32[cell], ca * (vb[u] >> 16));
+                    else
+                        atomicAdd(&G64[cell], (unsigned long long)ca * (unsigned long long)(vb[u] >> 16));
+                }
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < R * R; i += SPK_THREADS) {  // exact integer -> fp64, in place
-            const int r = i / R, c = i % R;
-            if (r > c) continue;
-            G64[r * R + c] = (unsigned long long)__double_as_longlong((double)G64[r * R + c]);
+        SSTAMP(45);
+        {   // exact integer -> fp64 (upper triangle), through registers: the two layouts overlap
+            double gv[(SPK_SMALL_R * SPK_SMALL_R + SPK_THREADS - 1) / SPK_THREADS];
+#pragma unroll
+            for (int k = 0; k < (SPK_SMALL_R * SPK_SMALL_R + SPK_THREADS - 1) / SPK_THREADS; ++k) {
+                const int i = k * SPK_THREADS + (int)threadIdx.x;
+                gv[k] = i < R * R ? (g32 ? (double)G32[i] : (double)G64[i]) : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < (SPK_SMALL_R * SPK_SMALL_R + SPK_THREADS - 1) / SPK_THREADS; ++k) {
+                const int i = k * SPK_THREADS + (int)threadIdx.x;
+                if (i < R * R) Wb[i] = gv[k];
+            }
         }
         __syncthreads();
+        const float rinv = 1.0f / (float)R;   // i / R for i < 4096, R <= 64: (i + 0.5) / R is >= 1/128 away from an integer
         for (int i = threadIdx.x; i < R * R; i += SPK_THREADS) {
-            const int r = i / R, c = i % R;
+            const int r = (int)(((float)i + 0.5f) * rinv), c = i - r * R;
             if (r > c) Wb[r * R + c] = Wb[c * R + r];
         }
         if (threadIdx.x < 64) {   // rows in use = non-zero diagonal entries (R <= 64)

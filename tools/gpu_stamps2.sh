@@ -35,5 +35,5 @@ for k in (5, 4, 3):
         print(f"k={k} block {blk}: stage+bitmaps={o[1]-o[0]} CSC={o[2]-o[1]} CSR={o[3]-o[2]} start={o[4]-o[3]} Vinit/G={o[5]-o[4]} orth0={o[7]-o[6]} "
               f"spmm1={o[8]-o[7]} spmm2+go={o[9]-o[8]} gram2={o[40]-o[9]} orth2={o[41]-o[40]} "
               f"rest={o[11]-o[41]} total={o[11]-o[0]}")
-        print(f"     CSC build: rank+passA={o[50]-o[1]} prefix={o[51]-o[50]} buckets+perm={o[52]-o[51]} scan+ptr={o[53]-o[52]} passB={o[2]-o[53]} | spmm1: wave={o[30]-o[7]} row={o[20]-o[30]} team={o[8]-o[20]}")
+        print(f"     CSC build: pre={o[55]-o[1]} passA={o[50]-o[55]} prefix={o[51]-o[50]} buckets+perm={o[52]-o[51]} scan+ptr={o[53]-o[52]} passB={o[2]-o[53]} | spmm1: wave={o[30]-o[7]} row={o[32]-o[30]} quad={o[20]-o[32]} lane={o[8]-o[20]} | G: zero={o[44]-o[4]} pairs={o[45]-o[44]} conv={o[5]-o[45]}")
 PY
