@@ -509,17 +509,27 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
     __syncthreads();
 }
 
-__device__ __forceinline__ bool spk_converged(double s4, int it, double& prev_sum, double& prev_delta) {
+// Stop when the Ritz sum has settled.  s_1, s_2, ... increase monotonically towards the limit with an (eventually)
+// constant error ratio rho = (sigma_5 / sigma_4)^2, so delta_k = s_k - s_(k-1) ~ the error of s_(k-1) and the error left
+// after s_k is the geometric tail delta_k rho / (1 - rho).  rho is taken as the LARGER of the last two measured ratios
+// delta_k / delta_(k-1): early ratios are optimistic (the start block's stray components die faster than the
+// asymptotic rate - with a single ratio 20 % of the splits stopped one product early with 3e-11 left in the score).
+// Tolerance: the score is sqrt(1 - s / trace); 1e-13 relative in s is < 1e-11 in any score >= 0.005.
+__device__ __forceinline__ bool spk_converged(double s4, int k, double& prev_sum, double& prev_delta, double& prev_ratio) {
     bool conv = false;
     const double delta = fabs(s4 - prev_sum);
-    if (it >= 2) {
-        double ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
+    double ratio = 1.0;
+    if (k >= 3) {   // delta_2 is the first real difference, so ratios exist from k = 3 on
+        ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
         ratio = fmin(fmax(ratio, 0.0), 0.9999);
-        const double tail = delta * ratio / (1.0 - ratio);
-        // (the Ritz sum itself carries ~2e-15 of rounding noise: a change below 2e-14 is at the floor)
-        // tolerance: the score is sqrt(1 - s4 / trace); 1e-13 relative in s4 is < 1e-11 in any score >= 0.005
-        if (it >= 3 && (delta <= 2e-14 * s4 || tail <= 1e-13 * s4)) conv = true;
+        if (k >= 4) {
+            const double r = fmax(ratio, prev_ratio);
+            const double tail = delta * r / (1.0 - r);
+            // (the Ritz sum itself carries ~2e-15 of rounding noise: a change below 2e-14 is at the floor)
+            if (delta <= 2e-14 * s4 || tail <= 1e-13 * s4) conv = true;
+        }
     }
+    prev_ratio = ratio;
     prev_delta = delta;
     prev_sum = s4;
     return conv;
@@ -760,23 +770,27 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     // ---- start block: unit vectors on the rows of the 4 largest counts (distinct rows) ----------------------------
     // (the dominant singular vectors of a count flattening sit on the few very frequent patterns); chosen by four
     // rounds of a block arg-max over (count, index), deterministic tie-break.
-    int top_row[SPK_NB];
+    int top_row[SPK_NB], top_cnt[SPK_NB];
     {
         // rows of the SPK_NTOP most frequent patterns (found once per alignment, k_sparse_meta); the first 4 distinct
         // rows among them, missing ones (fewer than 4 distinct) filled with the lowest unused row ids.  Any 4 strong
         // distinct rows make a good start block; the hash noise below covers the directions they miss.
-        int* rows_out = reinterpret_cast<int*>(sh.S);
+        int* rows_out = reinterpret_cast<int*>(sh.S);   // [0..3] rows, [4..7] largest count of each
         if (threadIdx.x < 64) {
             const int lane = threadIdx.x;
             const int ntop = (int)meta->ntop;
-            int myrow = -1;
-            if (lane < ntop) myrow = (int)(pc[meta->top[lane]] >> 16);
+            int myrow = -1, mycnt = 1;
+            if (lane < ntop) {
+                myrow = (int)(pc[meta->top[lane]] >> 16);
+                mycnt = (int)cnt[meta->top[lane]];
+            }
             u64 active = __ballot(myrow >= 0);
-            int got = 0, chosen[SPK_NB] = {-1, -1, -1, -1};
+            int got = 0, chosen[SPK_NB] = {-1, -1, -1, -1}, ccnt[SPK_NB] = {1, 1, 1, 1};
             for (int k = 0; k < SPK_NB && active; ++k) {
                 const int first = __builtin_ctzll(active);
                 const int r = __shfl(myrow, first, 64);
                 chosen[k] = r;
+                ccnt[k] = __shfl(mycnt, first, 64);
                 ++got;
                 active &= ~__ballot(myrow == r);
             }
@@ -787,12 +801,18 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             }
             if (lane == 0) {
 #pragma unroll
-                for (int k = 0; k < SPK_NB; ++k) rows_out[k] = chosen[k];
+                for (int k = 0; k < SPK_NB; ++k) {
+                    rows_out[k] = chosen[k];
+                    rows_out[SPK_NB + k] = ccnt[k];
+                }
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < SPK_NB; ++k) top_row[k] = rows_out[k];
+        for (int k = 0; k < SPK_NB; ++k) {
+            top_row[k] = rows_out[k];
+            top_cnt[k] = rows_out[SPK_NB + k];
+        }
         __syncthreads();
     }
     SSTAMP(4);
@@ -870,25 +890,57 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         __syncthreads();
         if (degenerate(sh.used_r, 5)) return;
     }
-    for (int e = threadIdx.x; e < Rp * SPK_VP; e += SPK_THREADS) V[e] = 0.0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < R; i += SPK_THREADS) {
-#pragma unroll
-        for (int k = 0; k < SPK_NB; ++k) V[i * SPK_VP + k] = 0.02 * spk_hash(i, k) + (top_row[k] == i ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    SSTAMP(5);
-    SSTAMP(6);
     // ---- iteration: alternate half products, one Ritz sum per half product -------------------------------------
     //   h odd :  W = C^T V  (V orthonormal)  ->  trace(W^T W) = trace(V^T C C^T V) = Ritz sum of C C^T on span(V)
     //   h even:  Y = C W    (W orthonormal)  ->  trace(Y^T Y) = Ritz sum of C^T C on span(W)
     // Both are Rayleigh-Ritz sums of the same four squared singular values, each better than the last by
     // (sigma_5 / sigma_4)^2; the block is re-orthonormalised by one Cholesky-QR step on the Gram matrix that has just
     // been formed (no eigen-decomposition, no polar factor).  Small row side: dense G instead of the two sparse halves.
-    double prev_sum = 0, prev_delta = 0, top4 = 0;
+    // Start: unit vectors on the 4 rows picked above.  General path: C^T of unit vectors is just those 4 rows of C, so
+    // the first half product is a scatter of 4 CSR rows into W (plus 1 % hash noise for the directions they miss).
+    double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0;
     int it = 0, conv = 0;
-    spk_gram(V, R, SPK_VP, sh);
-    spk_orth(V, R, SPK_VP, sh);
+    if (small) {
+        for (int e = threadIdx.x; e < Rp * SPK_VP; e += SPK_THREADS) V[e] = 0.0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < R; i += SPK_THREADS) {
+#pragma unroll
+            for (int k = 0; k < SPK_NB; ++k) V[i * SPK_VP + k] = 0.02 * spk_hash(i, k) + (top_row[k] == i ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        spk_gram(V, R, SPK_VP, sh);
+        spk_orth(V, R, SPK_VP, sh);
+    } else {
+        const double nscale = 0.01 * spk_rsqrt((double)Kc / 3.0);
+        double amp[SPK_NB];
+#pragma unroll
+        for (int k = 0; k < SPK_NB; ++k) amp[k] = nscale * (double)top_cnt[k];
+        for (int c = threadIdx.x; c < Kc; c += SPK_THREADS) {
+#pragma unroll
+            for (int k = 0; k < SPK_NB; ++k) Wb[c * wp + k] = amp[k] * spk_hash(c, k);
+        }
+        for (int idx = threadIdx.x; idx < R; idx += SPK_THREADS) {   // where do the 4 rows sit in the CSR layout?
+            const int m = perm_r[idx];
+#pragma unroll
+            for (int k = 0; k < SPK_NB; ++k)
+                if (m == top_row[k]) sh.bucket[k] = (u32)idx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SPK_NB; ++k) {
+            const int idx = (int)sh.bucket[k];
+            const int p0 = desc_r[idx], p1 = desc_r[idx + 1];
+            for (int e = p0 + (int)threadIdx.x; e < p1; e += SPK_THREADS) {
+                const u32 v = csr_ent[e];
+                Wb[(v & 0xFFFFu) * wp + k] = (double)(v >> 16);
+            }
+        }
+        __syncthreads();
+        spk_gram(Wb, Kc, wp, sh);
+        spk_orth(Wb, Kc, wp, sh);
+    }
+    SSTAMP(5);
+    SSTAMP(6);
     if (small) {
         for (it = 1; it <= SPK_MAXIT; ++it) {
             // Y = G V densely (R <= 64): thread (row, j); Ritz sum = trace(V^T Y); Y staged in registers, written over V
@@ -905,7 +957,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = part;
             __syncthreads();
             top4 = ((sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3])) + ((sh.red[4] + sh.red[5]) + (sh.red[6] + sh.red[7]));
-            if (spk_converged(top4, it, prev_sum, prev_delta)) {
+            if (spk_converged(top4, it, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
                 break;
             }
@@ -914,21 +966,22 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         }
     } else {
         SSTAMP(7);
-        for (it = 1; it <= 2 * SPK_MAXIT; ++it) {
+        for (it = 2; it <= 2 * SPK_MAXIT; ++it) {
             double* X;
             int rows, pitch;
             if (it & 1) {
-                spk_spmm(desc_c, csc_ent, Kc, perm_c, sh.nw_c, sh.nr_c, sh.nq_c, V, SPK_VP, Wb, wp, it == 1 ? 20 : -1);   // W = C^T V
+                spk_spmm(desc_c, csc_ent, Kc, perm_c, sh.nw_c, sh.nr_c, sh.nq_c, V, SPK_VP, Wb, wp, it == 3 ? 20 : -1);   // W = C^T V
                 X = Wb; rows = Kc; pitch = wp;
             } else {
                 spk_spmm(desc_r, csr_ent, R, perm_r, sh.nw_r, sh.nr_r, sh.nq_r, Wb, wp, V, SPK_VP, it == 2 ? 21 : -1);    // Y = C W
                 X = V; rows = R; pitch = SPK_VP;
             }
-            if (it <= 2) SSTAMP(7 + it);
+            if (it == 2) SSTAMP(9);
+            if (it == 3) SSTAMP(8);
             spk_gram(X, rows, pitch, sh);
             if (it == 2) SSTAMP(40);
             top4 = (sh.S[0] + sh.S[5]) + (sh.S[10] + sh.S[15]);
-            if (spk_converged(top4, it, prev_sum, prev_delta)) {
+            if (spk_converged(top4, it - 1, prev_sum, prev_delta, prev_ratio)) {   // (the first real Ritz sum is that of half product 2)
                 conv = 1;
                 break;
             }

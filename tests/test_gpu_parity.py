@@ -233,7 +233,7 @@ def test_histogram_from_sequences(sp):
     assert dict(dev3.items()) == {"ATCG": 2 / 5, "CGAT": 1 / 5, "GATC": 1 / 5, "TCGA": 1 / 5}
 
 
-PROP_TOL = 2e-11   # self-consistency of two converged runs (parity bar vs the oracle stays SCORE_TOL = 1e-10)
+PROP_TOL = 5e-12   # self-consistency of two converged runs (parity bar vs the oracle stays SCORE_TOL = 1e-10)
 
 
 def test_full_size_properties(sp):
@@ -251,7 +251,7 @@ def test_full_size_properties(sp):
     s2 = sp.score_splits(dev, splits)
     assert np.array_equal(s1, s2)
     # (2) side swap: score(A|B) == score(B|A) (transpose has the same singular values)
-    # (the iteration stops at a relative tail estimate of 1e-13 in the Ritz sum: ~5e-12 in a score, see sparse.hip)
+    # (the iteration stops at a relative tail estimate of 1e-13 in the Ritz sum: < 1e-12 in a score, see sparse.hip)
     swapped = [(b, a) for a, b in splits]
     s3 = sp.score_splits(dev, swapped)
     assert np.abs(s1 - s3).max() <= PROP_TOL
