@@ -3,14 +3,12 @@
 // Second half of the replacement for splitp/phylogenetics.py:280-300 (__dense_split_score):
 //     score = (1 - sum(sigma[:4]^2) / sum(sigma^2)) ** 0.5
 // With G = C C^T:  sum(sigma^2) = trace(G) (exact for integer counts) and sigma[:4]^2 are the four
-// largest eigenvalues of G.  They are found by block orthogonal (subspace) iteration with a
-// Rayleigh-Ritz step, block width 16 (the N of v_mfma_f64_16x16x4_f64):
-//     Y = G V            fp64 MFMA, G streamed from L2/HBM (symmetric: read as columns, 128-B segments),
-//                        V (R x 16) resident in LDS, Y accumulators in registers
-//     H = V^T Y          fp64 MFMA straight from the Y accumulators (C/D registers are B operands)
-//     H = Q Theta Q^T    16 x 16 parallel-order Jacobi by one wave
-//     Z = Y Q            (= G times the Ritz vectors; columns nearly orthogonal)
-//     V = orth(Z)        Cholesky-QR twice (Gram by MFMA, 16 x 16 Cholesky, row-wise solve)
+// largest eigenvalues of G.  They are found by block orthogonal (subspace) iteration, block width 16
+// (the N of v_mfma_f64_16x16x4_f64), in the G^2 form (eig_small.h):
+//     Y = G V            fp64 MFMA, G streamed from L2/HBM (symmetric: read as columns, 128-B segments)
+//     S = Y^T Y          = V^T G^2 V, 16 x 16 Gram by MFMA
+//     S = P D P^T        one-wave 2 x 2-block Jacobi;  Ritz values of G = sqrt(D)
+//     V = Y P D^-1/2     next orthonormal block (+ one Newton-Schulz polish step)
 // until the sum of the four largest Ritz values stops moving (geometric-tail estimate below
 // 1e-14 relative).  Phylogenetic flattenings have lambda_17 / lambda_4 < 1e-3, so this takes 3-4
 // products.
@@ -18,7 +16,7 @@
 // Launch structure: the product Y = G V is the only heavy step and G (up to 1024^2 doubles per
 // split) has to stream from HBM once per product, so it runs as its own kernel over ALL splits
 // with one workgroup per 64 rows (k_eig_gv: the whole chip pulls on HBM), while the small per-split
-// algebra (H, Jacobi, Cholesky-QR on an R x 16 block held in LDS) runs one workgroup per split
+// algebra (Gram of Y, Jacobi, block update on an R x 16 block held in LDS) runs one workgroup per split
 // (k_eig_init, k_eig_rr).  EIG_NFAST product rounds are enqueued without host synchronisation;
 // splits that have converged turn their workgroups into no-ops.  k_eig_finish then takes any
 // split that is still not converged (arbitrary matrices without a spectral gap) to convergence

@@ -441,6 +441,7 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
             spk_lane_sum<2, true>(ent, p0 + lane, 64, p1, in, pb, a);
         else
             spk_lane_sum<4, true>(ent, p0 + lane, 64, p1, in, pb, a);
+#ifndef SPK_NOREDUCE
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             a[c] += spk_dpp<SPK_DPP_QUAD_XOR1>(a[c]);
@@ -450,6 +451,7 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
             a[c] += __shfl_xor(a[c], 16, 64);
             a[c] += __shfl_xor(a[c], 32, 64);
         }
+#endif
         if (lane == 63) spk_store4(out + m * out_pitch, a);
     }
 #ifdef SPK_STAMPS
@@ -461,6 +463,7 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
             const int p0 = ptrp[idx], p1 = ptrp[idx + 1], m = perm[idx];
             double a[4] = {0, 0, 0, 0};
             spk_lane_sum<SPK_UW, true>(ent, p0 + t, 16, p1, in, pb, a);
+#ifndef SPK_NOREDUCE
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 a[c] += spk_dpp<SPK_DPP_QUAD_XOR1>(a[c]);
@@ -468,6 +471,7 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
                 a[c] += spk_dpp<SPK_DPP_ROW_SHR4>(a[c]);
                 a[c] += spk_dpp<SPK_DPP_ROW_SHR8>(a[c]);
             }
+#endif
             if (t == 15) spk_store4(out + m * out_pitch, a);
         }
     }
