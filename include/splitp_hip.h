@@ -87,7 +87,8 @@ int sp_ctx_set_gram_mode(sp_ctx* ctx, int mode);
 #define SP_PHASE_HIST 6     /* site-pattern histogram (alignment columns -> pattern table) */
 #define SP_PHASE_DENSE 7    /* full 4^a x 4^b dense scatter (sp_flatten_dense)             */
 #define SP_PHASE_SPARSE 8   /* sparse route: one workgroup per split, everything in LDS     */
-#define SP_N_PHASES 9
+#define SP_PHASE_DIVERGENCE 9 /* mutual-information score (marginals + sum over the patterns)  */
+#define SP_N_PHASES 10
 int sp_ctx_enable_timing(sp_ctx* ctx, int on);
 int sp_ctx_reset_timing(sp_ctx* ctx);
 int sp_ctx_phase_times(sp_ctx* ctx, double* ms /*[SP_N_PHASES]*/, int64_t* launches /*[SP_N_PHASES]*/);
@@ -153,6 +154,10 @@ int sp_score_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, int64_t cols
 int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* ci, const double* v, int64_t nnz,
                      int64_t rows, int64_t cols, double* score);
 
+/* phylogenetics.py:364-373 flattening_rank_1_approximation_divergence(matrix): sum over the non-zero cells of
+ * f * log(f / (column sum * row sum)), with the marginals of phylogenetics.py:332-341.  Dense row-major host matrix. */
+int sp_divergence_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, int64_t cols, int64_t ld, double* out);
+
 /* Batched: flattening + split_score for many splits of one alignment, everything on the
  * device (the README loop, README.md:36-41, as one call).
  *   split_taxa[n_splits * n]  for split s: order_a (a entries) then order_b (n - a entries)
@@ -160,7 +165,8 @@ int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* ci, const do
  *   method                    SP_METHOD_FLATTENING (auto: the sparse in-LDS route when the table holds counts
  *                             < 65536, the dense MFMA route otherwise or for splits the sparse kernel hands
  *                             back), SP_METHOD_FLATTENING_DENSE, SP_METHOD_FLATTENING_SPARSE (error if a split
- *                             cannot be handled there) or SP_METHOD_SUBFLATTENING
+ *                             cannot be handled there), SP_METHOD_SUBFLATTENING or SP_METHOD_MUTUAL_INFORMATION
+ *                             (flattening + flattening_rank_1_approximation_divergence instead of split_score)
  *   scores_host               may be NULL; if given, the stream is synchronised
  *   scores_dev                may be NULL; device buffer of n_splits doubles
  *   status_host               may be NULL; per-split flags (bit 0: eigen iteration hit its cap; bits 8..: number
@@ -169,6 +175,8 @@ int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* ci, const do
 #define SP_METHOD_SUBFLATTENING 1
 #define SP_METHOD_FLATTENING_DENSE 2
 #define SP_METHOD_FLATTENING_SPARSE 3
+#define SP_METHOD_MUTUAL_INFORMATION 4 /* KL divergence of the flattening from the product of its marginals
+                                        * (phylogenetics.py:364-373, erickson_SVD's Method.mutual_information) */
 int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
                     int method, double* scores_host, void* scores_dev, int32_t* status_host);
 

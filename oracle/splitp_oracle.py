@@ -229,6 +229,38 @@ def split_score(matrix, return_singular_values=False, force_frob_norm_on_dense=F
     return dense_split_score(matrix)
 
 
+def rank1_marginals(flattening):
+    """reference: splitp/phylogenetics.py:332-341 with return_vectors=True, dont_compute_matrix=True:
+    r = builtin sum over the rows (= column sums), c = builtin sum over the transposed rows (= row sums)."""
+    r = np.array([sum(flattening)])
+    c = np.array([sum(flattening.T)])
+    return r.tolist()[0], c.tolist()[0]
+
+
+def rank1_divergence(flattening):
+    """reference: splitp/phylogenetics.py:364-373 (flattening_rank_1_approximation_divergence): Python loops over
+    every cell, rows outer, columns inner, non-zero cells add f * log(f / (r[y] * c[x]))."""
+    r, c = rank1_marginals(flattening)
+    total = 0
+    for x in range(len(c)):
+        for y in range(len(r)):
+            if flattening[x, y] != 0:
+                total += flattening[x, y] * np.log(flattening[x, y] / (r[y] * c[x]))
+    return total
+
+
+def rank1_divergence_packed(keys, vals, n_taxa, order_a, order_b):
+    """Vectorised form on a packed table (a cell of the flattening is one pattern): same value up to summation order."""
+    rows, cols = flat_indices(keys, n_taxa, order_a, order_b)
+    vals = np.asarray(vals, dtype=np.float64)
+    _, ri = np.unique(rows, return_inverse=True)
+    _, ci = np.unique(cols, return_inverse=True)
+    rs = np.bincount(ri, weights=vals)
+    cs = np.bincount(ci, weights=vals)
+    nz = vals != 0
+    return float(np.sum(vals[nz] * np.log(vals[nz] / (rs[ri[nz]] * cs[ci[nz]]))))
+
+
 def all_splits(taxa, trivial=False, size=None):
     """Enumeration order of reference splitp/splits.py:27-59 (without randomise / string_format):
     sizes ascending from 2 (1 if trivial) to floor(n/2); combinations order inside a size;

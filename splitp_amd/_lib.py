@@ -16,8 +16,9 @@ SP_METHOD_FLATTENING = 0
 SP_METHOD_SUBFLATTENING = 1
 SP_METHOD_FLATTENING_DENSE = 2
 SP_METHOD_FLATTENING_SPARSE = 3
-SP_N_PHASES = 9
-PHASE_NAMES = ("reindex", "scatter", "gram", "eigen", "moment", "subscore", "hist", "dense", "sparse")
+SP_METHOD_MUTUAL_INFORMATION = 4
+SP_N_PHASES = 10
+PHASE_NAMES = ("reindex", "scatter", "gram", "eigen", "moment", "subscore", "hist", "dense", "sparse", "divergence")
 
 # every symbol include/splitp_hip.h declares
 SYMBOLS = (
@@ -28,7 +29,7 @@ SYMBOLS = (
     "sp_alignment_destroy", "sp_alignment_info", "sp_alignment_fetch",
     "sp_flatten_indices", "sp_flatten_reduced_prepare", "sp_flatten_reduced_fetch", "sp_flatten_dense_counts",
     "sp_subflatten", "sp_moment_matrix",
-    "sp_score_matrix_f64", "sp_score_coo_f64", "sp_score_splits", "sp_score_splits_async",
+    "sp_score_matrix_f64", "sp_score_coo_f64", "sp_divergence_matrix_f64", "sp_score_splits", "sp_score_splits_async",
     "sp_score_splits_multi_async",
 )
 
@@ -90,6 +91,7 @@ def load():
         "sp_moment_matrix": [vp, P(i64), P(dbl)],
         "sp_score_matrix_f64": [vp, P(dbl), i64, i64, i64, P(dbl)],
         "sp_score_coo_f64": [vp, P(i64), P(i64), P(dbl), i64, i64, i64, P(dbl)],
+        "sp_divergence_matrix_f64": [vp, P(dbl), i64, i64, i64, P(dbl)],
         "sp_score_splits": [vp, P(C.c_int32), P(C.c_int32), i64, i32, P(dbl), vp, P(C.c_int32)],
         "sp_score_splits_async": [vp, P(C.c_int32), P(C.c_int32), i64, i32, vp, vp],
         "sp_score_splits_multi_async": [P(vp), i32, P(C.c_int32), P(C.c_int32), i64, vp, vp],

@@ -61,7 +61,9 @@ def _method_code(method, route="auto"):
                 "sparse": _lib.SP_METHOD_FLATTENING_SPARSE}[route]
     if name in ("subflattening", Method.subflattening):
         return _lib.SP_METHOD_SUBFLATTENING
-    raise ValueError(f"unsupported method {method!r} (flattening or subflattening)")
+    if name in ("mutual_information", Method.mutual_information):
+        return _lib.SP_METHOD_MUTUAL_INFORMATION
+    raise ValueError(f"unsupported method {method!r} (flattening, subflattening or mutual_information)")
 
 
 def score_encoded(al, split_taxa, split_a, method_code, scores_dev_ptr=None, want_host=True):

@@ -694,6 +694,26 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
 
 int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S);  // subflat.hip
 
+// Mutual-information route (divergence.hip): reindex (compact coordinates per split), marginals, sum.
+static int run_divergence_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S) {
+    sp_ctx* ctx = al->ctx;
+    const int64_t D = al->D;
+    if (ctx->cache) ctx->cache->valid = false;   // the plan pools are overwritten
+    Plan plan;
+    SP_CHECK(plan_splits(al->n_taxa, D, split_taxa, split_a, S, false, false, false, plan));
+    SP_CHECK(upload_plan(ctx, plan, D));
+    SP_CHECK(ctx->scores.ensure((size_t)S * 8));
+    SP_CHECK(ctx->status.ensure((size_t)S * 4));
+    SP_CHECK(ctx->misc.ensure((size_t)S * 2 * (size_t)D * 8));
+    SP_CHECK(launch_reindex(ctx, al->keys.as<u64>(), D, al->n_taxa, ctx->splits.as<SplitDev>(), plan.splits, bm_ptr(ctx),
+                            pf_ptr(ctx, plan), ctx->dims.as<int2>(), rr_ptr(ctx), cc_ptr(ctx, S, D)));
+    SP_CHECK(launch_divergence(ctx, al->exact, D, S, rr_ptr(ctx), cc_ptr(ctx, S, D), al->counts.as<u32>(),
+                               al->weights.as<double>(), (double)al->N, ctx->misc.as<unsigned long long>(),
+                               ctx->scores.as<double>()));
+    SP_HIP(hipMemsetAsync(ctx->status.p, 0, (size_t)S * 4, ctx->stream));
+    return SP_OK;
+}
+
 extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
                                int method, double* scores_host, void* scores_dev, int32_t* status_host) {
     SP_REQUIRE(al && split_taxa && split_a, SP_EINVAL, "NULL argument");
@@ -737,6 +757,8 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
         }
     } else if (method == SP_METHOD_SUBFLATTENING) {
         SP_CHECK(run_subflat_route(al, split_taxa, split_a, n_splits));
+    } else if (method == SP_METHOD_MUTUAL_INFORMATION) {
+        SP_CHECK(run_divergence_route(al, split_taxa, split_a, n_splits));
     } else {
         sp_set_error("unknown method %d", method);
         return SP_EINVAL;
@@ -987,5 +1009,25 @@ extern "C" int sp_score_splits_multi_async(sp_alignment* const* als, int n_al, c
     SP_CHECK(launch_sparse_score(ctx, ctx->aldescs.as<AlDesc>(), n_al, al0->n_taxa, ctx->splits.as<SplitDev>(),
                                  ctx->gram_items.as<int>(), n_splits, (double*)scores_dev, (int*)status_dev));
     pc.valid = true;
+    return SP_OK;
+}
+
+// phylogenetics.py:364-373 for a dense row-major matrix on the host (any non-negative matrix; cells equal to 0 are skipped).
+extern "C" int sp_divergence_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, int64_t cols, int64_t ld,
+                                        double* out) {
+    SP_REQUIRE(ctx && m && out, SP_EINVAL, "NULL argument");
+    SP_REQUIRE(rows >= 1 && cols >= 1 && ld >= cols, SP_EINVAL, "bad matrix shape %lld x %lld (ld %lld)",
+               (long long)rows, (long long)cols, (long long)ld);
+    SP_HIP(hipSetDevice(ctx->device));
+    if (ctx->cache) ctx->cache->valid = false;
+    SP_CHECK(ctx->mats.ensure((size_t)rows * cols * 8));
+    SP_CHECK(ctx->misc.ensure((size_t)(2 * rows + cols + 1) * 8));
+    SP_HIP(hipMemcpy2DAsync(ctx->mats.p, (size_t)cols * 8, m, (size_t)ld * 8, (size_t)cols * 8, (size_t)rows,
+                            hipMemcpyHostToDevice, ctx->stream));
+    double* scratch = ctx->misc.as<double>();
+    double* res = scratch + 2 * rows + cols;
+    SP_CHECK(launch_divergence_matrix(ctx, ctx->mats.as<double>(), rows, cols, scratch, res));
+    SP_HIP(hipMemcpyAsync(out, res, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;
 }

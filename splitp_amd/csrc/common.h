@@ -189,6 +189,9 @@ int launch_zero_scatter_i8(sp_ctx* ctx, int nl, const SplitDev* splits_dev, cons
                            int64_t D, const int2* dims, const u32* rr, const u32* cc, const u32* vals, uint8_t* mats);
 int launch_gram_i8(sp_ctx* ctx, int nl, bool g_i32, const SplitDev* splits_dev, const GramItem* items_dev,
                    int64_t n_items, const int2* dims, const uint8_t* mats, void* grams);
+int launch_divergence(sp_ctx* ctx, bool exact, int64_t D, int64_t S, const u32* rr, const u32* cc, const u32* counts,
+                      const double* weights, double n_total, unsigned long long* marg, double* out);
+int launch_divergence_matrix(sp_ctx* ctx, const double* m_dev, int64_t rows, int64_t cols, double* scratch, double* out);
 int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta);
 int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,
                         const int* order_dev, int64_t S, double* scores, int* status);

@@ -21,8 +21,9 @@ def _flatten(group):
 
 def erickson_SVD(alignment, taxa=None, method=Method.flattening, show_work=False):
     name = getattr(method, "name", method)
-    if name not in ("flattening", "subflattening"):
-        raise NotImplementedError(f"erickson_SVD on the device supports flattening / subflattening, not {method!r}")
+    if name not in ("flattening", "subflattening", "mutual_information"):
+        raise NotImplementedError(f"erickson_SVD on the device supports flattening / subflattening / mutual_information, "
+                                  f"not {method!r}")
     first = next(iter(alignment.keys())) if not hasattr(alignment, "n_taxa") else None
     num_taxa = alignment.n_taxa if first is None else len(first)
     if taxa is None:  # reference :148-152

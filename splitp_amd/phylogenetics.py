@@ -41,3 +41,20 @@ def split_score(matrix, return_singular_values=False, force_frob_norm_on_dense=F
     _lib.check(lib.sp_score_matrix_f64(ctx.handle, _lib._ptr(m, C.c_double), m.shape[0], m.shape[1], m.shape[1],
                                        C.byref(out)))
     return np.float64(out.value)
+
+
+def flattening_rank_1_approximation_divergence(flattening):
+    """Kullback-Leibler divergence of a flattening from its rank-1 approximation (the product of its marginals):
+    sum over the non-zero cells of f * log(f / (column sum * row sum)).
+
+    reference: splitp/phylogenetics.py:364-373 with the marginals of :332-341; it is the score erickson_SVD uses
+    with Method.mutual_information (:135-140).  Computed on the device (row sums, column sums and the row-ordered
+    sum, `csrc/divergence.hip`); returns np.float64 like the reference's numpy accumulation."""
+    ctx = get_context()
+    m = np.ascontiguousarray(np.array(flattening), dtype=np.float64)
+    if m.ndim != 2:
+        raise ValueError("flattening_rank_1_approximation_divergence expects a 2-D matrix")
+    out = C.c_double()
+    _lib.check(ctx._lib.sp_divergence_matrix_f64(ctx.handle, _lib._ptr(m, C.c_double), m.shape[0], m.shape[1],
+                                                 m.shape[1], C.byref(out)))
+    return np.float64(out.value)

@@ -453,4 +453,47 @@ def test_erickson_svd_matches_reference(sp, golden):
         assert got[:-1] == exp[:-1], (method, got, exp)
         assert len(got) == len(exp) == 8 and got[-1] in got[:-1]
     with pytest.raises(NotImplementedError):
-        sp.erickson_SVD(table, method=sp.Method.mutual_information)
+        sp.erickson_SVD(table, method=sp.Method.distance)
+
+
+def test_mutual_information_score(sp, golden):
+    """flattening_rank_1_approximation_divergence (reference splitp/phylogenetics.py:364-373) - the matrix form, the
+    batched Method.mutual_information form (count table and float-weight table) and the erickson_SVD that uses it,
+    against values / the tree produced by the real reference (tests/golden/divergence_n10_L10k.json)."""
+    import json, os
+    from tests.conftest import GOLDEN
+
+    want = json.load(open(os.path.join(GOLDEN, "divergence_n10_L10k.json")))
+    g = golden("n10_L10k")
+    names = taxa_names(10)
+    table = O.unpack_table(g["keys"], g["probs"], 10)
+    splits = [mask_to_split(int(g["masks"][i]), 10, names) for i in want["split_ids"]]
+    ref = np.array(want["divergence"])
+    # matrix form on the drop-in reduced flattening
+    for j in (0, 7, 20, 41):
+        flat = sp.flattening(splits[j], table, sp.FlatFormat.reduced)
+        got = sp.phylogenetics.flattening_rank_1_approximation_divergence(flat)
+        assert isinstance(got, np.float64) and abs(got - ref[j]) <= SCORE_TOL
+    for s, v in zip(REF4_SPLITS, want["ref4"]):
+        flat = sp.flattening(s, REF4_TABLE, sp.FlatFormat.reduced)
+        assert abs(sp.phylogenetics.flattening_rank_1_approximation_divergence(flat) - v) <= 1e-12
+    # batched, count table (integer marginals) and float-weight table (fp64 atomics)
+    dev = sp.DeviceAlignment.from_table(table, taxa=names)
+    got = sp.score_splits(dev, splits, method=sp.Method.mutual_information)
+    assert np.abs(got - ref).max() <= SCORE_TOL
+    assert np.array_equal(got, sp.score_splits(dev, splits, method=sp.Method.mutual_information))   # integer marginals: repeatable
+    dev_w = sp.DeviceAlignment.from_arrays(g["keys"], g["probs"], 10, taxa=names, exact=False)
+    assert np.abs(sp.score_splits(dev_w, splits, method=sp.Method.mutual_information) - ref).max() <= SCORE_TOL
+    # oracle (vectorised) on all 501 splits of the 100 k-bp table
+    g2 = golden("n10_L100k")
+    all_splits_ = [mask_to_split(int(m), 10, names) for m in g2["masks"]]
+    dev2 = sp.DeviceAlignment.from_table(O.unpack_table(g2["keys"], g2["probs"], 10), taxa=names)
+    got2 = sp.score_splits(dev2, all_splits_, method=sp.Method.mutual_information)
+    for i in range(0, 501, 20):
+        oa = [names.index(t) for t in all_splits_[i][0]]
+        ob = [names.index(t) for t in all_splits_[i][1]]
+        assert abs(O.rank1_divergence_packed(g2["keys"], g2["probs"], 10, oa, ob) - got2[i]) <= SCORE_TOL
+    # the caller: neighbour joining by mutual information
+    tree = sp.erickson_SVD(table, method=sp.Method.mutual_information)
+    exp = [tuple(tuple(side) for side in s) for s in want["erickson_mutual_information"]]
+    assert tree[:-1] == exp[:-1] and len(tree) == len(exp) and tree[-1] in tree[:-1]

@@ -218,6 +218,36 @@ def main():
             json.dump({k: [[list(map(str, side)) for side in s] for s in v] for k, v in res.items()}, f)
         print("erickson done", res["flattening"])
 
+    # ------------------------------------- mutual-information score (phylogenetics.py:364-373) + its erickson_SVD
+    if want("divergence"):
+        import json
+        from splitp.phylogenetics import erickson_SVD, flattening_rank_1_approximation_divergence
+        import splitp as sp_ref
+        g = np.load(os.path.join(OUT, "n10_L10k.npz"))
+        names = [str(np.base_repr(i, base=max(i + 1, 2))) for i in range(10)]
+        table = {}
+        for k, v in zip(g["keys"].tolist(), g["probs"].tolist()):
+            table["".join("ACGT"[(k >> (2 * (9 - t))) & 3] for t in range(10))] = v
+        ids = list(range(0, 501, 12))
+        vals = []
+        t0 = time.time()
+        for i in ids:
+            m = int(g["masks"][i])
+            split = (tuple(names[t] for t in range(10) if (m >> t) & 1), tuple(names[t] for t in range(10) if not (m >> t) & 1))
+            flat = flattening(split, table, FlatFormat.reduced)
+            vals.append(float(flattening_rank_1_approximation_divergence(flat)))
+        print("divergence of", len(ids), "splits", time.time() - t0)
+        # the 4-taxon reference table too (dense 4 x 4 reduced flattenings)
+        ref4 = {"ATCG": 2 / 5, "GATC": 1 / 5, "CGAT": 1 / 5, "TCGA": 1 / 5}
+        v4 = [float(flattening_rank_1_approximation_divergence(flattening(s, ref4, FlatFormat.reduced)))
+              for s in ((("0", "1"), ("2", "3")), (("0", "2"), ("1", "3")), (("0", "3"), ("1", "2")))]
+        t0 = time.time()
+        tree = erickson_SVD(table, method=sp_ref.Method.mutual_information)
+        print("erickson mutual_information", time.time() - t0)
+        with open(os.path.join(OUT, "divergence_n10_L10k.json"), "w") as f:
+            json.dump({"versions": versions, "split_ids": ids, "divergence": vals, "ref4": v4,
+                       "erickson_mutual_information": [[list(map(str, side)) for side in s] for s in tree]}, f)
+
     # --------------------------------------------------------- degenerate cases
     if want("degenerate"):
         out = dict(versions=versions)
