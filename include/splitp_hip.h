@@ -113,6 +113,15 @@ int sp_alignment_from_sequences(sp_ctx* ctx, const uint8_t* seqs, int n_taxa, in
 /* Same, from already packed site keys resident on the host (one key per site). */
 int sp_alignment_from_site_keys(sp_ctx* ctx, const uint64_t* site_keys, int64_t L, int n_taxa, sp_alignment** out);
 
+/* Device simulator + histogram: replaces splitp/simulation.py:9-56 generate_alignment(tree, model, L).
+ * The tree is given parents-first: node 0 is the root (parent -1); parent[i] < i; leaf_taxon[i] = taxon index of a leaf,
+ * -1 for an internal node; transition[i] = row-major 4 x 4 matrix M of node i's branch with M[new][old] (a state is
+ * drawn from column `old`, simulation.py:17-18; ignored for the root, whose state is uniform, :28).  Sites are
+ * independent; the same seed gives the same table.  The result is the pattern table of the L simulated sites
+ * (counts / L), resident on the device like every other alignment. */
+int sp_simulate_alignment(sp_ctx* ctx, int n_nodes, const int32_t* parent, const int32_t* leaf_taxon,
+                          const double* transition, int n_taxa, int64_t L, uint64_t seed, sp_alignment** out);
+
 int sp_alignment_destroy(sp_alignment* al);
 /* D distinct patterns, n taxa, N sites (0 if unknown), exact = 1 when integer counts are held */
 int sp_alignment_info(const sp_alignment* al, int64_t* D, int* n_taxa, int64_t* N, int* exact);

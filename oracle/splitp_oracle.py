@@ -394,3 +394,47 @@ def score_from_matrix_gram(matrix):
     if tr == 0:
         return float("nan")
     return sqrt(max(0.0, 1.0 - top / tr))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Simulator: exact distribution of the site patterns reference splitp/simulation.py:9-40 samples from,
+# and a per-site restatement of that walk for small Monte-Carlo cross-checks.
+def pattern_distribution(parent, leaf_taxon, trans, n_taxa):
+    """P(pattern) for all 4^n patterns (index = base-4 value of the pattern, taxon 0 most significant).
+    Tree in parents-first arrays: parent[i] < i, root = node 0 (uniform state, simulation.py:28); trans[i] is node i's
+    4 x 4 matrix M with M[new, old] (a state is drawn from column `old`, simulation.py:17-18).  Pruning from the leaves up."""
+    n_nodes = len(parent)
+    pats = np.arange(4 ** n_taxa)
+    digit = lambda t: (pats >> (2 * (n_taxa - 1 - t))) & 3          # noqa: E731
+    like = [None] * n_nodes                                           # like[node][pattern, state of node]
+    children = [[] for _ in range(n_nodes)]
+    for i in range(1, n_nodes):
+        children[parent[i]].append(i)
+    for node in range(n_nodes - 1, -1, -1):
+        if leaf_taxon[node] >= 0:
+            lk = np.zeros((len(pats), 4))
+            lk[np.arange(len(pats)), digit(leaf_taxon[node])] = 1.0
+        else:
+            lk = np.ones((len(pats), 4))
+            for ch in children[node]:
+                lk = lk * (like[ch] @ np.asarray(trans[ch], dtype=np.float64))   # sum_new like[new] M[new, old]
+        like[node] = lk
+    return like[0] @ np.full(4, 0.25)
+
+
+def evolve_pattern_keys(parent, leaf_taxon, trans, n_taxa, n_sites, rng):
+    """Per-site walk of simulation.py:9-40 (vectorised over sites, numpy generator): packed keys of n_sites patterns."""
+    n_nodes = len(parent)
+    state = np.zeros((n_nodes, n_sites), dtype=np.int64)
+    state[0] = rng.integers(0, 4, size=n_sites)
+    keys = np.zeros(n_sites, dtype=np.uint64)
+    for node in range(1, n_nodes):
+        m = np.asarray(trans[node], dtype=np.float64)
+        cum = np.cumsum(m, axis=0)                                    # cumulative over the new state, per old state
+        u = rng.random(n_sites) * cum[3, state[parent[node]]]
+        old = state[parent[node]]
+        state[node] = (u >= cum[0, old]).astype(np.int64) + (u >= cum[1, old]) + (u >= cum[2, old])
+    for node in range(n_nodes):
+        if leaf_taxon[node] >= 0:
+            keys |= state[node].astype(np.uint64) << np.uint64(2 * (n_taxa - 1 - leaf_taxon[node]))
+    return keys

@@ -8,7 +8,7 @@ plus the device-resident batched form of the README loop:
     DeviceAlignment, score_splits
 Host code is Python; all compute is hand-written HIP for gfx950 behind a ctypes C ABI
 (include/splitp_hip.h).  There is no CPU fallback."""
-from . import constants, constructions, enums, matrix, phylogenetics, splits  # noqa: F401
+from . import constants, constructions, enums, matrix, phylogenetics, simulation, splits  # noqa: F401
 from .batch import score_splits  # noqa: F401
 from .constructions import (flattening, sparse_flattening_with_banned_patterns,  # noqa: F401
                             subflattening)
@@ -17,6 +17,7 @@ from .enums import FlatFormat, Method  # noqa: F401
 from .inference import erickson_SVD  # noqa: F401
 from .matrix import frobenius_norm, is_sparse  # noqa: F401
 from .phylogenetics import split_score  # noqa: F401
+from .simulation import generate_alignment  # noqa: F401
 from .splits import all_splits  # noqa: F401
 from ._lib import SplitPDeviceError  # noqa: F401
 

@@ -25,7 +25,7 @@ SYMBOLS = (
     "sp_abi_version", "sp_last_error", "sp_device_count",
     "sp_ctx_create", "sp_ctx_destroy", "sp_ctx_set_stream", "sp_ctx_set_stream_unordered", "sp_ctx_synchronize", "sp_ctx_set_gram_mode",
     "sp_ctx_enable_timing", "sp_ctx_reset_timing", "sp_ctx_phase_times",
-    "sp_alignment_create", "sp_alignment_from_sequences", "sp_alignment_from_site_keys",
+    "sp_alignment_create", "sp_alignment_from_sequences", "sp_alignment_from_site_keys", "sp_simulate_alignment",
     "sp_alignment_destroy", "sp_alignment_info", "sp_alignment_fetch",
     "sp_flatten_indices", "sp_flatten_reduced_prepare", "sp_flatten_reduced_fetch", "sp_flatten_dense_counts",
     "sp_subflatten", "sp_moment_matrix",
@@ -80,6 +80,7 @@ def load():
         "sp_alignment_create": [vp, P(C.c_uint64), P(dbl), P(i64), i64, i32, i64, P(vp)],
         "sp_alignment_from_sequences": [vp, P(C.c_uint8), i32, i64, i64, P(vp)],
         "sp_alignment_from_site_keys": [vp, P(C.c_uint64), i64, i32, P(vp)],
+        "sp_simulate_alignment": [vp, i32, P(C.c_int32), P(C.c_int32), P(dbl), i32, i64, C.c_uint64, P(vp)],
         "sp_alignment_destroy": [vp],
         "sp_alignment_info": [vp, P(i64), P(i32), P(i64), P(i32)],
         "sp_alignment_fetch": [vp, P(C.c_uint64), P(dbl), P(i64)],

@@ -359,3 +359,113 @@ extern "C" int sp_alignment_from_sequences(sp_ctx* ctx, const uint8_t* seqs, int
     }
     return build_from_device_keys(ctx, ctx->misc.p, n_taxa <= 15, L, n_taxa, out);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Alignment simulator: replaces splitp/simulation.py:9-56 (evolve_pattern / generate_alignment) - an
+// independent Markov walk down the tree per site: uniform root state (simulation.py:28), at every node the new state
+// is drawn from column `state` of that node's 4 x 4 transition matrix (simulation.py:17-18, probs = M[:, index(state)],
+// random.choices = inverse CDF over the cumulative weights), leaves write their state into the site's pattern.
+// One thread per site, the node states of the walk packed 2 bits each in registers, the cumulative columns of all
+// transition matrices in LDS, a counter-based generator (SplitMix64 of seed, site and node - any site can be
+// regenerated on its own, results do not depend on the launch shape).  The site words go straight into the histogram
+// above: L sites -> D (pattern, count) pairs without leaving the device.
+#define SIM_MAX_NODES 64
+
+__device__ __forceinline__ u64 sim_mix(u64 x) {   // SplitMix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+template <typename KT>
+__global__ __launch_bounds__(256) void k_simulate_sites(int n_nodes, const int* __restrict__ parent,
+                                                         const int* __restrict__ leaf_taxon,
+                                                         const double* __restrict__ trans, int n_taxa, int64_t L,
+                                                         u64 seed, KT* __restrict__ site_keys) {
+    __shared__ double cum[SIM_MAX_NODES][4][3];   // cumulative probabilities of the first three new states, per old state
+    __shared__ int par[SIM_MAX_NODES], leaf[SIM_MAX_NODES];
+    for (int i = threadIdx.x; i < n_nodes * 4; i += blockDim.x) {
+        const int node = i >> 2, old = i & 3;
+        const double* m = trans + (size_t)node * 16;   // row-major M[new][old]
+        const double p0 = m[0 * 4 + old], p1 = m[1 * 4 + old], p2 = m[2 * 4 + old];
+        cum[node][old][0] = p0;
+        cum[node][old][1] = p0 + p1;
+        cum[node][old][2] = (p0 + p1) + p2;
+    }
+    for (int i = threadIdx.x; i < n_nodes; i += blockDim.x) {
+        par[i] = parent[i];
+        leaf[i] = leaf_taxon[i];
+    }
+    __syncthreads();
+    for (int64_t site = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; site < L; site += (int64_t)gridDim.x * blockDim.x) {
+        const u64 base = sim_mix(seed ^ sim_mix((u64)site));
+        u64 st_lo = 0, st_hi = 0;   // 2 bits per node
+        KT key = 0;
+        for (int node = 0; node < n_nodes; ++node) {
+            const u64 rnd = sim_mix(base + (u64)node * 0xD1B54A32D192ED03ull);
+            const double u = (double)(rnd >> 11) * (1.0 / 9007199254740992.0);   // [0, 1)
+            int s;
+            const int p = par[node];
+            if (p < 0) {
+                s = (int)(rnd >> 62);                  // root: uniform over the four states
+            } else {
+                const int old = (int)(((p < 32 ? st_lo >> (2 * p) : st_hi >> (2 * (p - 32)))) & 3ull);
+                const double* c = cum[node][old];
+                s = (u >= c[0]) + (u >= c[1]) + (u >= c[2]);
+            }
+            if (node < 32)
+                st_lo |= (u64)s << (2 * node);
+            else
+                st_hi |= (u64)s << (2 * (node - 32));
+            const int t = leaf[node];
+            if (t >= 0) key |= (KT)s << (2 * (n_taxa - 1 - t));
+        }
+        site_keys[site] = key;
+    }
+}
+
+extern "C" int sp_simulate_alignment(sp_ctx* ctx, int n_nodes, const int32_t* parent, const int32_t* leaf_taxon,
+                                     const double* transition, int n_taxa, int64_t L, uint64_t seed,
+                                     sp_alignment** out) {
+    SP_REQUIRE(ctx && parent && leaf_taxon && transition && out, SP_EINVAL, "NULL argument");
+    SP_REQUIRE(n_taxa >= 2 && n_taxa <= 16, SP_ELIMIT, "device simulator supports 2..16 taxa (got %d)", n_taxa);
+    SP_REQUIRE(n_nodes >= n_taxa && n_nodes <= SIM_MAX_NODES, SP_ELIMIT, "tree has %d nodes (supported: n_taxa..%d)",
+               n_nodes, SIM_MAX_NODES);
+    SP_REQUIRE(L >= 0, SP_EINVAL, "L < 0");
+    std::vector<int> seen((size_t)n_taxa, 0);
+    int roots = 0;
+    for (int i = 0; i < n_nodes; ++i) {
+        SP_REQUIRE(parent[i] < i, SP_EINVAL, "nodes must be listed parents first (node %d has parent %d)", i, parent[i]);
+        roots += parent[i] < 0;
+        SP_REQUIRE(leaf_taxon[i] < n_taxa, SP_EINVAL, "leaf_taxon[%d] = %d out of range", i, leaf_taxon[i]);
+        if (leaf_taxon[i] >= 0) seen[leaf_taxon[i]] += 1;
+        for (int k = 0; k < 16 && parent[i] >= 0; ++k)
+            SP_REQUIRE(transition[(size_t)i * 16 + k] >= 0.0, SP_EINVAL, "negative transition probability at node %d", i);
+    }
+    SP_REQUIRE(roots == 1 && parent[0] < 0, SP_EINVAL, "exactly one root, listed first");
+    for (int t = 0; t < n_taxa; ++t) SP_REQUIRE(seen[t] == 1, SP_EINVAL, "taxon %d is the leaf of %d nodes", t, seen[t]);
+    SP_HIP(hipSetDevice(ctx->device));
+    const bool keys32 = n_taxa <= 15;
+    SP_CHECK(ctx->misc.ensure((size_t)std::max<int64_t>(L, 1) * (keys32 ? 4 : 8)));
+    SP_CHECK(ctx->misc2.ensure((size_t)n_nodes * (16 * 8 + 8)));
+    double* d_trans = ctx->misc2.as<double>();
+    int* d_parent = reinterpret_cast<int*>(d_trans + (size_t)n_nodes * 16);
+    int* d_leaf = d_parent + n_nodes;
+    SP_HIP(hipMemcpyAsync(d_trans, transition, (size_t)n_nodes * 16 * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipMemcpyAsync(d_parent, parent, (size_t)n_nodes * 4, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipMemcpyAsync(d_leaf, leaf_taxon, (size_t)n_nodes * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (L > 0) {
+        PhaseScope ps(ctx, SP_PHASE_HIST);
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((L + 255) / 256, (int64_t)ctx->n_cu * 16));
+        if (keys32)
+            hipLaunchKernelGGL(k_simulate_sites<u32>, dim3(grid), dim3(256), 0, ctx->stream, n_nodes, d_parent, d_leaf,
+                               d_trans, n_taxa, L, (u64)seed, ctx->misc.as<u32>());
+        else
+            hipLaunchKernelGGL(k_simulate_sites<u64>, dim3(grid), dim3(256), 0, ctx->stream, n_nodes, d_parent, d_leaf,
+                               d_trans, n_taxa, L, (u64)seed, ctx->misc.as<u64>());
+        SP_HIP(hipGetLastError());
+    }
+    SP_HIP(hipStreamSynchronize(ctx->stream));   // the host arrays may die at return
+    return build_from_device_keys(ctx, ctx->misc.p, keys32, L, n_taxa, out);
+}

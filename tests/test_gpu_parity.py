@@ -497,3 +497,79 @@ def test_mutual_information_score(sp, golden):
     tree = sp.erickson_SVD(table, method=sp.Method.mutual_information)
     exp = [tuple(tuple(side) for side in s) for s in want["erickson_mutual_information"]]
     assert tree[:-1] == exp[:-1] and len(tree) == len(exp) and tree[-1] in tree[:-1]
+
+
+def test_device_simulator(sp):
+    """generate_alignment on the device (reference splitp/simulation.py:9-56): sampling semantics with deterministic
+    matrices (column orientation, root uniform), the exact pattern distribution (chi-square against the oracle, JC and
+    asymmetric matrices), reproducibility, the reference's Phylogeny duck type, and the scores of a simulated alignment."""
+    import networkx as nx
+    from splitp_amd import simulation as sim
+    from splitp_amd import synthetic as syn
+
+    # (1) deterministic walk: f = 0->1, 1->3, 2->0, 3->2 (not an involution: M != M^T), M[new, old]
+    f = [1, 3, 0, 2]
+    M = np.zeros((4, 4))
+    for old, new in enumerate(f):
+        M[new, old] = 1.0
+
+    class Fixed:
+        def transition_matrix(self, t):
+            return M
+
+    tree4 = ((0, 1), (2, 3))      # every leaf two branches below the root
+    table = sim.generate_alignment(tree4, Fixed(), 40_000, seed=1, branch_length=1.0)
+    want = {"".join("ACGT"[f[f[r]]] * 4): None for r in range(4)}
+    assert set(table) == set(want) and list(table) == sorted(table)
+    assert abs(sum(table.values()) - 1) < 1e-12 and all(abs(v - 0.25) < 0.02 for v in table.values())
+    # (2) exact distribution: Jukes-Cantor and per-branch asymmetric matrices
+    jc = sim.JukesCantor()
+    parent, leaf, trans, taxa = sim.tree_arrays(tree4, jc, 0.15)
+    n_sites = 2_000_000
+    dev = sim.generate_device_alignment(tree4, jc, n_sites, seed=7, branch_length=0.15)
+    keys, w, cnt = dev.fetch()
+    assert dev.info()["N"] == n_sites and int(cnt.sum()) == n_sites and np.all(np.diff(keys.astype(np.int64)) > 0)
+    p = O.pattern_distribution(parent.tolist(), leaf.tolist(), trans, 4)
+    freq = np.zeros(256)
+    freq[keys.astype(np.int64)] = cnt / n_sites
+    chi2 = float(np.sum((freq - p) ** 2 / p) * n_sites)
+    assert 255 - 6 * 22.6 < chi2 < 255 + 6 * 22.6, chi2
+    rng = np.random.default_rng(11)
+    g = nx.DiGraph()
+    g.add_edges_from([("r", "x"), ("r", "y"), ("x", "0"), ("x", "1"), ("y", "2"), ("y", "z"), ("z", "3"), ("z", "4")])
+    for node in g.nodes:
+        m = rng.random((4, 4)) + 2 * np.eye(4)
+        g.nodes[node]["transition_matrix"] = m / m.sum(axis=0, keepdims=True)
+        g.nodes[node]["branch_length"] = 0.1
+
+    class Phylo:          # the reference's Phylogeny, as far as the simulator looks at it
+        networkx_graph = g
+        taxa = ["0", "1", "2", "3", "4"]
+
+    parent, leaf, trans, taxa = sim.tree_arrays(Phylo(), None)
+    dev5 = sim.generate_device_alignment(Phylo(), None, n_sites, seed=3)
+    keys, w, cnt = dev5.fetch()
+    p = O.pattern_distribution(parent.tolist(), leaf.tolist(), trans, 5)
+    freq = np.zeros(1024)
+    freq[keys.astype(np.int64)] = cnt / n_sites
+    chi2 = float(np.sum((freq - p) ** 2 / p) * n_sites)
+    assert 1023 - 6 * 45.2 < chi2 < 1023 + 6 * 45.2, chi2
+    # the same tree through a model object: branch lengths from the nodes
+    dev5b = sim.generate_device_alignment(Phylo(), jc, 100_000, seed=3)
+    assert dev5b.info()["N"] == 100_000
+    # (3) reproducible, seed-dependent
+    a = sim.generate_alignment(tree4, jc, 50_000, seed=42, branch_length=0.15)
+    b = sim.generate_alignment(tree4, jc, 50_000, seed=42, branch_length=0.15)
+    c = sim.generate_alignment(tree4, jc, 50_000, seed=43, branch_length=0.15)
+    assert a == b and a != c
+    # (4) downstream: a simulated 10-taxon alignment, the tree's own splits score lowest
+    names = taxa_names(10)
+    tree10 = syn.balanced_tree(10)
+    dev10 = sim.generate_device_alignment(tree10, jc, 100_000, seed=9, branch_length=0.05)
+    dev10.taxa = tuple(names)
+    splits = list(sp.all_splits(names))
+    s = sp.score_splits(dev10, splits)
+    true = syn.tree_splits(tree10, 10)
+    is_true = np.array([frozenset(names.index(t) for t in x) in true or frozenset(names.index(t) for t in y) in true
+                        for x, y in splits])
+    assert is_true.sum() == 7 and s[is_true].max() < s[~is_true].min()
