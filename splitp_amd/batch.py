@@ -103,11 +103,12 @@ def score_encoded_multi_async(als, split_taxa, split_a, scores_dev_ptr, status_d
 
 
 def finish_async(al, split_taxa, split_a, scores_host, status_host):
-    """Hand-back for the asynchronous form: re-score on the dense route whatever the in-LDS kernel flagged
-    (status bit 1).  scores_host / status_host are NumPy views of the fetched results, patched in place."""
+    """Hand-back for the asynchronous form: re-score with the synchronous entry point whatever the in-LDS kernel
+    flagged (status bit 1) - it walks the chain LDS form -> global-memory form of the same kernel -> dense route.
+    scores_host / status_host are NumPy views of the fetched results, patched in place."""
     redo = np.nonzero(np.asarray(status_host) & 2)[0]
     if len(redo):
-        sc, st = score_encoded(al, split_taxa[redo], split_a[redo], _lib.SP_METHOD_FLATTENING_DENSE)
+        sc, st = score_encoded(al, split_taxa[redo], split_a[redo], _lib.SP_METHOD_FLATTENING)
         scores_host[redo] = sc
         status_host[redo] = st
     return len(redo)

@@ -645,6 +645,45 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
                "sparse route: %zu of %lld splits were handed back by the in-LDS kernel (first: split %d, status 0x%x: "
                "%s)", redo.size(), (long long)S, redo[0], st[redo[0]],
                (st[redo[0]] >> 8) ? "no convergence with the 4-wide block" : "lists / blocks do not fit LDS");
+    {   // splits that only lacked LDS space: the same kernel with its arrays in a global-memory slab per workgroup
+        std::vector<int> fit;
+        int64_t bmw = 0;
+        for (int i : redo)
+            if ((st[i] >> 8) == 0) {
+                fit.push_back(i);
+                bmw = std::max<int64_t>(bmw, (int64_t)plan.splits[i].rw + plan.splits[i].cw);
+            }
+        if (!fit.empty() && al->D <= 65535) {
+            const size_t slab = (sparse_slab_bytes(al->D, bmw) + 255) & ~(size_t)255;
+            const size_t chunk = std::max<size_t>(1, std::min<size_t>(fit.size(), ((size_t)2 << 30) / slab));
+            DevBuf slabs, fidx;
+            int rc2 = SP_OK;
+            if ((rc2 = slabs.ensure(chunk * slab)) || (rc2 = fidx.ensure(fit.size() * 4))) {
+                slabs.release(); fidx.release();
+                return rc2;
+            }
+            hipError_t e = hipMemcpyAsync(fidx.p, fit.data(), fit.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+            for (size_t k0 = 0; k0 < fit.size() && e == hipSuccess && rc2 == SP_OK; k0 += chunk) {
+                const size_t cnt = std::min(chunk, fit.size() - k0);
+                rc2 = launch_sparse_score_hbm(ctx, ctx->aldescs.as<AlDesc>(), al->n_taxa, ctx->splits.as<SplitDev>(),
+                                              fidx.as<int>() + k0, (int64_t)cnt, S, ctx->scores.as<double>(),
+                                              ctx->status.as<int>(), slabs.as<unsigned char>(), slab);
+            }
+            if (e == hipSuccess && rc2 == SP_OK)
+                e = hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            slabs.release(); fidx.release();
+            if (rc2 != SP_OK) return rc2;
+            if (e != hipSuccess) {
+                sp_set_error("sparse route (HBM form): %s", hipGetErrorString(e));
+                return SP_EHIP;
+            }
+            redo.clear();
+            for (int64_t i = 0; i < S; ++i)
+                if (st[i] & 2) redo.push_back((int)i);
+            if (redo.empty()) return SP_OK;
+        }
+    }
     // dense route on the handed-back subset (overwrites the context pools, hence the parking buffer)
     const int n = al->n_taxa;
     std::vector<int32_t> t2(redo.size() * (size_t)n), a2(redo.size());

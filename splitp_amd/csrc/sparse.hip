@@ -110,9 +110,16 @@ __device__ __forceinline__ u32 spk_scan(u32 v, SpkShared& sh, u32& total) {
     return base + x - v;
 }
 
+// read of a word that other waves of the workgroup have updated with atomics (see k_sparse_score, HBM form); for LDS
+// pointers this is a plain ds_read
+template <typename T>
+__device__ __forceinline__ T spk_aload(const T* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // rank of key k in a presence bitmap with per-word exclusive popcount prefixes
 __device__ __forceinline__ u32 bm_rank(const u64* bm, const u32* pf, u32 k) {
-    return pf[k >> 6] + __popcll(bm[k >> 6] & ((1ull << (k & 63)) - 1));
+    return pf[k >> 6] + __popcll(spk_aload(bm + (k >> 6)) & ((1ull << (k & 63)) - 1));
 }
 
 // S = X^T X of the rows x 4 block X (row pitch `pitch` doubles) on the matrix cores: one v_mfma_f64_4x4x4 (4 blocks of
@@ -248,7 +255,7 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
         for (int f = 0; f < PER; ++f) run[f] = 0;
         u32 words[SPK_WAVES];
 #pragma unroll
-        for (int ww = 0; ww < SPK_WAVES; ++ww) words[ww] = cw[ww * stride + q];
+        for (int ww = 0; ww < SPK_WAVES; ++ww) words[ww] = spk_aload(cw + ww * stride + q);
 #pragma unroll
         for (int ww = 0; ww < SPK_WAVES; ++ww) {
             u32 outw = 0;
@@ -544,13 +551,24 @@ __device__ __forceinline__ bool spk_converged(double s4, int k, double& prev_sum
 
 // grid = n_al * S workgroups: block b scores split order[b / n_al] of alignment b % n_al (heaviest splits of every
 // alignment first); score / status index = alignment * S + split.
+//
+// HBM = false: every array of the workgroup lives in its 160 KB of LDS (the fast path, tables up to ~9 k patterns at
+// 10 taxa).  HBM = true: the same code with every array in a per-workgroup slab of global memory (L2-resident) and only
+// SpkShared in LDS - for the splits the LDS form hands back (status 2, e.g. 12 taxa x 100 k sites: 13.5 k patterns, row and
+// column sides of ~1800 ids).  Communication inside the workgroup then goes through global memory: plain stores are
+// coherent at workgroup scope after __syncthreads(); words that were updated by ATOMICS (key bitmaps, sort counters, the
+// integer Gram) are read back with agent-scope atomic loads (spk_aload), since device atomics are done in L2 past the L1.
+template <bool HBM>
 __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __restrict__ als, int n_al, int n,
                                                               const SplitDev* __restrict__ splits,
                                                               const int* __restrict__ order, int S,
                                                               double* __restrict__ scores_all,
-                                                              int* __restrict__ status_all) {
+                                                              int* __restrict__ status_all,
+                                                              unsigned char* __restrict__ slabs, size_t slab_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SpkShared& sh = *reinterpret_cast<SpkShared*>(smem);
+    unsigned char* const base = HBM ? slabs + (size_t)blockIdx.x * slab_bytes : smem;
+    const size_t cap = HBM ? slab_bytes : (size_t)SPK_LDS_BYTES;
     const int ai = blockIdx.x % n_al;
     const int sid = order[blockIdx.x / n_al];
     const u32* __restrict__ keys = als[ai].keys32;
@@ -567,9 +585,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     }
     if (threadIdx.x == 0) sh.flag = 0;
     __syncthreads();  // shifts are read by every wave below
-    size_t off = (sizeof(SpkShared) + 15) & ~(size_t)15;
+    size_t off = HBM ? 0 : (sizeof(SpkShared) + 15) & ~(size_t)15;
     auto carve = [&](size_t bytes) {
-        unsigned char* p = smem + off;
+        unsigned char* p = base + off;
         off = (off + bytes + 15) & ~(size_t)15;
         return p;
     };
@@ -589,7 +607,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     const int r_cap = raw_r ? (1 << (2 * nr)) : (int)min((long long)D, nr >= 8 ? (long long)D : (1ll << (2 * nr)));
     const bool small_sure = r_cap <= SPK_SMALL_R;   // then no CSR list is needed
     const size_t need_build = off + (size_t)(D + 8) * (small_sure ? 4 : 8) + (size_t)D * 6 + (size_t)W * 12 + 256;
-    if (D > 65535 || n > 16 || need_build + 2048 > SPK_LDS_BYTES) {
+    if (D > 65535 || n > 16 || need_build + 2048 > cap) {
         if (threadIdx.x == 0) {
             scores[sid] = 0.0;
             status[sid] = 2;
@@ -658,16 +676,16 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     int dimsRC[2] = {1 << (2 * (raw_r ? nr : 0)), 1 << (2 * (raw_c ? nc : 0))};
     for (int which = 0; which < 2; ++which) {
         if (which ? raw_c : raw_r) continue;
-        const int base = which ? rwl : 0, cntw = which ? cwl : rwl;
+        const int wbase = which ? rwl : 0, cntw = which ? cwl : rwl;
         const int per = (cntw + SPK_THREADS - 1) / SPK_THREADS;
         const int lo = min(cntw, (int)threadIdx.x * per), hi = min(cntw, lo + per);
         u32 s = 0;
-        for (int i = lo; i < hi; ++i) s += __popcll(bm[base + i]);
+        for (int i = lo; i < hi; ++i) s += __popcll(spk_aload(bm + wbase + i));
         u32 tot;
         u32 run = spk_scan(s, sh, tot);
         for (int i = lo; i < hi; ++i) {
-            pf[base + i] = run;
-            run += __popcll(bm[base + i]);
+            pf[wbase + i] = run;
+            run += __popcll(spk_aload(bm + wbase + i));
         }
         dimsRC[which] = (int)tot;
     }
@@ -712,17 +730,17 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     const int Rp = (R + 3) & ~3;
     // group descriptors + permutations (now that R and Kc are known) are carved top-down from the end of LDS; the key
     // bitmaps are dead: the counting-sort counters start where they were
-    size_t top = SPK_LDS_BYTES;
+    size_t top = cap;
     auto carve_top = [&](size_t bytes) {
         top = (top - bytes) & ~(size_t)15;
-        return smem + top;
+        return base + top;
     };
     unsigned short* desc_c = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)(Kc + 1) * 2));
     unsigned short* desc_r = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)(R + 1) * 2));
     unsigned short* perm_c = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)Kc * 2));
     unsigned short* perm_r = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)R * 2));
     unsigned short* csc_ptr = small ? reinterpret_cast<unsigned short*>(carve_top((size_t)(Kc + 1) * 2)) : nullptr;
-    const size_t build_end = reinterpret_cast<unsigned char*>(bm) - smem;
+    const size_t build_end = reinterpret_cast<unsigned char*>(bm) - base;
     // W row pitch: 5 doubles when LDS allows it (rows start on 32 different bank offsets instead of 8: the gathers
     // of Y = C W hit random rows), 4 otherwise
     size_t top_probe = top;
@@ -743,9 +761,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         }
         return;
     }
-    u32* cwbuf = reinterpret_cast<u32*>(smem + build_end);
+    u32* cwbuf = reinterpret_cast<u32*>(base + build_end);
     unsigned short* grp_c = reinterpret_cast<unsigned short*>(csr_ent);
-    unsigned short* grp_r = reinterpret_cast<unsigned short*>(smem + ((build_end + cw_r + 15) & ~(size_t)15));
+    unsigned short* grp_r = reinterpret_cast<unsigned short*>(base + ((build_end + cw_r + 15) & ~(size_t)15));
     // small path: end of the column of every CSC position (for the entry-parallel Gram below); it lives in the G area's tail
     unsigned short* colof = nullptr;
     if (small) {
@@ -823,7 +841,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     // V and W / G are laid out over the (now dead) staging area
     off = off_after_lists;
     double* V = reinterpret_cast<double*>(carve((size_t)Rp * SPK_VP * 8));
-    double* Wb = reinterpret_cast<double*>(smem + off);   // large: W (Kc x 4);  small: G (R x R)
+    double* Wb = reinterpret_cast<double*>(base + off);   // large: W (Kc x 4);  small: G (R x R)
     if (small) {
         // exact Gram G = C C^T: all pairs of entries inside every column, accumulated with integer LDS atomics (exact,
         // order independent).  One thread per CSC position i of a column of n entries takes the pairs (i, i + d mod n),
@@ -872,7 +890,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
 #pragma unroll
             for (int k = 0; k < (SPK_SMALL_R * SPK_SMALL_R + SPK_THREADS - 1) / SPK_THREADS; ++k) {
                 const int i = k * SPK_THREADS + (int)threadIdx.x;
-                gv[k] = i < R * R ? (g32 ? (double)G32[i] : (double)G64[i]) : 0.0;
+                gv[k] = i < R * R ? (g32 ? (double)spk_aload(G32 + i) : (double)spk_aload(G64 + i)) : 0.0;
             }
             __syncthreads();
 #pragma unroll
@@ -1070,12 +1088,34 @@ int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa
     PhaseScope ps(ctx, SP_PHASE_SPARSE);
     static bool attr = false;
     if (!attr) {
-        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_score),
+        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_score<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_BYTES));
         attr = true;
     }
-    hipLaunchKernelGGL(k_sparse_score, dim3((unsigned)(S * n_al)), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream, als_dev,
-                       n_al, n_taxa, splits_dev, order_dev, (int)S, scores, status);
+    hipLaunchKernelGGL(k_sparse_score<false>, dim3((unsigned)(S * n_al)), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream,
+                       als_dev, n_al, n_taxa, splits_dev, order_dev, (int)S, scores, status, (unsigned char*)nullptr,
+                       (size_t)0);
+    SP_HIP(hipGetLastError());
+    return SP_OK;
+}
+
+// Bytes of global memory one workgroup of the HBM form needs for a table of D patterns whose bitmaps take `bm_words`
+// 64-bit words: the same carve as the LDS form with every size at its a-priori bound (sides <= max(D, 1024) ids).
+size_t sparse_slab_bytes(int64_t D, int64_t bm_words) {
+    const size_t d1 = (size_t)std::max<int64_t>(D, 1024) + 16;
+    return (size_t)(D + 8) * 8 + (size_t)D * 6 + (size_t)bm_words * 12 + d1 * (16 + 16 + 2 * 48) + (size_t)D * 2 + 65536;
+}
+
+// The splits listed in order_dev[0 .. S_sub) (indices into the split / score arrays), one alignment, HBM form.
+int launch_sparse_score_hbm(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, const SplitDev* splits_dev,
+                            const int* order_dev, int64_t S_sub, int64_t S, double* scores, int* status,
+                            unsigned char* slabs, size_t slab_bytes) {
+    if (S_sub == 0) return SP_OK;
+    if (ctx->upload_ev) SP_HIP(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
+    PhaseScope ps(ctx, SP_PHASE_SPARSE);
+    const size_t lds = (sizeof(SpkShared) + 31) & ~(size_t)15;
+    hipLaunchKernelGGL(k_sparse_score<true>, dim3((unsigned)S_sub), dim3(SPK_THREADS), lds, ctx->stream, als_dev, 1, n_taxa,
+                       splits_dev, order_dev, (int)S, scores, status, slabs, slab_bytes);
     SP_HIP(hipGetLastError());
     return SP_OK;
 }

@@ -573,3 +573,35 @@ def test_device_simulator(sp):
     is_true = np.array([frozenset(names.index(t) for t in x) in true or frozenset(names.index(t) for t in y) in true
                         for x, y in splits])
     assert is_true.sum() == 7 and s[is_true].max() < s[~is_true].min()
+
+
+def test_config5_shape_12_taxa(sp):
+    """BASELINE config 5 shape (simulated 12-taxon alignments x all 2035 splits): a 100 k-site table has 13.5 k patterns
+    and 5|7, 6|6 flattenings of ~1800 x 1800 used ids - too much for one workgroup's LDS, so these splits run the same
+    kernel with its arrays in global memory (HBM form, sparse.hip); the small table stays in LDS.  Both against the oracle."""
+    from splitp_amd import simulation as sim
+    from splitp_amd import synthetic as syn
+
+    n = 12
+    names = taxa_names(n)
+    splits = list(sp.all_splits(names))
+    assert len(splits) == 2035
+    tree = syn.balanced_tree(n)
+    for length, seed in ((20_000, 5), (100_000, 6)):
+        dev = sim.generate_device_alignment(tree, sim.JukesCantor(), length, seed=seed, branch_length=0.05)
+        dev.taxa = tuple(names)
+        scores, status = sp.score_splits(dev, splits, return_status=True)
+        assert np.all((status & 3) == 0) and np.all(np.isfinite(scores))
+        keys, w, cnt = dev.fetch()
+        true = syn.tree_splits(tree, n)
+        is_true = np.array([frozenset(names.index(t) for t in a) in true or frozenset(names.index(t) for t in b) in true
+                            for a, b in splits])
+        assert is_true.sum() == 9 and scores[is_true].max() < scores[~is_true].min()
+        for i in (0, 300, 1200, 2034):          # 2|10, 3|9, 5|7 and 6|6 splits
+            oa = [names.index(t) for t in splits[i][0]]
+            ob = [names.index(t) for t in splits[i][1]]
+            M = O.reduced_flattening_packed(keys, cnt.astype(np.float64), n, oa, ob)[0]
+            assert abs(O.dense_split_score(M) - scores[i]) <= SCORE_TOL, (length, i, M.shape)
+        # the multi-alignment entry point + hand-back on the same table
+        again = sp.score_splits(dev, splits[1900:2035])
+        assert np.array_equal(again, scores[1900:2035])
