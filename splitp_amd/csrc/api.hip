@@ -270,6 +270,8 @@ extern "C" int sp_alignment_destroy(sp_alignment* al) {
     al->counts.release();
     al->keys32.release();
     al->spk_meta.release();
+    al->spk_keys.release();
+    al->spk_counts.release();
     al->moments.release();
     delete al;
     return SP_OK;
@@ -584,20 +586,72 @@ static int mark_upload(sp_ctx* ctx) {
     return SP_OK;
 }
 
+// Rows of the table the sparse kernel sees: D, plus one row per further 65535 of every count >= 2^16 (common.h).  The
+// first call for an alignment with such counts copies the counts to the host once.
+static int sparse_rows(sp_alignment* al, int64_t* rows) {
+    if (al->spk_D < 0) {
+        if (!al->exact || al->D == 0 || al->max_count < 65536u) {
+            al->spk_D = al->D;
+        } else {
+            std::vector<u32> hc((size_t)al->D);
+            SP_HIP(hipMemcpy(hc.data(), al->counts.p, (size_t)al->D * 4, hipMemcpyDeviceToHost));
+            int64_t extra = 0;
+            for (u32 c : hc) extra += c >= 65536u ? (int64_t)((c + 65534u) / 65535u) - 1 : 0;
+            al->spk_D = al->D + extra;
+        }
+    }
+    *rows = al->spk_D;
+    return SP_OK;
+}
+
+static int prepare_sparse_table(sp_ctx* ctx, sp_alignment* al) {
+    SP_REQUIRE(al->n_taxa <= 16, SP_ELIMIT, "sparse route: at most 16 taxa");
+    int64_t rows = 0;
+    SP_CHECK(sparse_rows(al, &rows));
+    unsigned long long trace = 0;
+    const u64* keys = al->keys.as<u64>();
+    const u32* counts = al->counts.as<u32>();
+    if (rows != al->D) {   // expand on the host (a few dozen patterns at most carry such counts)
+        std::vector<u64> hk((size_t)al->D), ek;
+        std::vector<u32> hc((size_t)al->D), ec;
+        SP_HIP(hipMemcpy(hk.data(), al->keys.p, (size_t)al->D * 8, hipMemcpyDeviceToHost));
+        SP_HIP(hipMemcpy(hc.data(), al->counts.p, (size_t)al->D * 4, hipMemcpyDeviceToHost));
+        ek.reserve((size_t)rows);
+        ec.reserve((size_t)rows);
+        for (int64_t i = 0; i < al->D; ++i) {
+            u32 c = hc[i];
+            trace += (unsigned long long)c * c;
+            do {
+                const u32 piece = c > 65535u ? 65535u : c;
+                ek.push_back(hk[i]);
+                ec.push_back(piece);
+                c -= piece;
+            } while (c > 0);
+        }
+        SP_REQUIRE((int64_t)ek.size() == rows, SP_EINVAL, "expanded table has %zu rows, expected %lld", ek.size(),
+                   (long long)rows);
+        SP_CHECK(al->spk_keys.ensure((size_t)rows * 8));
+        SP_CHECK(al->spk_counts.ensure((size_t)rows * 4));
+        SP_HIP(hipMemcpy(al->spk_keys.p, ek.data(), (size_t)rows * 8, hipMemcpyHostToDevice));
+        SP_HIP(hipMemcpy(al->spk_counts.p, ec.data(), (size_t)rows * 4, hipMemcpyHostToDevice));
+        keys = al->spk_keys.as<u64>();
+        counts = al->spk_counts.as<u32>();
+    }
+    SP_CHECK(al->keys32.ensure((size_t)std::max<int64_t>(rows, 1) * 4));
+    SP_CHECK(al->spk_meta.ensure(sizeof(SpkMeta)));
+    SP_CHECK(launch_sparse_meta(ctx, keys, counts, rows, al->keys32.as<u32>(), al->spk_meta.as<SpkMeta>(), trace));
+    SP_CHECK(mark_upload(ctx));
+    al->spk_ready = true;
+    return SP_OK;
+}
+
 static int upload_aldescs(sp_ctx* ctx, sp_alignment* const* als, int n_al) {
     std::vector<AlDesc> d((size_t)n_al);
     for (int i = 0; i < n_al; ++i) {
         sp_alignment* al = als[i];
-        if (!al->spk_ready) {   // one-time, on the stream: 32-bit keys, trace, largest counts
-            SP_REQUIRE(al->n_taxa <= 16, SP_ELIMIT, "sparse route: at most 16 taxa");
-            SP_CHECK(al->keys32.ensure((size_t)std::max<int64_t>(al->D, 1) * 4));
-            SP_CHECK(al->spk_meta.ensure(sizeof(SpkMeta)));
-            SP_CHECK(launch_sparse_meta(ctx, al->keys.as<u64>(), al->counts.as<u32>(), al->D, al->keys32.as<u32>(),
-                                        al->spk_meta.as<SpkMeta>()));
-            SP_CHECK(mark_upload(ctx));
-            al->spk_ready = true;
-        }
-        d[i] = AlDesc{al->keys32.as<u32>(), al->counts.as<u32>(), al->spk_meta.as<SpkMeta>(), al->D};
+        if (!al->spk_ready) SP_CHECK(prepare_sparse_table(ctx, al));   // one-time: 32-bit keys, trace, largest counts
+        d[i] = AlDesc{al->keys32.as<u32>(), al->spk_D != al->D ? al->spk_counts.as<u32>() : al->counts.as<u32>(),
+                      al->spk_meta.as<SpkMeta>(), al->spk_D};
     }
     if (ctx->aldescs_host.size() == d.size() && ctx->aldescs.p &&
         memcmp(ctx->aldescs_host.data(), d.data(), d.size() * sizeof(AlDesc)) == 0)
@@ -653,8 +707,8 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
                 fit.push_back(i);
                 bmw = std::max<int64_t>(bmw, (int64_t)plan.splits[i].rw + plan.splits[i].cw);
             }
-        if (!fit.empty() && al->D <= 65535) {
-            const size_t slab = (sparse_slab_bytes(al->D, bmw) + 255) & ~(size_t)255;
+        if (!fit.empty() && al->spk_D <= 65535) {
+            const size_t slab = (sparse_slab_bytes(al->spk_D, bmw) + 255) & ~(size_t)255;
             const size_t chunk = std::max<size_t>(1, std::min<size_t>(fit.size(), ((size_t)2 << 30) / slab));
             DevBuf slabs, fidx;
             int rc2 = SP_OK;
@@ -766,9 +820,11 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
         if (!ctx->cache) ctx->cache = new PlanCache();
         PlanCache& pc = *ctx->cache;
         const size_t nt = (size_t)n_splits * al->n_taxa;
-        const bool sparse_ok = al->exact && al->max_count < 65536u && al->D <= 65535 && al->n_taxa <= 16;
+        int64_t srows = 0;
+        SP_CHECK(sparse_rows(al, &srows));
+        const bool sparse_ok = al->exact && srows <= 65535 && al->n_taxa <= 16;
         SP_REQUIRE(method != SP_METHOD_FLATTENING_SPARSE || sparse_ok, SP_ELIMIT,
-                   "sparse route needs integer counts < 65536 and at most 65535 patterns");
+                   "sparse route needs integer counts, at most 65535 table rows (counts >= 65536 take several) and at most 16 taxa");
         const bool use_sparse = method == SP_METHOD_FLATTENING_SPARSE ||
                                 (method == SP_METHOD_FLATTENING && sparse_ok && ctx->gram_mode == 0);
         const int nl = use_sparse ? -1 : limbs_for(al);
@@ -972,11 +1028,13 @@ extern "C" int sp_score_splits_async(sp_alignment* al, const int32_t* split_taxa
     SP_HIP(hipSetDevice(ctx->device));
     if (n_splits == 0) return SP_OK;
     SP_REQUIRE(al->D > 0, SP_EINVAL, "empty pattern table");
-    const bool sparse_ok = al->exact && al->max_count < 65536u && al->D <= 65535 && al->n_taxa <= 16;
+    int64_t srows = 0;
+    SP_CHECK(sparse_rows(al, &srows));
+    const bool sparse_ok = al->exact && srows <= 65535 && al->n_taxa <= 16;
     const bool want_sparse = method == SP_METHOD_FLATTENING_SPARSE ||
                              (method == SP_METHOD_FLATTENING && sparse_ok && ctx->gram_mode == 0);
     if (want_sparse) {
-        SP_REQUIRE(sparse_ok, SP_ELIMIT, "sparse route needs integer counts < 65536 and at most 65535 patterns");
+        SP_REQUIRE(sparse_ok, SP_ELIMIT, "sparse route needs integer counts, at most 65535 table rows (counts >= 65536 take several) and at most 16 taxa");
         if (!ctx->cache) ctx->cache = new PlanCache();
         PlanCache& pc = *ctx->cache;
         const size_t nt = (size_t)n_splits * al->n_taxa;
@@ -1017,8 +1075,10 @@ extern "C" int sp_score_splits_multi_async(sp_alignment* const* als, int n_al, c
     for (int i = 0; i < n_al; ++i) {
         SP_REQUIRE(als[i] && als[i]->ctx == ctx && als[i]->n_taxa == al0->n_taxa, SP_EINVAL,
                    "alignments of one multi call must share the context and the number of taxa");
-        SP_REQUIRE(als[i]->exact && als[i]->max_count < 65536u && als[i]->D <= 65535 && als[i]->D > 0 && als[i]->n_taxa <= 16, SP_ELIMIT,
-                   "multi-alignment scoring uses the sparse route: integer counts < 65536, 1..65535 patterns");
+        int64_t srows = 0;
+        if (als[i]) SP_CHECK(sparse_rows(als[i], &srows));
+        SP_REQUIRE(als[i]->exact && srows <= 65535 && als[i]->D > 0 && als[i]->n_taxa <= 16, SP_ELIMIT,
+                   "multi-alignment scoring uses the sparse route: integer counts, 1..65535 table rows, at most 16 taxa");
         dmax = std::max(dmax, als[i]->D);
     }
     if (!ctx->cache) ctx->cache = new PlanCache();

@@ -110,6 +110,12 @@ struct sp_alignment {
     DevBuf keys32;   // u32[D]   sparse route: keys narrowed to 32 bits (n_taxa <= 16), filled on first use
     DevBuf spk_meta; // SpkMeta  sparse route: trace + largest counts, filled on first use
     bool spk_ready = false;
+    // counts >= 2^16 do not fit the 16-bit count field of the sparse kernel's list entries: such a pattern is entered as
+    // several table rows with the same key whose counts add up (every product is linear in the entries); spk_D = number
+    // of rows of that expanded table (-1: not computed yet), spk_keys / spk_counts hold it when it differs from the table
+    int64_t spk_D = -1;
+    DevBuf spk_keys;    // u64[spk_D]
+    DevBuf spk_counts;  // u32[spk_D], every value < 65536
     double sumsq_w = 0;  // sum of weights^2 (host-computed, informational)
     uint32_t max_count = 0;  // largest count (exact only): decides the number of 7-bit limbs of the int8 Gram
     // cached signed second-moment matrix (subflattening path)
@@ -196,7 +202,8 @@ size_t sparse_slab_bytes(int64_t D, int64_t bm_words);
 int launch_sparse_score_hbm(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, const SplitDev* splits_dev,
                             const int* order_dev, int64_t S_sub, int64_t S, double* scores, int* status,
                             unsigned char* slabs, size_t slab_bytes);
-int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta);
+int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta,
+                       unsigned long long trace_override);
 int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,
                         const int* order_dev, int64_t S, double* scores, int* status);
 template <typename T>

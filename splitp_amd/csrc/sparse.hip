@@ -876,10 +876,12 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
                     if (d0 + u >= steps) break;
                     const int rb = vb[u] & 0xFFFF;
                     const int cell = min(ra, rb) * R + max(ra, rb);
+                    // two different entries on the same row are the pieces of one large count: (c1 + c2)^2 has 2 c1 c2
+                    const u32 twice = (ra == rb && d0 + u > 0) ? 2u : 1u;
                     if (g32)
-                        atomicAdd(&G32[cell], ca * (vb[u] >> 16));
+                        atomicAdd(&G32[cell], twice * ca * (vb[u] >> 16));
                     else
-                        atomicAdd(&G64[cell], (unsigned long long)ca * (unsigned long long)(vb[u] >> 16));
+                        atomicAdd(&G64[cell], (unsigned long long)twice * ca * (unsigned long long)(vb[u] >> 16));
                 }
             }
         }
@@ -1026,8 +1028,11 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
 
 // Once per alignment: keys narrowed to 32 bits, trace = sum count^2, the SPK_NTOP largest counts (descending, ties by
 // lowest index).  One 1024-thread block; D <= 65535.
+// trace_override != 0: the table is an expanded one (large counts entered in pieces, common.h) and the caller supplies the
+// trace of the real counts.
 __global__ __launch_bounds__(1024) void k_sparse_meta(const u64* __restrict__ keys, const u32* __restrict__ counts, int D,
-                                                      u32* __restrict__ keys32, SpkMeta* __restrict__ meta) {
+                                                      u32* __restrict__ keys32, SpkMeta* __restrict__ meta,
+                                                      unsigned long long trace_override) {
     __shared__ unsigned long long red[16];
     __shared__ unsigned long long winner;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1044,7 +1049,7 @@ __global__ __launch_bounds__(1024) void k_sparse_meta(const u64* __restrict__ ke
     if (threadIdx.x == 0) {
         unsigned long long t = 0;
         for (int i = 0; i < 16; ++i) t += red[i];
-        meta->trace = t;
+        meta->trace = trace_override ? trace_override : t;
         meta->ntop = (u32)(D < SPK_NTOP ? D : SPK_NTOP);
         meta->pad = 0;
     }
@@ -1075,8 +1080,10 @@ __global__ __launch_bounds__(1024) void k_sparse_meta(const u64* __restrict__ ke
     }
 }
 
-int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta) {
-    hipLaunchKernelGGL(k_sparse_meta, dim3(1), dim3(1024), 0, ctx->stream, keys, counts, (int)D, keys32, meta);
+int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta,
+                       unsigned long long trace_override) {
+    hipLaunchKernelGGL(k_sparse_meta, dim3(1), dim3(1024), 0, ctx->stream, keys, counts, (int)D, keys32, meta,
+                       trace_override);
     SP_HIP(hipGetLastError());
     return SP_OK;
 }

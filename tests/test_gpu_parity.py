@@ -318,15 +318,31 @@ def test_routes_agree(sp, golden):
         assert np.array_equal(s_auto, s_sparse)
         for _ in range(3):
             assert np.array_equal(sp.score_splits(dev, splits, route="sparse"), s_sparse)
-    # hand-back: a table the sparse kernel cannot take (counts >= 65536) silently uses the dense route
+    # counts >= 65536 exceed the 16-bit count field of the list entries: such patterns enter as several table rows whose
+    # counts add up.  (a) a table that still fits LDS (short branches: few patterns, huge counts) - all size classes,
+    # including the small-side Gram where the pieces of one count meet on one row; (b) a 700 k-site table: too many
+    # rows for LDS, so "sparse" (strict) refuses and auto runs the global-memory form of the kernel
     from splitp_amd import synthetic as syn
+    sites = syn.simulate_sites(10, 600_000, 0.004, seed=8)
+    keys, counts = syn.pattern_table(sites)
+    assert counts.max() >= 2 * 65536 and len(keys) < 4000
+    small_big = sp.DeviceAlignment.from_arrays(keys, None, 10, counts=counts, n_sites=600_000, taxa=names)
+    s_sp, st_sp = sp.score_splits(small_big, splits, route="sparse", return_status=True)
+    assert np.all((st_sp & 3) == 0)
+    assert np.abs(s_sp - sp.score_splits(small_big, splits, route="dense")).max() <= SCORE_TOL
+    for i in (0, 30, 100, 300, 500):
+        M = O.reduced_flattening_packed(keys, counts.astype(np.float64), 10, [names.index(t) for t in splits[i][0]],
+                                        [names.index(t) for t in splits[i][1]])[0]
+        assert abs(O.dense_split_score(M) - s_sp[i]) <= SCORE_TOL
     sites = syn.simulate_sites(10, 700_000, 0.05, seed=8)
     keys, counts = syn.pattern_table(sites)
     assert counts.max() >= 65536
     big = sp.DeviceAlignment.from_arrays(keys, None, 10, counts=counts, n_sites=700_000, taxa=names)
     with pytest.raises(NotImplementedError):
         sp.score_splits(big, splits[:5], route="sparse")
-    sb = sp.score_splits(big, splits[::25])
+    sb, stb = sp.score_splits(big, splits[::25], return_status=True)
+    assert np.all((stb & 3) == 0) and np.all((stb >> 8) <= 8)          # scored by the sparse kernel (HBM form), not the dense route
+    assert np.abs(sb - sp.score_splits(big, splits[::25], route="dense")).max() <= SCORE_TOL
     for i, spl in enumerate(splits[::25][:4]):
         M = O.reduced_flattening_packed(keys, counts.astype(np.float64), 10, [names.index(t) for t in spl[0]],
                                         [names.index(t) for t in spl[1]])[0]
