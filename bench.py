@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--alignments", type=int, default=1, help="alignments scored per rank per step")
-    ap.add_argument("--lanes", type=int, default=3, help="steps in flight (one HIP stream + buffers each)")
+    ap.add_argument("--lanes", type=int, default=0, help="steps in flight (one HIP stream + buffers each); 0 = 3 on one GPU, 4 with RCCL")
     ap.add_argument("--debug-timeline", action="store_true", help="print host-side retire/launch times of the last steps")
     ap.add_argument("--spinup", type=float, default=1.0, help="seconds of untimed load before the warmup steps")
     ap.add_argument("--no-hipri", action="store_true", help="RCCL stream at normal priority (diagnostic)")
@@ -142,7 +142,8 @@ def main():
             self.done = torch.cuda.Event()
             self.busy = False
 
-    lanes = [Lane() for _ in range(max(1, args.lanes))]
+    # (one more lane with RCCL: the all-gather adds latency to every step, not work)
+    lanes = [Lane() for _ in range(args.lanes if args.lanes > 0 else (4 if world > 1 else 3))]
 
     def launch(lane):
         with torch.cuda.stream(lane.stream):

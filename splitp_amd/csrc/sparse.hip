@@ -568,7 +568,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SpkShared& sh = *reinterpret_cast<SpkShared*>(smem);
     unsigned char* const base = HBM ? slabs + (size_t)blockIdx.x * slab_bytes : smem;
-    const size_t cap = HBM ? slab_bytes : (size_t)SPK_LDS_BYTES;
+    const size_t cap = HBM ? slab_bytes : (slab_bytes ? slab_bytes : (size_t)SPK_LDS_BYTES);   // (LDS form: slab_bytes = debug cap)
     const int ai = blockIdx.x % n_al;
     const int sid = order[blockIdx.x / n_al];
     const u32* __restrict__ keys = als[ai].keys32;
@@ -1101,7 +1101,7 @@ int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa
     }
     hipLaunchKernelGGL(k_sparse_score<false>, dim3((unsigned)(S * n_al)), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream,
                        als_dev, n_al, n_taxa, splits_dev, order_dev, (int)S, scores, status, (unsigned char*)nullptr,
-                       (size_t)0);
+                       getenv("SPLITP_DEBUG_LDS_CAP") ? (size_t)atol(getenv("SPLITP_DEBUG_LDS_CAP")) : (size_t)0);
     SP_HIP(hipGetLastError());
     return SP_OK;
 }
