@@ -1,27 +1,29 @@
-// Sparse route: flattening + split score of one split entirely inside one workgroup's LDS.
+// Sparse route: flattening + split score of one split entirely inside one workgroup (LDS; global memory for big tables).
 //
 // Replaces, like the dense route, splitp/constructions.py:31-55 + splitp/phylogenetics.py:280-300 (and is
 // the device form of the reference's own sparse scorer, phylogenetics.py:303-312: top-4 singular values of
 // the sparse flattening + its Frobenius norm).  A flattening of a 100 k-site alignment has ~8 k non-zeros
 // in up to 10^6 cells, so instead of materialising the matrix (dense route: scatter -> Gram -> eigen, all
-// through HBM) the workgroup keeps the D non-zeros as CSC + CSR lists in LDS and runs block subspace
-// iteration on the implicit Gram operator:
-//       W = C^T V          (sparse, CSC: one 4-lane group per column, whole waves for heavy columns)
-//       Y = C W            (sparse, CSR)
+// through HBM) the workgroup keeps the D non-zeros as CSC + CSR lists and runs block subspace iteration on the
+// implicit Gram operator, one half product at a time:
+//       W = C^T V          (sparse, CSC)          Y = C W            (sparse, CSR)
+//   one lane per entry (all four columns), groups laid out by size class: a wave / a 16-lane row / a quad / a lane per
+//   group, partial sums combined with DPP;
 //   after EACH half product the Gram matrix of the fresh block (v_mfma_f64_4x4x4) gives a Ritz sum - its trace, the
 //   input block being orthonormal - and the Cholesky factor that re-orthonormalises the block (Cholesky-QR);
 //   the sums converge to the sum of the 4 largest squared singular values of C by (sigma_5 / sigma_4)^2 per half product
-//   score = sqrt(max(0, 1 - top4 / trace)),  trace = sum of count^2 (exact integer).
+//   score = sqrt(max(0, 1 - top4 / trace)),  trace = sum of count^2 (exact integer, k_sparse_meta).
 // Block width 4: on these matrices lambda_5..lambda_16 are of one magnitude, so guard vectors 5-8 buy almost
-// nothing (rate lambda_5/lambda_4 ~ 2e-3 vs lambda_9/lambda_4), while a 4-wide block halves every LDS array.
-// Small row sides (R <= 64, i.e. |A| <= 3 taxa) have a long column side whose W would not fit, but their
-// Gram matrix does: it is accumulated exactly (u64 LDS atomics over the pairs inside every column) and the
+// nothing (rate lambda_5/lambda_4 ~ 2e-3 vs lambda_9/lambda_4), while a 4-wide block halves every array.
+// Small row sides (<= 64 ids, i.e. |A| <= 3 taxa) have a long column side whose W would not fit, but their
+// Gram matrix does: it is accumulated exactly (integer atomics over the pairs inside every column) and the
 // iteration runs on it densely.
 //
-// Everything is deterministic: the lists are ordered by a bitmap-rank construction (no atomic append), sums
-// run in a fixed order, heavy columns are reduced by a fixed shuffle tree, the Gram accumulation is integer.
-// A split whose lists / blocks do not fit the 160 KiB of LDS, or that has not converged after SPK_MAXIT
-// products, is flagged (status bit 1) and re-scored by the caller on the dense route.
+// Every group is summed in table order (stable counting sort with wave-private counters) and every reduction has a
+// fixed tree, the Gram accumulation is integer: results are reproducible bit for bit.  Which group sits where inside a
+// size class depends on the arrival order of aggregated atomics - that moves groups around, never a sum.
+// A split whose arrays do not fit the 160 KiB of LDS is flagged (status 2) and re-run by the same kernel instantiated on
+// a slab of global memory (HBM = true); one that has not converged after SPK_MAXIT products goes to the dense route.
 #include "common.h"
 
 #define SPK_THREADS 512
@@ -29,7 +31,7 @@
 #define SPK_NB 4
 #define SPK_VP 5            // row pitch of V / Y in doubles
 #ifndef SPK_TEAM_MAX
-#define SPK_TEAM_MAX 32     // a column / row with more entries than this is shared by the 4 teams of a 16-lane row
+#define SPK_TEAM_MAX 32     // a column / row with more entries than this is shared by the 16 lanes of a row (9..32: a quad)
 #endif
 #ifndef SPK_ROW_MAX
 #define SPK_ROW_MAX 64      // ... and with more than this by the 64 lanes of a wave
@@ -939,9 +941,12 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         double amp[SPK_NB];
 #pragma unroll
         for (int k = 0; k < SPK_NB; ++k) amp[k] = nscale * (double)top_cnt[k];
-        for (int c = threadIdx.x; c < Kc; c += SPK_THREADS) {
+        for (int c = threadIdx.x; c < Kc; c += SPK_THREADS) {   // one 32-bit hash per row, a signed byte of it per column
+            u32 h = (u32)c * 0x9E3779B1u + 0x7F4A7C15u;
+            h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
 #pragma unroll
-            for (int k = 0; k < SPK_NB; ++k) Wb[c * wp + k] = amp[k] * spk_hash(c, k);
+            for (int k = 0; k < SPK_NB; ++k)
+                Wb[c * wp + k] = amp[k] * (double)((float)((int)(h << (8 * k)) >> 24) * (1.0f / 128.0f));
         }
         for (int idx = threadIdx.x; idx < R; idx += SPK_THREADS) {   // where do the 4 rows sit in the CSR layout?
             const int m = perm_r[idx];
