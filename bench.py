@@ -97,9 +97,12 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        opts = dist.ProcessGroupNCCL.Options()
-        opts.is_high_priority_stream = not args.no_hipri   # the all-gather competes with queued scoring workgroups
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
+        try:
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = not args.no_hipri   # the all-gather competes with queued scoring workgroups
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
+        except (TypeError, AttributeError):                     # older / newer torch without these options
+            dist.init_process_group("nccl")
     else:
         torch.cuda.set_device(0)
     dev_t = torch.device("cuda", torch.cuda.current_device())

@@ -621,3 +621,49 @@ def test_config5_shape_12_taxa(sp):
         # the multi-alignment entry point + hand-back on the same table
         again = sp.score_splits(dev, splits[1900:2035])
         assert np.array_equal(again, scores[1900:2035])
+
+
+def test_sparse_kernel_edge_tables(sp):
+    """Small and odd tables through the batched entry point (LDS form, its small-side path and the global-memory form):
+    a single pattern, fewer than 5 patterns (min(shape) <= 4: exactly 0 like the reference), an all-constant alignment,
+    3 and 4 taxa, and a 16-taxon table (largest n of the sparse kernel) against the oracle."""
+    from splitp_amd import synthetic as syn
+
+    # 4 taxa, the reference's own table: every flattening is 4 x 4 -> 0.0
+    dev4 = sp.DeviceAlignment.from_table(REF4_TABLE, taxa=("0", "1", "2", "3"))
+    s4 = sp.score_splits(dev4, [(("0", "1"), ("2", "3")), (("0", "2"), ("1", "3")), (("0",), ("1", "2", "3"))])
+    assert np.array_equal(s4, np.zeros(3))
+    # one pattern / all-constant alignment: rank 1 -> 0.0
+    one = sp.DeviceAlignment.from_table({"ACGTAC": 1.0}, taxa=tuple("012345"))
+    assert sp.score_splits(one, [(("0", "1", "2"), ("3", "4", "5"))])[0] == 0.0
+    const = sp.DeviceAlignment.from_table({"AAAAAA": 0.25, "CCCCCC": 0.25, "GGGGGG": 0.25, "TTTTTT": 0.25}, taxa=tuple("012345"))
+    assert sp.score_splits(const, [(("0", "1", "2"), ("3", "4", "5")), (("0", "1"), ("2", "3", "4", "5"))]).max() == 0.0
+    # 6 taxa, short alignment: every split, LDS form, against the oracle (includes 5 x 5 .. 64 x 64 used shapes)
+    names = taxa_names(6)
+    keys, counts = syn.pattern_table(syn.simulate_sites(6, 3000, 0.3, seed=2))
+    dev6 = sp.DeviceAlignment.from_arrays(keys, None, 6, counts=counts, n_sites=3000, taxa=names)
+    splits6 = list(sp.all_splits(names))
+    s6, st6 = sp.score_splits(dev6, splits6, return_status=True)
+    assert np.all((st6 & 3) == 0)
+    for i, spl in enumerate(splits6):
+        M = O.reduced_flattening_packed(keys, counts.astype(np.float64), 6, [names.index(t) for t in spl[0]],
+                                        [names.index(t) for t in spl[1]])[0]
+        want = 0.0 if min(M.shape) <= 4 else O.dense_split_score(M)
+        assert abs(want - s6[i]) <= SCORE_TOL, (i, M.shape)
+    # 16 taxa (32-bit keys exactly full), 4000 sites: balanced 8|8 splits need the global-memory form
+    g_names = taxa_names(16)
+    keys, counts = syn.pattern_table(syn.simulate_sites(16, 4000, 0.05, seed=4))
+    dev16 = sp.DeviceAlignment.from_arrays(keys, None, 16, counts=counts, n_sites=4000, taxa=g_names)
+    rng = np.random.default_rng(0)
+    some = []
+    for k in (2, 5, 8):
+        left = sorted(rng.choice(16, size=k, replace=False).tolist())
+        some.append((tuple(g_names[t] for t in left), tuple(g_names[t] for t in range(16) if t not in left)))
+    tree_split = (tuple(g_names[:8]), tuple(g_names[8:]))
+    some.append(tree_split)
+    s16, st16 = sp.score_splits(dev16, some, return_status=True)
+    assert np.all((st16 & 3) == 0)
+    for i, spl in enumerate(some):
+        M = O.reduced_flattening_packed(keys, counts.astype(np.float64), 16, [g_names.index(t) for t in spl[0]],
+                                        [g_names.index(t) for t in spl[1]])[0]
+        assert abs(O.dense_split_score(M) - s16[i]) <= SCORE_TOL, (i, M.shape)
