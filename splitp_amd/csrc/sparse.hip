@@ -29,7 +29,6 @@
 #define SPK_THREADS 512
 #define SPK_WAVES 8
 #define SPK_NB 4
-#define SPK_VP 5            // row pitch of V / Y in doubles
 #ifndef SPK_TEAM_MAX
 #define SPK_TEAM_MAX 32     // a column / row with more entries than this is shared by the 16 lanes of a row (9..32: a quad)
 #endif
@@ -128,13 +127,13 @@ __device__ __forceinline__ u32 bm_rank(const u64* bm, const u32* pf, u32 k) {
 // 4 x 4 x 4) consumes 16 rows; lane l supplies X[base + l/4][l%4] as BOTH operands (A[i][k] of block b sits in lane
 // i + 4b + 16k, B[k][j] in lane j + 4b + 16k - probed, tools/mfma_f64_4x4_probe.hip), D[i][j] of block b comes back in
 // lane j + 4b + 16i.  Blocks are summed with two shuffles, waves through LDS in a fixed order.  Ends with a barrier.
-__device__ __forceinline__ void spk_gram(const double* X, int rows, int pitch, SpkShared& sh) {
+__device__ __forceinline__ void spk_gram(const double* X, int rows, int rs, int cs, SpkShared& sh) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = lane & 3, rl = lane >> 2;
     double acc = 0.0;
     for (int base = w * 16; base < rows; base += SPK_WAVES * 16) {
         const int row = base + rl;
-        const double x = row < rows ? X[row * pitch + c] : 0.0;
+        const double x = row < rows ? X[row * rs + c * cs] : 0.0;
         acc = __builtin_amdgcn_mfma_f64_4x4x4f64(x, x, acc, 0, 0, 0);
     }
     acc += __shfl_xor(acc, 4, 64);
@@ -152,7 +151,7 @@ __device__ __forceinline__ void spk_gram(const double* X, int rows, int pitch, S
 // Cholesky-QR step: S = L L^T (sh.S, every thread redundantly in registers), X <- X L^-T by forward substitution per
 // row, so that X^T X = I.  A pivot below 1e-28 of the largest diagonal marks a dead direction (rank < 4): its column
 // becomes zero and stays zero.  Returns min pivot / max pivot (conditioning indicator).  Ends with a barrier.
-__device__ __forceinline__ double spk_chol_apply(double* X, int rows, int pitch, const SpkShared& sh) {
+__device__ __forceinline__ double spk_chol_apply(double* X, int rows, int rs, int cs, const SpkShared& sh) {
     const double s00 = sh.S[0], s10 = sh.S[4], s20 = sh.S[8], s30 = sh.S[12];
     const double s11 = sh.S[5], s21 = sh.S[9], s31 = sh.S[13], s22 = sh.S[10], s32 = sh.S[14], s33 = sh.S[15];
     const double dmax = fmax(fmax(s00, s11), fmax(s22, s33));
@@ -171,12 +170,12 @@ __device__ __forceinline__ double spk_chol_apply(double* X, int rows, int pitch,
     const double i3 = d3 > tiny ? spk_rsqrt(d3) : 0.0;
     pmin = fmin(fmin(d0 > tiny ? d0 : dmax, d1 > tiny ? d1 : dmax), fmin(d2 > tiny ? d2 : dmax, d3 > tiny ? d3 : dmax));
     for (int row = threadIdx.x; row < rows; row += SPK_THREADS) {
-        double* x = X + row * pitch;
+        double* x = X + row * rs;
         const double v0 = x[0] * i0;
-        const double v1 = fma(-l10, v0, x[1]) * i1;
-        const double v2 = fma(-l21, v1, fma(-l20, v0, x[2])) * i2;
-        const double v3 = fma(-l32, v2, fma(-l31, v1, fma(-l30, v0, x[3]))) * i3;
-        x[0] = v0; x[1] = v1; x[2] = v2; x[3] = v3;
+        const double v1 = fma(-l10, v0, x[cs]) * i1;
+        const double v2 = fma(-l21, v1, fma(-l20, v0, x[2 * cs])) * i2;
+        const double v3 = fma(-l32, v2, fma(-l31, v1, fma(-l30, v0, x[3 * cs]))) * i3;
+        x[0] = v0; x[cs] = v1; x[2 * cs] = v2; x[3 * cs] = v3;
     }
     __syncthreads();
     return dmax > 0 ? pmin / dmax : 1.0;
@@ -185,11 +184,11 @@ __device__ __forceinline__ double spk_chol_apply(double* X, int rows, int pitch,
 // Orthonormalise the block in place (its Gram matrix is already in sh.S).  One Cholesky-QR pass leaves
 // |X^T X - I| ~ eps * cond(S); count flattenings have four leading singular values of one magnitude (cond < 100), so
 // one pass is enough; an ill-conditioned block (pivot ratio < 0.05) gets up to two more passes (CholeskyQR2/3).
-__device__ __forceinline__ void spk_orth(double* X, int rows, int pitch, SpkShared& sh) {
-    double ratio = spk_chol_apply(X, rows, pitch, sh);
+__device__ __forceinline__ void spk_orth(double* X, int rows, int rs, int cs, SpkShared& sh) {
+    double ratio = spk_chol_apply(X, rows, rs, cs, sh);
     for (int pass = 0; pass < 2 && ratio < 0.05; ++pass) {
-        spk_gram(X, rows, pitch, sh);
-        ratio = spk_chol_apply(X, rows, pitch, sh);
+        spk_gram(X, rows, rs, cs, sh);
+        ratio = spk_chol_apply(X, rows, rs, cs, sh);
     }
 }
 
@@ -408,7 +407,7 @@ __device__ __forceinline__ double spk_dpp(double x) {
 // the caller guarantees (p1 - start) / step is a multiple of U (no tail).
 template <int U, bool PRED>
 __device__ __forceinline__ void spk_lane_sum(const u32* ent, int start, int step, int p1, const char* in,
-                                             int pitch_bytes, double (&a)[4]) {
+                                             int pitch_bytes, int cs, double (&a)[4]) {
     for (int e = start; e < p1; e += U * step) {
         u32 v[U];
 #pragma unroll
@@ -420,7 +419,7 @@ __device__ __forceinline__ void spk_lane_sum(const u32* ent, int start, int step
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const double* row = reinterpret_cast<const double*>(in + (v[u] & 0xFFFFu) * pitch_bytes);
-            x[u][0] = row[0]; x[u][1] = row[1]; x[u][2] = row[2]; x[u][3] = row[3];
+            x[u][0] = row[0]; x[u][1] = row[cs]; x[u][2] = row[2 * cs]; x[u][3] = row[3 * cs];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -433,13 +432,14 @@ __device__ __forceinline__ void spk_lane_sum(const u32* ent, int start, int step
     }
 }
 
-__device__ __forceinline__ void spk_store4(double* out, const double (&a)[4]) {
-    out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; out[3] = a[3];
+__device__ __forceinline__ void spk_store4(double* out, int cs, const double (&a)[4]) {
+    out[0] = a[0]; out[cs] = a[1]; out[2 * cs] = a[2]; out[3 * cs] = a[3];
 }
 
 __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* ent, int nmajor,
                                          const unsigned short* perm, int nwave, int nrow, int nquad, const double* in_d,
-                                         int in_pitch, double* out, int out_pitch, int stamp_at = -1) {
+                                         int in_pitch, int in_cs, double* out, int out_pitch, int out_cs,
+                                         int stamp_at = -1) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const char* in = reinterpret_cast<const char*>(in_d);
     const int pb = in_pitch * 8;
@@ -447,9 +447,9 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
         const int p0 = ptrp[idx], p1 = ptrp[idx + 1], m = perm[idx];
         double a[4] = {0, 0, 0, 0};
         if (p1 - p0 <= 128)   // (uniform: one group per wave)
-            spk_lane_sum<2, true>(ent, p0 + lane, 64, p1, in, pb, a);
+            spk_lane_sum<2, true>(ent, p0 + lane, 64, p1, in, pb, in_cs, a);
         else
-            spk_lane_sum<4, true>(ent, p0 + lane, 64, p1, in, pb, a);
+            spk_lane_sum<4, true>(ent, p0 + lane, 64, p1, in, pb, in_cs, a);
 #ifndef SPK_NOREDUCE
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -461,7 +461,7 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
             a[c] += __shfl_xor(a[c], 32, 64);
         }
 #endif
-        if (lane == 63) spk_store4(out + m * out_pitch, a);
+        if (lane == 63) spk_store4(out + m * out_pitch, out_cs, a);
     }
 #ifdef SPK_STAMPS
     if (stamp_at >= 0) SSTAMP(stamp_at + 10);
@@ -471,7 +471,7 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
         for (int idx = nwave + row; idx < nwave + nrow; idx += SPK_THREADS / 16) {
             const int p0 = ptrp[idx], p1 = ptrp[idx + 1], m = perm[idx];
             double a[4] = {0, 0, 0, 0};
-            spk_lane_sum<SPK_UW, true>(ent, p0 + t, 16, p1, in, pb, a);
+            spk_lane_sum<SPK_UW, true>(ent, p0 + t, 16, p1, in, pb, in_cs, a);
 #ifndef SPK_NOREDUCE
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -481,7 +481,7 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
                 a[c] += spk_dpp<SPK_DPP_ROW_SHR8>(a[c]);
             }
 #endif
-            if (t == 15) spk_store4(out + m * out_pitch, a);
+            if (t == 15) spk_store4(out + m * out_pitch, out_cs, a);
         }
     }
 #ifdef SPK_STAMPS
@@ -493,13 +493,13 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
         for (int idx = q0 + quad; idx < q0 + nquad; idx += SPK_THREADS / 4) {
             const int p0 = ptrp[idx], p1 = ptrp[idx + 1], m = perm[idx];
             double a[4] = {0, 0, 0, 0};
-            spk_lane_sum<SPK_UW, true>(ent, p0 + t, 4, p1, in, pb, a);
+            spk_lane_sum<SPK_UW, true>(ent, p0 + t, 4, p1, in, pb, in_cs, a);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 a[c] += spk_dpp<SPK_DPP_QUAD_XOR1>(a[c]);
                 a[c] += spk_dpp<SPK_DPP_QUAD_XOR2>(a[c]);
             }
-            if (t == 0) spk_store4(out + m * out_pitch, a);
+            if (t == 0) spk_store4(out + m * out_pitch, out_cs, a);
         }
     }
 #ifdef SPK_STAMPS
@@ -510,14 +510,14 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
         double a[4] = {0, 0, 0, 0};
         // the classes are sorted, so the lanes of a wave hold groups of (nearly) one size
         if (__ballot(len > 4))
-            spk_lane_sum<SPK_UW, true>(ent, p0, 1, p1, in, pb, a);
+            spk_lane_sum<SPK_UW, true>(ent, p0, 1, p1, in, pb, in_cs, a);
         else if (__ballot(len > 2))
-            spk_lane_sum<4, true>(ent, p0, 1, p1, in, pb, a);
+            spk_lane_sum<4, true>(ent, p0, 1, p1, in, pb, in_cs, a);
         else if (__ballot(len != 1) == 0)
-            spk_lane_sum<1, false>(ent, p0, 1, p1, in, pb, a);
+            spk_lane_sum<1, false>(ent, p0, 1, p1, in, pb, in_cs, a);
         else
-            spk_lane_sum<2, true>(ent, p0, 1, p1, in, pb, a);
-        spk_store4(out + m * out_pitch, a);
+            spk_lane_sum<2, true>(ent, p0, 1, p1, in, pb, in_cs, a);
+        spk_store4(out + m * out_pitch, out_cs, a);
     }
     __syncthreads();
 }
@@ -743,12 +743,12 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     unsigned short* perm_r = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)R * 2));
     unsigned short* csc_ptr = small ? reinterpret_cast<unsigned short*>(carve_top((size_t)(Kc + 1) * 2)) : nullptr;
     const size_t build_end = reinterpret_cast<unsigned char*>(bm) - base;
-    // W row pitch: 5 doubles when LDS allows it (rows start on 32 different bank offsets instead of 8: the gathers
-    // of Y = C W hit random rows), 4 otherwise
-    size_t top_probe = top;
-    const size_t base_iter = off_after_lists + (size_t)Rp * SPK_VP * 8 + 16;
-    const int wp = (!small && base_iter + (size_t)Kc * 5 * 8 <= top_probe) ? 5 : 4;
-    const size_t need_iter = base_iter + (small ? (size_t)R * R * 8 : (size_t)Kc * wp * 8);
+    // V and W are column-major: four arrays of Rp / Kcp doubles.  A lane's four gathers then go to four arrays -
+    // measured 9 % faster than four consecutive doubles of one row (fewer LDS bank conflicts), and no row padding.
+    const int Kcp = (Kc + 3) & ~3;
+    const int v_rs = 1, v_cs = Rp, w_rs = 1, w_cs = Kcp;
+    const size_t base_iter = off_after_lists + (size_t)Rp * 4 * 8 + 16;
+    const size_t need_iter = base_iter + (small ? (size_t)R * R * 8 : (size_t)Kcp * 4 * 8);
     // counters: SPK_WAVES rows of 16-bit (8-bit when a group cannot exceed 255 entries) fields
     const bool bits8 = small;   // a column has at most R <= 64 entries
     const size_t cw_c = (size_t)SPK_WAVES * ((Kc + (bits8 ? 3 : 1)) / (bits8 ? 4 : 2)) * 4;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     SSTAMP(4);
     // V and W / G are laid out over the (now dead) staging area
     off = off_after_lists;
-    double* V = reinterpret_cast<double*>(carve((size_t)Rp * SPK_VP * 8));
+    double* V = reinterpret_cast<double*>(carve((size_t)Rp * 4 * 8));
     double* Wb = reinterpret_cast<double*>(base + off);   // large: W (Kc x 4);  small: G (R x R)
     if (small) {
         // exact Gram G = C C^T: all pairs of entries inside every column, accumulated with integer LDS atomics (exact,
@@ -927,15 +927,14 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0;
     int it = 0, conv = 0;
     if (small) {
-        for (int e = threadIdx.x; e < Rp * SPK_VP; e += SPK_THREADS) V[e] = 0.0;
-        __syncthreads();
         for (int i = threadIdx.x; i < R; i += SPK_THREADS) {
 #pragma unroll
-            for (int k = 0; k < SPK_NB; ++k) V[i * SPK_VP + k] = 0.02 * spk_hash(i, k) + (top_row[k] == i ? 1.0 : 0.0);
+            for (int k = 0; k < SPK_NB; ++k)
+                V[i * v_rs + k * v_cs] = 0.02 * spk_hash(i, k) + (top_row[k] == i ? 1.0 : 0.0);
         }
         __syncthreads();
-        spk_gram(V, R, SPK_VP, sh);
-        spk_orth(V, R, SPK_VP, sh);
+        spk_gram(V, R, v_rs, v_cs, sh);
+        spk_orth(V, R, v_rs, v_cs, sh);
     } else {
         const double nscale = 0.01 * spk_rsqrt((double)Kc / 3.0);
         double amp[SPK_NB];
@@ -946,7 +945,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
 #pragma unroll
             for (int k = 0; k < SPK_NB; ++k)
-                Wb[c * wp + k] = amp[k] * (double)((float)((int)(h << (8 * k)) >> 24) * (1.0f / 128.0f));
+                Wb[c * w_rs + k * w_cs] = amp[k] * (double)((float)((int)(h << (8 * k)) >> 24) * (1.0f / 128.0f));
         }
         for (int idx = threadIdx.x; idx < R; idx += SPK_THREADS) {   // where do the 4 rows sit in the CSR layout?
             const int m = perm_r[idx];
@@ -961,12 +960,12 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             const int p0 = desc_r[idx], p1 = desc_r[idx + 1];
             for (int e = p0 + (int)threadIdx.x; e < p1; e += SPK_THREADS) {
                 const u32 v = csr_ent[e];
-                Wb[(v & 0xFFFFu) * wp + k] = (double)(v >> 16);
+                Wb[(v & 0xFFFFu) * w_rs + k * w_cs] = (double)(v >> 16);
             }
         }
         __syncthreads();
-        spk_gram(Wb, Kc, wp, sh);
-        spk_orth(Wb, Kc, wp, sh);
+        spk_gram(Wb, Kc, w_rs, w_cs, sh);
+        spk_orth(Wb, Kc, w_rs, w_cs, sh);
     }
     SSTAMP(5);
     SSTAMP(6);
@@ -976,13 +975,13 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             const int row = threadIdx.x >> 2, j = threadIdx.x & 3;
             double acc = 0, part = 0;
             if (row < R) {
-                for (int k = 0; k < R; ++k) acc = fma(Wb[row * R + k], V[k * SPK_VP + j], acc);
-                part = acc * V[row * SPK_VP + j];
+                for (int k = 0; k < R; ++k) acc = fma(Wb[row * R + k], V[k * v_rs + j * v_cs], acc);
+                part = acc * V[row * v_rs + j * v_cs];
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
             __syncthreads();
-            if (row < R) V[row * SPK_VP + j] = acc;
+            if (row < R) V[row * v_rs + j * v_cs] = acc;
             if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = part;
             __syncthreads();
             top4 = ((sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3])) + ((sh.red[4] + sh.red[5]) + (sh.red[6] + sh.red[7]));
@@ -990,31 +989,33 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
                 conv = 1;
                 break;
             }
-            spk_gram(V, R, SPK_VP, sh);
-            spk_orth(V, R, SPK_VP, sh);
+            spk_gram(V, R, v_rs, v_cs, sh);
+            spk_orth(V, R, v_rs, v_cs, sh);
         }
     } else {
         SSTAMP(7);
         for (it = 2; it <= 2 * SPK_MAXIT; ++it) {
             double* X;
-            int rows, pitch;
+            int rows, xrs, xcs;
             if (it & 1) {
-                spk_spmm(desc_c, csc_ent, Kc, perm_c, sh.nw_c, sh.nr_c, sh.nq_c, V, SPK_VP, Wb, wp, it == 3 ? 20 : -1);   // W = C^T V
-                X = Wb; rows = Kc; pitch = wp;
+                spk_spmm(desc_c, csc_ent, Kc, perm_c, sh.nw_c, sh.nr_c, sh.nq_c, V, v_rs, v_cs, Wb, w_rs, w_cs,
+                         it == 3 ? 20 : -1);   // W = C^T V
+                X = Wb; rows = Kc; xrs = w_rs; xcs = w_cs;
             } else {
-                spk_spmm(desc_r, csr_ent, R, perm_r, sh.nw_r, sh.nr_r, sh.nq_r, Wb, wp, V, SPK_VP, it == 2 ? 21 : -1);    // Y = C W
-                X = V; rows = R; pitch = SPK_VP;
+                spk_spmm(desc_r, csr_ent, R, perm_r, sh.nw_r, sh.nr_r, sh.nq_r, Wb, w_rs, w_cs, V, v_rs, v_cs,
+                         it == 2 ? 21 : -1);   // Y = C W
+                X = V; rows = R; xrs = v_rs; xcs = v_cs;
             }
             if (it == 2) SSTAMP(9);
             if (it == 3) SSTAMP(8);
-            spk_gram(X, rows, pitch, sh);
+            spk_gram(X, rows, xrs, xcs, sh);
             if (it == 2) SSTAMP(40);
             top4 = (sh.S[0] + sh.S[5]) + (sh.S[10] + sh.S[15]);
             if (spk_converged(top4, it - 1, prev_sum, prev_delta, prev_ratio)) {   // (the first real Ritz sum is that of half product 2)
                 conv = 1;
                 break;
             }
-            spk_orth(X, rows, pitch, sh);
+            spk_orth(X, rows, xrs, xcs, sh);
             if (it == 2) SSTAMP(41);
         }
     }
