@@ -33,7 +33,7 @@
 #define SPK_TEAM_MAX 32     // a column / row with more entries than this is shared by the 16 lanes of a row (9..32: a quad)
 #endif
 #ifndef SPK_ROW_MAX
-#define SPK_ROW_MAX 64      // ... and with more than this by the 64 lanes of a wave
+#define SPK_ROW_MAX 128     // ... and with more than this by the 64 lanes of a wave
 #endif
 #define SPK_MAXIT 40
 #define SPK_LDS_BYTES 163840
