@@ -745,10 +745,13 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     const size_t build_end = reinterpret_cast<unsigned char*>(bm) - base;
     // V and W are column-major: four arrays of Rp / Kcp doubles.  A lane's four gathers then go to four arrays -
     // measured 9 % faster than four consecutive doubles of one row (fewer LDS bank conflicts), and no row padding.
-    const int Kcp = (Kc + 3) & ~3;
-    const int v_rs = 1, v_cs = Rp, w_rs = 1, w_cs = Kcp;
-    const size_t base_iter = off_after_lists + (size_t)Rp * 4 * 8 + 16;
-    const size_t need_iter = base_iter + (small ? (size_t)R * R * 8 : (size_t)Kcp * 4 * 8);
+    // (+ 4: the four columns of one row start on different banks - the dense small-side product reads them together)
+    const int Kcp = ((Kc + 3) & ~3) + 4;
+    const int Vp = Rp + 4;
+    const int v_rs = 1, v_cs = Vp, w_rs = 1, w_cs = Kcp;
+    const size_t base_iter = off_after_lists + (size_t)Vp * 4 * 8 + 16;
+    const int Gp = R | 1;   // odd row pitch of the dense G: a pitch of 64 doubles puts every row on the same LDS bank
+    const size_t need_iter = base_iter + (small ? (size_t)R * Gp * 8 : (size_t)Kcp * 4 * 8);
     // counters: SPK_WAVES rows of 16-bit (8-bit when a group cannot exceed 255 entries) fields
     const bool bits8 = small;   // a column has at most R <= 64 entries
     const size_t cw_c = (size_t)SPK_WAVES * ((Kc + (bits8 ? 3 : 1)) / (bits8 ? 4 : 2)) * 4;
@@ -842,7 +845,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     SSTAMP(4);
     // V and W / G are laid out over the (now dead) staging area
     off = off_after_lists;
-    double* V = reinterpret_cast<double*>(carve((size_t)Rp * 4 * 8));
+    double* V = reinterpret_cast<double*>(carve((size_t)Vp * 4 * 8));
     double* Wb = reinterpret_cast<double*>(base + off);   // large: W (Kc x 4);  small: G (R x R)
     if (small) {
         // exact Gram G = C C^T: all pairs of entries inside every column, accumulated with integer LDS atomics (exact,
@@ -853,7 +856,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         const bool g32 = meta->trace < (1ull << 32);
         u32* G32 = reinterpret_cast<u32*>(Wb);
         unsigned long long* G64 = reinterpret_cast<unsigned long long*>(Wb);
-        const int gwords = g32 ? R * R : 2 * R * R;
+        const int gwords = g32 ? R * Gp : 2 * R * Gp;   // (integer G with the same odd pitch: cells spread over the banks)
         for (int i = threadIdx.x; i < gwords; i += SPK_THREADS) G32[i] = 0;
         __syncthreads();
         SSTAMP(44);
@@ -877,7 +880,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
                 for (int u = 0; u < 4; ++u) {
                     if (d0 + u >= steps) break;
                     const int rb = vb[u] & 0xFFFF;
-                    const int cell = min(ra, rb) * R + max(ra, rb);
+                    const int cell = min(ra, rb) * Gp + max(ra, rb);
                     // two different entries on the same row are the pieces of one large count: (c1 + c2)^2 has 2 c1 c2
                     const u32 twice = (ra == rb && d0 + u > 0) ? 2u : 1u;
                     if (g32)
@@ -889,28 +892,29 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         }
         __syncthreads();
         SSTAMP(45);
-        {   // exact integer -> fp64 (upper triangle), through registers: the two layouts overlap
-            double gv[(SPK_SMALL_R * SPK_SMALL_R + SPK_THREADS - 1) / SPK_THREADS];
+        {   // exact integer -> fp64 in place (same R x Gp layout), through registers: 4- / 8-byte cells overlap
+            constexpr int NG = (SPK_SMALL_R * (SPK_SMALL_R + 1) + SPK_THREADS - 1) / SPK_THREADS;
+            double gv[NG];
 #pragma unroll
-            for (int k = 0; k < (SPK_SMALL_R * SPK_SMALL_R + SPK_THREADS - 1) / SPK_THREADS; ++k) {
+            for (int k = 0; k < NG; ++k) {
                 const int i = k * SPK_THREADS + (int)threadIdx.x;
-                gv[k] = i < R * R ? (g32 ? (double)spk_aload(G32 + i) : (double)spk_aload(G64 + i)) : 0.0;
+                gv[k] = i < R * Gp ? (g32 ? (double)spk_aload(G32 + i) : (double)spk_aload(G64 + i)) : 0.0;
             }
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < (SPK_SMALL_R * SPK_SMALL_R + SPK_THREADS - 1) / SPK_THREADS; ++k) {
+            for (int k = 0; k < NG; ++k) {
                 const int i = k * SPK_THREADS + (int)threadIdx.x;
-                if (i < R * R) Wb[i] = gv[k];
+                if (i < R * Gp) Wb[i] = gv[k];
             }
         }
         __syncthreads();
-        const float rinv = 1.0f / (float)R;   // i / R for i < 4096, R <= 64: (i + 0.5) / R is >= 1/128 away from an integer
-        for (int i = threadIdx.x; i < R * R; i += SPK_THREADS) {
-            const int r = (int)(((float)i + 0.5f) * rinv), c = i - r * R;
-            if (r > c) Wb[r * R + c] = Wb[c * R + r];
+        const float pinv = 1.0f / (float)Gp;   // i / Gp for i < 4160, Gp <= 65: (i + 0.5) / Gp is >= 1/130 away from an integer
+        for (int i = threadIdx.x; i < R * Gp; i += SPK_THREADS) {
+            const int r = (int)(((float)i + 0.5f) * pinv), c = i - r * Gp;
+            if (c < R && r > c) Wb[r * Gp + c] = Wb[c * Gp + r];
         }
         if (threadIdx.x < 64) {   // rows in use = non-zero diagonal entries (R <= 64)
-            const u64 nzd = __ballot((int)threadIdx.x < R && Wb[threadIdx.x * R + threadIdx.x] != 0.0);
+            const u64 nzd = __ballot((int)threadIdx.x < R && Wb[threadIdx.x * Gp + threadIdx.x] != 0.0);
             if (threadIdx.x == 0) sh.used_r = (int)__popcll(nzd);
         }
         __syncthreads();
@@ -975,7 +979,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             const int row = threadIdx.x >> 2, j = threadIdx.x & 3;
             double acc = 0, part = 0;
             if (row < R) {
-                for (int k = 0; k < R; ++k) acc = fma(Wb[row * R + k], V[k * v_rs + j * v_cs], acc);
+                for (int k = 0; k < R; ++k) acc = fma(Wb[row * Gp + k], V[k * v_rs + j * v_cs], acc);
                 part = acc * V[row * v_rs + j * v_cs];
             }
 #pragma unroll
