@@ -26,8 +26,11 @@
 // a slab of global memory (HBM = true); one that has not converged after SPK_MAXIT products goes to the dense route.
 #include "common.h"
 
-#define SPK_THREADS 512
-#define SPK_WAVES 8
+#ifndef SPK_THREADS
+#define SPK_THREADS 1024
+#endif
+#define SPK_WAVES (SPK_THREADS / 64)
+#define SPK_SORT_WAVES 8    // wave-private counter rows of the counting sort (waves beyond them sit the two passes out)
 #define SPK_NB 4
 #ifndef SPK_TEAM_MAX
 #define SPK_TEAM_MAX 32     // a column / row with more entries than this is shared by the 16 lanes of a row (9..32: a quad)
@@ -64,6 +67,9 @@ struct SpkShared {
     unsigned long long trace;
     int R, Kc, nw_c, nr_c, nq_c, nw_r, nr_r, nq_r, used_c, used_r, flag, pad;   // nw_* / nr_*: groups handled by a whole wave / by a 16-lane row
     int shifts[32];
+    // (trace above and the two below: copies of the alignment metadata, fetched while the table is being staged)
+    u32 top[SPK_NTOP];
+    u32 ntop, padm;
     unsigned int scan[SPK_WAVES + 1];
     unsigned int bucket[68];
 };
@@ -193,7 +199,7 @@ __device__ __forceinline__ void spk_orth(double* X, int rows, int rs, int cs, Sp
 }
 
 // Build one list grouped by `major` (CSC: compact column, CSR: compact row) as a STABLE counting sort of the
-// table order: the table is cut into SPK_WAVES contiguous chunks, wave w owns chunk w and a private row of
+// table order: the table is cut into SPK_SORT_WAVES contiguous chunks, wave w owns chunk w and a private row of
 // per-group counters (BITS-wide fields packed into 32-bit LDS words); position of an entry = ptr[group] + (entries of
 // the group in earlier chunks) + (rank among the wave's own earlier entries).  The last term is the value returned by
 // the wave's own LDS atomic add: lanes of one ds_add_rtn instruction that hit the same word are resolved by the LDS in
@@ -216,7 +222,8 @@ template <bool MAJOR_IS_COL, int BITS, bool PERMUTE>
 __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned short* cnt, int D, int nmajor,
                                                unsigned short* ptr, unsigned short* ptrp, u32* ent,
                                                unsigned short* perm, int* nwave, int* nrow, int* nquad, int* used, u32* cw,
-                                               SpkShared& sh, unsigned short* end_of = nullptr, int stamp0 = -1) {
+                                               int nsort, SpkShared& sh, unsigned short* end_of = nullptr,
+                                               int stamp0 = -1) {
 #ifdef SPK_STAMPS
 #define BSTAMP(k) do { if (stamp0 >= 0) SSTAMP(stamp0 + (k)); } while (0)
 #else
@@ -228,14 +235,14 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // entries per lane: ODD, so that the 64 lanes of a load (stride q words) spread over all LDS banks - an even q puts
     // them on 2 .. 16 banks (q = 16: a 32-way conflict on every load of both passes)
-    const int q = ((D + SPK_WAVES * 64 - 1) / (SPK_WAVES * 64)) | 1;
+    const int q = ((D + nsort * 64 - 1) / (nsort * 64)) | 1;   // nsort = wave-private counter rows in use (<= SPK_WAVES)
     const int chunk = q * 64;
     const int lo = min(D, w * chunk), hi = min(D, lo + chunk);
-    for (int i = threadIdx.x; i < SPK_WAVES * stride; i += SPK_THREADS) cw[i] = 0;
+    for (int i = threadIdx.x; i < nsort * stride; i += SPK_THREADS) cw[i] = 0;
     if (threadIdx.x < 68) sh.bucket[threadIdx.x] = 0;
     __syncthreads();
     BSTAMP(5);
-    u32* myrow = cw + w * stride;
+    u32* myrow = cw + (w < nsort ? w : 0) * stride;   // (waves >= nsort have an empty chunk)
     // lane l walks the contiguous sub-chunk [lo + l*q, lo + (l+1)*q): consecutive table entries share their leading
     // digits (hence often their row or column), so giving them to ONE lane keeps the 64 lanes of an atomic on
     // different counters (measured: 64-way same-word conflicts otherwise)
@@ -256,9 +263,10 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
         for (int f = 0; f < PER; ++f) run[f] = 0;
         u32 words[SPK_WAVES];
 #pragma unroll
-        for (int ww = 0; ww < SPK_WAVES; ++ww) words[ww] = spk_aload(cw + ww * stride + q);
+        for (int ww = 0; ww < SPK_WAVES; ++ww) words[ww] = ww < nsort ? spk_aload(cw + ww * stride + q) : 0u;
 #pragma unroll
         for (int ww = 0; ww < SPK_WAVES; ++ww) {
+            if (ww >= nsort) break;
             u32 outw = 0;
 #pragma unroll
             for (int f = 0; f < PER; ++f) {
@@ -586,6 +594,11 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         sh.shifts[threadIdx.x] = 2 * (n - 1 - t);
     }
     if (threadIdx.x == 0) sh.flag = 0;
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + SPK_NTOP) sh.top[threadIdx.x - 64] = meta->top[threadIdx.x - 64];
+    if (threadIdx.x == 64 + SPK_NTOP) {
+        sh.trace = meta->trace;
+        sh.ntop = meta->ntop;
+    }
     __syncthreads();  // shifts are read by every wave below
     size_t off = HBM ? 0 : (sizeof(SpkShared) + 15) & ~(size_t)15;
     auto carve = [&](size_t bytes) {
@@ -694,7 +707,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     __syncthreads();
     SSTAMP(1);
     const int R = dimsRC[0], Kc = dimsRC[1];   // matrix sizes (ids), >= the rows / columns in use on raw sides
-    const double trace = (double)meta->trace;
+    const double trace = (double)sh.trace;
     // min(shape) <= 4: the reference's SVD returns at most 4 values, so it computes 1 - x/x = 0 exactly; an all-zero
     // table gives 0/0 = nan.  (raw sides: the number of ids in use is known after the lists are built, checked there)
     auto degenerate = [&](int used_r, int used_c) {
@@ -752,10 +765,17 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     const size_t base_iter = off_after_lists + (size_t)Vp * 4 * 8 + 16;
     const int Gp = R | 1;   // odd row pitch of the dense G: a pitch of 64 doubles puts every row on the same LDS bank
     const size_t need_iter = base_iter + (small ? (size_t)R * Gp * 8 : (size_t)Kcp * 4 * 8);
-    // counters: SPK_WAVES rows of 16-bit (8-bit when a group cannot exceed 255 entries) fields
+    // small path: column of every CSC position (for the entry-parallel Gram below), carved from the top as well
+    unsigned short* colof = small ? reinterpret_cast<unsigned short*>(carve_top((size_t)Di * 2)) : nullptr;
+    // counters: rows of 16-bit (8-bit when a group cannot exceed 255 entries) fields
     const bool bits8 = small;   // a column has at most R <= 64 entries
-    const size_t cw_c = (size_t)SPK_WAVES * ((Kc + (bits8 ? 3 : 1)) / (bits8 ? 4 : 2)) * 4;
-    const size_t cw_r = small ? 0 : (size_t)SPK_WAVES * ((R + 1) / 2) * 4;
+    // every wave gets its own row when that fits (shorter chunks per lane), else the first SPK_SORT_WAVES waves sort
+    const size_t cw_c1 = (size_t)((Kc + (bits8 ? 3 : 1)) / (bits8 ? 4 : 2)) * 4, cw_r1 = (size_t)((R + 1) / 2) * 4;
+    const size_t grp_r_probe = small ? 0 : (((size_t)R + 1) * 2 + 15) & ~(size_t)15;
+    const int ns_c = build_end + SPK_WAVES * cw_c1 <= top ? SPK_WAVES : SPK_SORT_WAVES;
+    const int ns_r = build_end + SPK_WAVES * cw_r1 + grp_r_probe + 16 <= top ? SPK_WAVES : SPK_SORT_WAVES;
+    const size_t cw_c = (size_t)ns_c * cw_c1;
+    const size_t cw_r = small ? 0 : (size_t)ns_r * cw_r1;
     // build-time start of every group (general path): columns - in the not yet written CSR list; rows - right behind
     // the row counters
     const size_t grp_r_bytes = small ? 0 : (((size_t)R + 1) * 2 + 15) & ~(size_t)15;
@@ -769,28 +789,16 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     u32* cwbuf = reinterpret_cast<u32*>(base + build_end);
     unsigned short* grp_c = reinterpret_cast<unsigned short*>(csr_ent);
     unsigned short* grp_r = reinterpret_cast<unsigned short*>(base + ((build_end + cw_r + 15) & ~(size_t)15));
-    // small path: end of the column of every CSC position (for the entry-parallel Gram below); it lives in the G area's tail
-    unsigned short* colof = nullptr;
-    if (small) {
-        colof = reinterpret_cast<unsigned short*>(carve_top((size_t)Di * 2));
-        if (need_iter > top || build_end + cw_c > top) {
-            if (threadIdx.x == 0) {
-                scores[sid] = 0.0;
-                status[sid] = 2;
-            }
-            return;
-        }
-    }
     if (small)
         spk_build_list<true, 8, false>(pc, cnt, Di, Kc, csc_ptr, nullptr, csc_ent, nullptr, nullptr, nullptr, nullptr, &sh.used_c,
-                                       cwbuf, sh, colof);
+                                       cwbuf, ns_c, sh, colof);
     else
         spk_build_list<true, 16, true>(pc, cnt, Di, Kc, grp_c, desc_c, csc_ent, perm_c, &sh.nw_c, &sh.nr_c, &sh.nq_c, &sh.used_c,
-                                       cwbuf, sh, nullptr, 50);
+                                       cwbuf, ns_c, sh, nullptr, 50);
     SSTAMP(2);
     if (!small)
         spk_build_list<false, 16, true>(pc, cnt, Di, R, grp_r, desc_r, csr_ent, perm_r, &sh.nw_r, &sh.nr_r, &sh.nq_r, &sh.used_r,
-                                        cwbuf, sh);
+                                        cwbuf, ns_r, sh);
     SSTAMP(3);
     // ids in use on raw sides (small path: the used rows are the non-zero diagonal entries of G, checked below)
     if (degenerate(small ? 5 : sh.used_r, sh.used_c)) return;
@@ -805,11 +813,11 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         int* rows_out = reinterpret_cast<int*>(sh.S);   // [0..3] rows, [4..7] largest count of each
         if (threadIdx.x < 64) {
             const int lane = threadIdx.x;
-            const int ntop = (int)meta->ntop;
+            const int ntop = (int)sh.ntop;
             int myrow = -1, mycnt = 1;
             if (lane < ntop) {
-                myrow = (int)(pc[meta->top[lane]] >> 16);
-                mycnt = (int)cnt[meta->top[lane]];
+                myrow = (int)(pc[sh.top[lane]] >> 16);
+                mycnt = (int)cnt[sh.top[lane]];
             }
             u64 active = __ballot(myrow >= 0);
             int got = 0, chosen[SPK_NB] = {-1, -1, -1, -1}, ccnt[SPK_NB] = {1, 1, 1, 1};
@@ -853,7 +861,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         // d = 0 .. n/2 - every unordered pair once, every thread of a column the same number of steps (walking the
         // rest of the column instead leaves half of the lanes of a long column idle).  32-bit atomics when every entry
         // fits (G[r][r'] <= trace), 64-bit otherwise.
-        const bool g32 = meta->trace < (1ull << 32);
+        const bool g32 = sh.trace < (1ull << 32);
         u32* G32 = reinterpret_cast<u32*>(Wb);
         unsigned long long* G64 = reinterpret_cast<unsigned long long*>(Wb);
         const int gwords = g32 ? R * Gp : 2 * R * Gp;   // (integer G with the same odd pitch: cells spread over the banks)
@@ -988,7 +996,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             if (row < R) V[row * v_rs + j * v_cs] = acc;
             if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = part;
             __syncthreads();
-            top4 = ((sh.red[0] + sh.red[1]) + (sh.red[2] + sh.red[3])) + ((sh.red[4] + sh.red[5]) + (sh.red[6] + sh.red[7]));
+            top4 = 0;
+#pragma unroll
+            for (int ww = 0; ww < SPK_WAVES; ++ww) top4 += sh.red[ww];
             if (spk_converged(top4, it, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
                 break;
