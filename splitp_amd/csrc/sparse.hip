@@ -63,6 +63,7 @@ extern "C" int sp_debug_spk_stamps(long long* out) {
 struct SpkShared {
     double red[SPK_WAVES * 16];
     double S[16];        // X^T X of the current block (full symmetric 4 x 4, row-major)
+    double L[12];        // its Cholesky factor: 1 / l_jj (4), l_10 l_20 l_30 l_21 l_31 l_32, pivot ratio
     double top4;
     unsigned long long trace;
     int R, Kc, nw_c, nr_c, nq_c, nw_r, nr_r, nq_r, used_c, used_r, flag, pad;   // nw_* / nr_*: groups handled by a whole wave / by a 16-lane row
@@ -154,27 +155,37 @@ __device__ __forceinline__ void spk_gram(const double* X, int rows, int rs, int 
     __syncthreads();
 }
 
-// Cholesky-QR step: S = L L^T (sh.S, every thread redundantly in registers), X <- X L^-T by forward substitution per
+// Cholesky-QR step: S = L L^T (sh.S, factored by wave 0, broadcast through sh.L), X <- X L^-T by forward substitution per
 // row, so that X^T X = I.  A pivot below 1e-28 of the largest diagonal marks a dead direction (rank < 4): its column
 // becomes zero and stays zero.  Returns min pivot / max pivot (conditioning indicator).  Ends with a barrier.
-__device__ __forceinline__ double spk_chol_apply(double* X, int rows, int rs, int cs, const SpkShared& sh) {
-    const double s00 = sh.S[0], s10 = sh.S[4], s20 = sh.S[8], s30 = sh.S[12];
-    const double s11 = sh.S[5], s21 = sh.S[9], s31 = sh.S[13], s22 = sh.S[10], s32 = sh.S[14], s33 = sh.S[15];
-    const double dmax = fmax(fmax(s00, s11), fmax(s22, s33));
-    const double tiny = 1e-28 * dmax;
-    double pmin = dmax;
-    const double d0 = s00;
-    const double i0 = d0 > tiny ? spk_rsqrt(d0) : 0.0;
-    const double l10 = s10 * i0, l20 = s20 * i0, l30 = s30 * i0;
-    const double d1 = fma(-l10, l10, s11);
-    const double i1 = d1 > tiny ? spk_rsqrt(d1) : 0.0;
-    const double l21 = fma(-l20, l10, s21) * i1, l31 = fma(-l30, l10, s31) * i1;
-    const double d2 = fma(-l21, l21, fma(-l20, l20, s22));
-    const double i2 = d2 > tiny ? spk_rsqrt(d2) : 0.0;
-    const double l32 = fma(-l31, l21, fma(-l30, l20, s32)) * i2;
-    const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33)));
-    const double i3 = d3 > tiny ? spk_rsqrt(d3) : 0.0;
-    pmin = fmin(fmin(d0 > tiny ? d0 : dmax, d1 > tiny ? d1 : dmax), fmin(d2 > tiny ? d2 : dmax, d3 > tiny ? d3 : dmax));
+__device__ __forceinline__ double spk_chol_apply(double* X, int rows, int rs, int cs, SpkShared& sh) {
+    if (threadIdx.x < 64) {   // wave 0 factors S (64 lanes redundantly, no divergence); everyone else just reads L
+        const double s00 = sh.S[0], s10 = sh.S[4], s20 = sh.S[8], s30 = sh.S[12];
+        const double s11 = sh.S[5], s21 = sh.S[9], s31 = sh.S[13], s22 = sh.S[10], s32 = sh.S[14], s33 = sh.S[15];
+        const double dmax = fmax(fmax(s00, s11), fmax(s22, s33));
+        const double tiny = 1e-28 * dmax;
+        const double d0 = s00;
+        const double i0 = d0 > tiny ? spk_rsqrt(d0) : 0.0;
+        const double l10 = s10 * i0, l20 = s20 * i0, l30 = s30 * i0;
+        const double d1 = fma(-l10, l10, s11);
+        const double i1 = d1 > tiny ? spk_rsqrt(d1) : 0.0;
+        const double l21 = fma(-l20, l10, s21) * i1, l31 = fma(-l30, l10, s31) * i1;
+        const double d2 = fma(-l21, l21, fma(-l20, l20, s22));
+        const double i2 = d2 > tiny ? spk_rsqrt(d2) : 0.0;
+        const double l32 = fma(-l31, l21, fma(-l30, l20, s32)) * i2;
+        const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33)));
+        const double i3 = d3 > tiny ? spk_rsqrt(d3) : 0.0;
+        const double pmin = fmin(fmin(d0 > tiny ? d0 : dmax, d1 > tiny ? d1 : dmax), fmin(d2 > tiny ? d2 : dmax, d3 > tiny ? d3 : dmax));
+        if (threadIdx.x == 0) {
+            sh.L[0] = i0; sh.L[1] = i1; sh.L[2] = i2; sh.L[3] = i3;
+            sh.L[4] = l10; sh.L[5] = l20; sh.L[6] = l30; sh.L[7] = l21; sh.L[8] = l31; sh.L[9] = l32;
+            sh.L[10] = dmax > 0 ? pmin / dmax : 1.0;
+        }
+    }
+    __syncthreads();
+    const double i0 = sh.L[0], i1 = sh.L[1], i2 = sh.L[2], i3 = sh.L[3];
+    const double l10 = sh.L[4], l20 = sh.L[5], l30 = sh.L[6], l21 = sh.L[7], l31 = sh.L[8], l32 = sh.L[9];
+    const double ratio = sh.L[10];
     for (int row = threadIdx.x; row < rows; row += SPK_THREADS) {
         double* x = X + row * rs;
         const double v0 = x[0] * i0;
@@ -184,7 +195,7 @@ __device__ __forceinline__ double spk_chol_apply(double* X, int rows, int rs, in
         x[0] = v0; x[cs] = v1; x[2 * cs] = v2; x[3 * cs] = v3;
     }
     __syncthreads();
-    return dmax > 0 ? pmin / dmax : 1.0;
+    return ratio;
 }
 
 // Orthonormalise the block in place (its Gram matrix is already in sh.S).  One Cholesky-QR pass leaves
