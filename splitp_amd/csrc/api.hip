@@ -133,7 +133,7 @@ extern "C" int sp_ctx_destroy(sp_ctx* c) {
     for (auto e : c->timer.pool) (void)hipEventDestroy(e);
     if (c->upload_ev) (void)hipEventDestroy(c->upload_ev);
     DevBuf* bufs[] = {&c->splits, &c->bitmaps, &c->coords, &c->dims, &c->mats,  &c->grams,  &c->eigws,
-                      &c->scores, &c->status,  &c->misc,   &c->misc2, &c->gram_items, &c->aldescs};
+                      &c->scores, &c->status,  &c->misc,   &c->misc2, &c->gram_items, &c->aldescs, &c->slabs};
     delete c->cache;
     for (auto* b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -710,10 +710,11 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
         if (!fit.empty() && al->spk_D <= 65535) {
             const size_t slab = (sparse_slab_bytes(al->spk_D, bmw) + 255) & ~(size_t)255;
             const size_t chunk = std::max<size_t>(1, std::min<size_t>(fit.size(), ((size_t)2 << 30) / slab));
-            DevBuf slabs, fidx;
+            DevBuf fidx;
+            DevBuf& slabs = ctx->slabs;   // kept for the next call (a 2 GB hipMalloc costs more than the kernel)
             int rc2 = SP_OK;
             if ((rc2 = slabs.ensure(chunk * slab)) || (rc2 = fidx.ensure(fit.size() * 4))) {
-                slabs.release(); fidx.release();
+                fidx.release();
                 return rc2;
             }
             hipError_t e = hipMemcpyAsync(fidx.p, fit.data(), fit.size() * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -726,7 +727,7 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
             if (e == hipSuccess && rc2 == SP_OK)
                 e = hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            slabs.release(); fidx.release();
+            fidx.release();
             if (rc2 != SP_OK) return rc2;
             if (e != hipSuccess) {
                 sp_set_error("sparse route (HBM form): %s", hipGetErrorString(e));

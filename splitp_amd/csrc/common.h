@@ -92,6 +92,7 @@ struct sp_ctx {
     DevBuf misc2;
     DevBuf gram_items; // GramItem[]: Gram tiles, then the row-block items
     DevBuf aldescs;    // AlDesc[] of the current multi-alignment call
+    DevBuf slabs;      // per-workgroup global-memory slabs of the sparse kernel's HBM form (grow-only)
     std::vector<AlDesc> aldescs_host;
     hipEvent_t upload_ev = nullptr;  // last plan / descriptor upload of the sparse route (other streams wait on it)
     PlanCache* cache = nullptr;
