@@ -66,7 +66,7 @@ struct SpkShared {
     double L[12];        // its Cholesky factor: 1 / l_jj (4), l_10 l_20 l_30 l_21 l_31 l_32, pivot ratio
     double top4;
     unsigned long long trace;
-    int R, Kc, nw_c, nr_c, nq_c, nw_r, nr_r, nq_r, used_c, used_r, flag, pad;   // nw_* / nr_*: groups handled by a whole wave / by a 16-lane row
+    int R, Kc, nw_c, nr_c, nq_c, nw_r, nr_r, nq_r, used_c, used_r, pad0, pad1;   // nw_* / nr_*: groups handled by a whole wave / by a 16-lane row
     int shifts[32];
     // (trace above and the two below: copies of the alignment metadata, fetched while the table is being staged)
     u32 top[SPK_NTOP];
@@ -97,7 +97,7 @@ __device__ __forceinline__ void spk_rowcol(u64 key, const int* shifts, int nr, i
     c = cc;
 }
 
-// exclusive scan of one u32 per thread over the 512-thread block; returns the exclusive prefix, total in `total`
+// exclusive scan of one u32 per thread over the block; returns the exclusive prefix, total in `total`
 __device__ __forceinline__ u32 spk_scan(u32 v, SpkShared& sh, u32& total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     u32 x = v;
@@ -293,8 +293,8 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
     __syncthreads();
     BSTAMP(1);
     if (PERMUTE) {
-        // Size classes (spk_class), largest first: whole-wave groups, 16-lane-row groups, single-team groups by number of
-        // 8- (then 4-, 2-, 1-) entry batches, empty groups last.  Counting sort with wave-aggregated counters: one ballot
+        // Size classes (spk_class), largest first: whole-wave groups, 16-lane-row groups, quad groups (4 / 3 / 2 batches of
+        // 8 entries), lane groups (5-8, 3-4, 2, 1 entries), empty groups last.  Counting sort with wave-aggregated counters: one ballot
         // per class, lane c of the wave adds the class-c population with ONE atomic (per-lane atomics on a handful of
         // hot counters serialise: measured 11 k cycles).  The order INSIDE a class depends on which wave gets there
         // first; that only moves groups around - every group is still summed in table order, so results do not change.
@@ -604,7 +604,6 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         const int t = threadIdx.x < nr + nc ? sp.taxa[threadIdx.x] : 0;
         sh.shifts[threadIdx.x] = 2 * (n - 1 - t);
     }
-    if (threadIdx.x == 0) sh.flag = 0;
     if (threadIdx.x >= 64 && threadIdx.x < 64 + SPK_NTOP) sh.top[threadIdx.x - 64] = meta->top[threadIdx.x - 64];
     if (threadIdx.x == 64 + SPK_NTOP) {
         sh.trace = meta->trace;
@@ -618,7 +617,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         return p;
     };
     // ---- stage the table in LDS once: pc[i] = row id << 16 | col id, cnt[i] = count --------------------------------
-    // (every later pass reads LDS; a pass over global memory costs D / 512 serialised load latencies)
+    // (every later pass reads LDS; a pass over global memory costs D / SPK_THREADS serialised load latencies)
     // A side of at most 5 taxa keeps its raw base-4 id (<= 1024 ids: the V / W rows of unused ids stay zero); a longer
     // side is compacted to the ids in use with a presence bitmap + popcount ranks.
 #ifndef SPK_RAW_MAX
