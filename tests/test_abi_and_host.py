@@ -149,3 +149,41 @@ def test_shard_plan_is_balanced_and_complete():
         loads = [costs[s].sum() for s in shards]
         assert max(loads) / min(loads) < 1.05          # every rank gets an equal share of every class
         assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+
+
+def test_simulation_host_logic():
+    """Host side of the device simulator (no GPU): tree -> parents-first arrays for both tree forms, and the closed-form
+    Jukes-Cantor matrix against expm of the reference's normalised rate matrix (model.py:14-16, :49-58, :66-75)."""
+    import numpy as np
+    import scipy.linalg
+    from splitp_amd import simulation as sim
+    from splitp_amd import synthetic as syn
+
+    jc = sim.JukesCantor()
+    q = np.full((4, 4), 1.0 / 3.0)
+    np.fill_diagonal(q, -1.0)                      # JC rate matrix scaled to one expected substitution per unit time
+    for t in (0.0, 0.05, 0.7, 3.0):
+        np.testing.assert_allclose(jc.transition_matrix(t), scipy.linalg.expm(t * q), rtol=0, atol=1e-15)
+    parent, leaf, trans, taxa = sim.tree_arrays(syn.balanced_tree(10), jc, 0.05)
+    assert len(parent) == 19 and parent[0] == -1 and all(parent[i] < i for i in range(1, 19))
+    assert sorted(int(x) for x in leaf if x >= 0) == list(range(10)) and trans.shape == (19, 4, 4)
+    assert taxa == syn.taxa_names(10)
+    np.testing.assert_allclose(trans[1:].sum(axis=1), 1.0, atol=1e-15)      # columns are distributions
+    # the reference's Phylogeny, as far as the simulator looks at it
+    import networkx as nx
+    g = nx.DiGraph()
+    g.add_edges_from([("r", "x"), ("r", "C"), ("x", "A"), ("x", "B")])
+    for node in g.nodes:
+        g.nodes[node]["branch_length"] = 0.2
+
+    class Phylo:
+        networkx_graph = g
+        taxa = ["A", "B", "C"]
+
+    parent, leaf, trans, taxa = sim.tree_arrays(Phylo(), jc)
+    assert parent.tolist()[0] == -1 and sorted(x for x in leaf.tolist() if x >= 0) == [0, 1, 2] and taxa == ["A", "B", "C"]
+    np.testing.assert_allclose(trans[1], jc.transition_matrix(0.2))
+    with pytest.raises(ValueError):
+        sim.tree_arrays(syn.balanced_tree(4), None, 0.1)          # nested tuples carry no matrices
+    with pytest.raises(ValueError):
+        sim.tree_arrays(syn.balanced_tree(4), jc)                 # ... and no branch lengths
