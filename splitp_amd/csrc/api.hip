@@ -639,7 +639,7 @@ static int prepare_sparse_table(sp_ctx* ctx, sp_alignment* al) {
     }
     SP_CHECK(al->keys32.ensure((size_t)std::max<int64_t>(rows, 1) * 4));
     SP_CHECK(al->spk_meta.ensure(sizeof(SpkMeta)));
-    SP_CHECK(launch_sparse_meta(ctx, keys, counts, rows, al->keys32.as<u32>(), al->spk_meta.as<SpkMeta>(), trace));
+    SP_CHECK(launch_sparse_meta(ctx, keys, counts, rows, al->keys32.as<u32>(), al->spk_meta.as<SpkMeta>(), trace, al->D));
     SP_CHECK(mark_upload(ctx));
     al->spk_ready = true;
     return SP_OK;

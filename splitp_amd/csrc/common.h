@@ -62,7 +62,7 @@ struct SpkMeta {
     unsigned long long trace;   // sum of count^2 (exact)
     u32 top[SPK_NTOP];          // indices of the SPK_NTOP largest counts, descending (ties: lowest index first)
     u32 ntop;                   // min(SPK_NTOP, D)
-    u32 pad;
+    u32 pad;                    // rows of the table before large counts were split into pieces (== D when none was)
 };
 struct AlDesc {
     const u32* keys32;          // pattern keys narrowed to 32 bits (n_taxa <= 16)
@@ -204,7 +204,7 @@ int launch_sparse_score_hbm(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, cons
                             const int* order_dev, int64_t S_sub, int64_t S, double* scores, int* status,
                             unsigned char* slabs, size_t slab_bytes);
 int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta,
-                       unsigned long long trace_override);
+                       unsigned long long trace_override, int64_t orig_rows);
 int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,
                         const int* order_dev, int64_t S, double* scores, int* status);
 template <typename T>

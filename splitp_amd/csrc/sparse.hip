@@ -70,7 +70,7 @@ struct SpkShared {
     int shifts[32];
     // (trace above and the two below: copies of the alignment metadata, fetched while the table is being staged)
     u32 top[SPK_NTOP];
-    u32 ntop, padm;
+    u32 ntop, ntab;             // ntab: rows of the table before large counts were split (== D when none was)
     unsigned int scan[SPK_WAVES + 1];
     unsigned int bucket[68];
 };
@@ -608,6 +608,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     if (threadIdx.x == 64 + SPK_NTOP) {
         sh.trace = meta->trace;
         sh.ntop = meta->ntop;
+        sh.ntab = meta->pad;
     }
     __syncthreads();  // shifts are read by every wave below
     size_t off = HBM ? 0 : (sizeof(SpkShared) + 15) & ~(size_t)15;
@@ -878,35 +879,37 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         for (int i = threadIdx.x; i < gwords; i += SPK_THREADS) G32[i] = 0;
         __syncthreads();
         SSTAMP(44);
-        for (int a = threadIdx.x; a < Di; a += SPK_THREADS) {
-            const int col = colof[a];
-            const int p0 = csc_ptr[col], n = csc_ptr[col + 1] - p0, i = a - p0, half = n >> 1;
-            const u32 va = csc_ent[a];
-            const u32 ca = va >> 16;
-            const int ra = va & 0xFFFF;
-            const int steps = ((n & 1) == 0 && i >= half) ? half : half + 1;   // even n: the pair (i, i + n/2) belongs to i < n/2
-            for (int d0 = 0; d0 < steps; d0 += 4) {   // 4 partners per step: the loads, then the atomics, back to back
-                u32 vb[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    int j = i + d0 + u;
-                    j = j >= n ? j - n : j;
-                    j = j >= n ? j - n : j;   // (d0 + u may overshoot by up to 3 past a wrap)
-                    vb[u] = csc_ent[p0 + j];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (d0 + u >= steps) break;
-                    const int rb = vb[u] & 0xFFFF;
-                    const int cell = min(ra, rb) * Gp + max(ra, rb);
-                    // two different entries on the same row are the pieces of one large count: (c1 + c2)^2 has 2 c1 c2
-                    const u32 twice = (ra == rb && d0 + u > 0) ? 2u : 1u;
-                    if (g32)
-                        atomicAdd(&G32[cell], twice * ca * (vb[u] >> 16));
-                    else
-                        atomicAdd(&G64[cell], (unsigned long long)twice * ca * (unsigned long long)(vb[u] >> 16));
+        // (instruction count is what this loop costs - 16 waves share 4 SIMDs, so every instruction of the body is 16
+        // cycles of the block: the partner index walks and wraps by compare-select, the cell is min * Gp + max, and the
+        // rare table with split counts - pieces of one large count on one row pair twice - has its own copy of the loop)
+        const bool has_pieces = Di != (int)sh.ntab;
+        auto pair_loop = [&](auto add_cell, bool pieces) {
+            for (int a = threadIdx.x; a < Di; a += SPK_THREADS) {
+                const int col = colof[a];
+                const int p0 = csc_ptr[col], pend = csc_ptr[col + 1], n = pend - p0, i = a - p0, half = n >> 1;
+                const u32 va = csc_ent[a];
+                const u32 ca = va >> 16;
+                const int ra = va & 0xFFFF;
+                const int steps = ((n & 1) == 0 && i >= half) ? half : half + 1;   // even n: the pair (i, i + n/2) belongs to i < n/2
+                int q = a;
+                for (int d = 0; d < steps; ++d) {
+                    const u32 vb = csc_ent[q];
+                    q = q + 1 == pend ? p0 : q + 1;
+                    const int rb = vb & 0xFFFF;
+                    u32 val = ca * (vb >> 16);
+                    if (pieces && ra == rb && d > 0) val *= 2u;   // (c1 + c2)^2 has 2 c1 c2
+                    add_cell(min(ra, rb) * Gp + max(ra, rb), val, ca, vb >> 16, pieces && ra == rb && d > 0);
                 }
             }
+        };
+        auto add32 = [&](int cell, u32 val, u32, u32, bool) { atomicAdd(&G32[cell], val); };
+        auto add64 = [&](int cell, u32, u32 c1, u32 c2, bool twice) {
+            atomicAdd(&G64[cell], (unsigned long long)c1 * (unsigned long long)c2 * (twice ? 2ull : 1ull));
+        };
+        if (g32) {
+            if (has_pieces) pair_loop(add32, true); else pair_loop(add32, false);
+        } else {
+            if (has_pieces) pair_loop(add64, true); else pair_loop(add64, false);
         }
         __syncthreads();
         SSTAMP(45);
@@ -1062,7 +1065,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
 // trace of the real counts.
 __global__ __launch_bounds__(1024) void k_sparse_meta(const u64* __restrict__ keys, const u32* __restrict__ counts, int D,
                                                       u32* __restrict__ keys32, SpkMeta* __restrict__ meta,
-                                                      unsigned long long trace_override) {
+                                                      unsigned long long trace_override, u32 orig_rows) {
     __shared__ unsigned long long red[16];
     __shared__ unsigned long long winner;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1081,7 +1084,7 @@ __global__ __launch_bounds__(1024) void k_sparse_meta(const u64* __restrict__ ke
         for (int i = 0; i < 16; ++i) t += red[i];
         meta->trace = trace_override ? trace_override : t;
         meta->ntop = (u32)(D < SPK_NTOP ? D : SPK_NTOP);
-        meta->pad = 0;
+        meta->pad = orig_rows;
     }
     unsigned long long bound = ~0ull;   // candidates = (count << 32) | (0xFFFFFFFF - index): extracted in descending order
     for (int k = 0; k < SPK_NTOP; ++k) {
@@ -1111,9 +1114,9 @@ __global__ __launch_bounds__(1024) void k_sparse_meta(const u64* __restrict__ ke
 }
 
 int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta,
-                       unsigned long long trace_override) {
+                       unsigned long long trace_override, int64_t orig_rows) {
     hipLaunchKernelGGL(k_sparse_meta, dim3(1), dim3(1024), 0, ctx->stream, keys, counts, (int)D, keys32, meta,
-                       trace_override);
+                       trace_override, (u32)orig_rows);
     SP_HIP(hipGetLastError());
     return SP_OK;
 }
