@@ -632,7 +632,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     const int kc_cap = raw_c ? (1 << (2 * nc)) : (int)min((long long)D, nc >= 8 ? (long long)D : (1ll << (2 * nc)));
     const int r_cap = raw_r ? (1 << (2 * nr)) : (int)min((long long)D, nr >= 8 ? (long long)D : (1ll << (2 * nr)));
     const bool small_sure = r_cap <= SPK_SMALL_R;   // then no CSR list is needed
-    const size_t need_build = off + (size_t)(D + 8) * (small_sure ? 4 : 8) + (size_t)D * 6 + (size_t)W * 12 + 256;
+    const size_t need_build = off + (size_t)(D + 8) * (small_sure ? 4 : 8) + (size_t)D * 6 + (size_t)W * 12 + 4096 + 256;
     if (D > 65535 || n > 16 || need_build + 2048 > cap) {
         if (threadIdx.x == 0) {
             scores[sid] = 0.0;
@@ -657,17 +657,27 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     u32* pf = reinterpret_cast<u32*>(carve((size_t)W * 4));
     const int* shifts = sh.shifts;
     for (int i = threadIdx.x; i < W; i += SPK_THREADS) bm[i] = 0;
-    // cell = sum_t digit_t(key) << dst_t: source / destination shifts are wave-uniform -> scalar registers
-    int ssrc[16], sdst[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int valid = t < nr + nc;
-        ssrc[t] = __builtin_amdgcn_readfirstlane(valid ? shifts[t] : 0);
-        sdst[t] = __builtin_amdgcn_readfirstlane(valid ? (t < nr ? 2 * (nc + nr - 1 - t) : 2 * (nr + nc - 1 - t)) : 0);
+    // cell = sum_t digit_t(key) << dst_t is a bit permutation of the key: done per key BYTE through four 256-entry
+    // tables (4 taxa each) built here - 3 look-ups + 2 ORs per pattern instead of 4 instructions per taxon (the
+    // staging loop is instruction-bound: 16 waves share 4 SIMDs)
+    u32* lut = reinterpret_cast<u32*>(carve(4 * 256 * 4));
+    {
+        const int chunk = threadIdx.x >> 8, val = threadIdx.x & 255;   // SPK_THREADS >= 1024: one entry per thread
+        for (int e = threadIdx.x; e < 1024; e += SPK_THREADS) {
+            const int ch = e >> 8, v = e & 255;
+            u32 out = 0;
+            for (int t = 0; t < nr + nc; ++t) {
+                const int src = shifts[t];
+                const int dst = t < nr ? 2 * (nc + nr - 1 - t) : 2 * (nr + nc - 1 - t);
+                if ((src >> 3) == ch) out |= (u32)((v >> (src & 7)) & 3) << dst;
+            }
+            lut[e] = out;
+        }
+        (void)chunk; (void)val;
     }
-    const int ntax = nr + nc;
     const u32 cmask = (nc >= 16) ? 0xFFFFFFFFu : ((1u << (2 * nc)) - 1);
     const bool both_raw = raw_r && raw_c;
+    const bool wide_key = n > 12;   // bits 24..31 in use
     __syncthreads();   // bitmaps are zero
     for (int base = 0; base < Di; base += SPK_THREADS * 8) {   // 8 global loads in flight per thread
         u32 key[8], cv[8];
@@ -681,10 +691,8 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         for (int u = 0; u < 8; ++u) {
             const int i = base + u * SPK_THREADS + (int)threadIdx.x;
             if (i >= Di) continue;
-            u32 cell = 0;
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-                if (t < ntax) cell |= ((key[u] >> ssrc[t]) & 3u) << sdst[t];
+            u32 cell = lut[key[u] & 255u] | lut[256 + ((key[u] >> 8) & 255u)] | lut[512 + ((key[u] >> 16) & 255u)];
+            if (wide_key) cell |= lut[768 + (key[u] >> 24)];
             const u32 r = cell >> (2 * nc), c = cell & cmask;
             pc[i] = both_raw ? ((r << 16) | c) : cell;
             cnt[i] = (unsigned short)cv[u];
