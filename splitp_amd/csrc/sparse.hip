@@ -299,14 +299,29 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
         // hot counters serialise: measured 11 k cycles).  The order INSIDE a class depends on which wave gets there
         // first; that only moves groups around - every group is still summed in table order, so results do not change.
         const int rounds = (nmajor + SPK_THREADS - 1) / SPK_THREADS;
-        for (int r = 0; r < rounds; ++r) {
-            const int m = r * SPK_THREADS + threadIdx.x;
-            const int cls = m < nmajor ? spk_class(ptr[m]) : -1;
-            u32 mine = 0;
+        // (the ballots of the first SPK_KEEP rounds are kept in registers for the placement pass: 10 ballots a round are
+        // ~50 instructions, and every instruction of a loop costs the block 16 cycles)
+        constexpr int SPK_KEEP = 4;
+        int kcls[SPK_KEEP];
+        u32 kmine[SPK_KEEP], krank[SPK_KEEP];
+        auto classify = [&](int m, int& cls, u32& mine, u32& rank) {
+            cls = m < nmajor ? spk_class(ptr[m]) : -1;
+            mine = 0;
+            u64 mymask = 0;
 #pragma unroll
             for (int k = 0; k < SPK_NCLASS; ++k) {
                 const u64 b = __ballot(cls == k);
                 if (lane == k) mine = (u32)__popcll(b);
+                if (cls == k) mymask = b;
+            }
+            rank = (u32)__popcll(mymask & ((1ull << lane) - 1));
+        };
+        for (int r = 0; r < rounds; ++r) {
+            int cls;
+            u32 mine, rank;
+            classify(r * SPK_THREADS + (int)threadIdx.x, cls, mine, rank);
+            if (r < SPK_KEEP) {
+                kcls[r] = cls; kmine[r] = mine; krank[r] = rank;
             }
             if (lane < SPK_NCLASS && mine) atomicAdd(&sh.bucket[lane], mine);
         }
@@ -325,21 +340,24 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
             *nquad -= *nwave + *nrow;
         }
         __syncthreads();
-        for (int r = 0; r < rounds; ++r) {
-            const int m = r * SPK_THREADS + threadIdx.x;
-            const int cls = m < nmajor ? spk_class(ptr[m]) : -1;
-            u32 mine = 0;
-            u64 mymask = 0;
 #pragma unroll
-            for (int k = 0; k < SPK_NCLASS; ++k) {
-                const u64 b = __ballot(cls == k);
-                if (lane == k) mine = (u32)__popcll(b);
-                if (cls == k) mymask = b;
-            }
+        for (int r = 0; r < SPK_KEEP; ++r) {
+            if (r >= rounds) break;
+            const int m = r * SPK_THREADS + (int)threadIdx.x;
+            u32 base = 0;
+            if (lane < SPK_NCLASS && kmine[r]) base = atomicAdd(&sh.bucket[lane], kmine[r]);
+            base = __shfl(base, kcls[r] < 0 ? 0 : kcls[r], 64);
+            if (kcls[r] >= 0) perm[base + krank[r]] = (unsigned short)m;
+        }
+        for (int r = SPK_KEEP; r < rounds; ++r) {
+            const int m = r * SPK_THREADS + (int)threadIdx.x;
+            int cls;
+            u32 mine, rank;
+            classify(m, cls, mine, rank);
             u32 base = 0;
             if (lane < SPK_NCLASS && mine) base = atomicAdd(&sh.bucket[lane], mine);
             base = __shfl(base, cls < 0 ? 0 : cls, 64);
-            if (cls >= 0) perm[base + __popcll(mymask & ((1ull << lane) - 1))] = (unsigned short)m;
+            if (cls >= 0) perm[base + rank] = (unsigned short)m;
         }
         __syncthreads();
         BSTAMP(2);
