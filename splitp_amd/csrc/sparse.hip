@@ -320,9 +320,11 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
             int cls;
             u32 mine, rank;
             classify(r * SPK_THREADS + (int)threadIdx.x, cls, mine, rank);
-            if (r < SPK_KEEP) {
-                kcls[r] = cls; kmine[r] = mine; krank[r] = rank;
-            }
+#pragma unroll
+            for (int kk = 0; kk < SPK_KEEP; ++kk)
+                if (r == kk) {
+                    kcls[kk] = cls; kmine[kk] = mine; krank[kk] = rank;
+                }
             if (lane < SPK_NCLASS && mine) atomicAdd(&sh.bucket[lane], mine);
         }
         __syncthreads();
@@ -857,19 +859,27 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
                 mycnt = (int)cnt[sh.top[lane]];
             }
             u64 active = __ballot(myrow >= 0);
-            int got = 0, chosen[SPK_NB] = {-1, -1, -1, -1}, ccnt[SPK_NB] = {1, 1, 1, 1};
-            for (int k = 0; k < SPK_NB && active; ++k) {
-                const int first = __builtin_ctzll(active);
-                const int r = __shfl(myrow, first, 64);
-                chosen[k] = r;
-                ccnt[k] = __shfl(mycnt, first, 64);
-                ++got;
-                active &= ~__ballot(myrow == r);
+            // (fully unrolled, constant indices: a runtime-indexed local array would live in scratch = global memory)
+            int chosen[SPK_NB] = {-1, -1, -1, -1}, ccnt[SPK_NB] = {1, 1, 1, 1};
+#pragma unroll
+            for (int k = 0; k < SPK_NB; ++k) {
+                if (active) {
+                    const int first = __builtin_ctzll(active);
+                    const int r = __shfl(myrow, first, 64);
+                    chosen[k] = r;
+                    ccnt[k] = __shfl(mycnt, first, 64);
+                    active &= ~__ballot(myrow == r);
+                }
             }
-            for (int r = 0; got < SPK_NB && r < R; ++r) {
-                bool used = false;
-                for (int k = 0; k < got; ++k) used = used || chosen[k] == r;
-                if (!used) chosen[got++] = r;
+#pragma unroll
+            for (int k = 0; k < SPK_NB; ++k) {
+                if (chosen[k] < 0) {   // fewer than 4 distinct rows among the candidates: lowest row id not taken yet
+                    int r = 0;
+#pragma unroll
+                    for (int t = 0; t < SPK_NB; ++t)
+                        r += (r == chosen[0]) | (r == chosen[1]) | (r == chosen[2]) | (r == chosen[3]);
+                    chosen[k] = r;
+                }
             }
             if (lane == 0) {
 #pragma unroll
@@ -932,11 +942,12 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         auto add64 = [&](int cell, u32, u32 c1, u32 c2, bool twice) {
             atomicAdd(&G64[cell], (unsigned long long)c1 * (unsigned long long)c2 * (twice ? 2ull : 1ull));
         };
-        if (g32) {
-            if (has_pieces) pair_loop(add32, true); else pair_loop(add32, false);
-        } else {
-            if (has_pieces) pair_loop(add64, true); else pair_loop(add64, false);
-        }
+        if (g32 && !has_pieces)   // (the common case gets the lean copy, everything else the general one)
+            pair_loop(add32, false);
+        else
+            pair_loop([&](int cell, u32 val, u32 c1, u32 c2, bool twice) {
+                if (g32) add32(cell, val, c1, c2, twice); else add64(cell, val, c1, c2, twice);
+            }, has_pieces);
         __syncthreads();
         SSTAMP(45);
         {   // exact integer -> fp64 in place (same R x Gp layout), through registers: 4- / 8-byte cells overlap
@@ -1048,17 +1059,13 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     } else {
         SSTAMP(7);
         for (it = 2; it <= 2 * SPK_MAXIT; ++it) {
-            double* X;
-            int rows, xrs, xcs;
-            if (it & 1) {
-                spk_spmm(desc_c, csc_ent, Kc, perm_c, sh.nw_c, sh.nr_c, sh.nq_c, V, v_rs, v_cs, Wb, w_rs, w_cs,
-                         it == 3 ? 20 : -1);   // W = C^T V
-                X = Wb; rows = Kc; xrs = w_rs; xcs = w_cs;
-            } else {
-                spk_spmm(desc_r, csr_ent, R, perm_r, sh.nw_r, sh.nr_r, sh.nq_r, Wb, w_rs, w_cs, V, v_rs, v_cs,
-                         it == 2 ? 21 : -1);   // Y = C W
-                X = V; rows = R; xrs = v_rs; xcs = v_cs;
-            }
+            // (one call site: the product code is inlined once, the kernel has to stay inside the 64 KB instruction cache)
+            const bool odd = it & 1;                          // odd: W = C^T V (CSC)   even: Y = C W (CSR)
+            double* X = odd ? Wb : V;
+            const int rows = odd ? Kc : R, xrs = odd ? w_rs : v_rs, xcs = odd ? w_cs : v_cs;
+            spk_spmm(odd ? desc_c : desc_r, odd ? csc_ent : csr_ent, rows, odd ? perm_c : perm_r, odd ? sh.nw_c : sh.nw_r,
+                     odd ? sh.nr_c : sh.nr_r, odd ? sh.nq_c : sh.nq_r, odd ? V : Wb, odd ? v_rs : w_rs, odd ? v_cs : w_cs, X,
+                     xrs, xcs, it == 3 ? 20 : -1);
             if (it == 2) SSTAMP(9);
             if (it == 3) SSTAMP(8);
             spk_gram(X, rows, xrs, xcs, sh);
