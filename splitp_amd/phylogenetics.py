@@ -31,6 +31,9 @@ def split_score(matrix, return_singular_values=False, force_frob_norm_on_dense=F
         ri = np.ascontiguousarray(coo.row, dtype=np.int64)
         ci = np.ascontiguousarray(coo.col, dtype=np.int64)
         v = np.ascontiguousarray(coo.data, dtype=np.float64)
+        big = _score_big_sparse(ri, ci, v, matrix.shape)
+        if big is not None:
+            return big
         _lib.check(lib.sp_score_coo_f64(ctx.handle, _lib._ptr(ri, C.c_int64), _lib._ptr(ci, C.c_int64),
                                         _lib._ptr(v, C.c_double), len(v), matrix.shape[0], matrix.shape[1],
                                         C.byref(out)))
@@ -41,6 +44,41 @@ def split_score(matrix, return_singular_values=False, force_frob_norm_on_dense=F
     _lib.check(lib.sp_score_matrix_f64(ctx.handle, _lib._ptr(m, C.c_double), m.shape[0], m.shape[1], m.shape[1],
                                        C.byref(out)))
     return np.float64(out.value)
+
+
+def _score_big_sparse(ri, ci, v, shape):
+    """A sparse matrix whose smaller side exceeds what the dense route keeps in LDS (1024 compact rows): the flattening of
+    12 and more taxa in the reference's default FlatFormat.sparse.  Re-expressed as a pattern table - key = row * 4^b + col
+    with 4^a >= rows, 4^b >= cols is a table of a + b "taxa" whose flattening for the split (first a | last b) IS the
+    matrix - and scored by the batched sparse kernel (LDS form or its global-memory form).  Needs count-derived values
+    (value = count / N, as every table from an alignment has) and a + b <= 16; otherwise None (the caller's dense route
+    then reports the limit)."""
+    from .batch import score_encoded
+    from .device import DeviceAlignment, infer_counts
+
+    rows, cols = int(shape[0]), int(shape[1])
+    if min(rows, cols) <= 1024 or len(v) == 0 or len(v) > 65535:
+        return None
+    a = max(1, (max(rows - 1, 1).bit_length() + 1) // 2)
+    b = max(1, (max(cols - 1, 1).bit_length() + 1) // 2)
+    if a + b > 16:
+        return None
+    keys = ri.astype(np.uint64) * np.uint64(4 ** b) + ci.astype(np.uint64)
+    order = np.argsort(keys, kind="stable")
+    keys, vals = keys[order], v[order]
+    if len(keys) > 1 and (np.diff(keys.astype(np.int64)) == 0).any():
+        return None                                  # duplicate cells: not a flattening
+    inf = infer_counts(vals)
+    if inf is None:
+        return None
+    counts, n_sites = inf
+    dev = DeviceAlignment.from_arrays(keys, None, a + b, counts=counts, n_sites=n_sites)
+    taxa_arr = np.arange(a + b, dtype=np.int32)[None, :]
+    try:
+        scores, status = score_encoded(dev, taxa_arr, np.array([a], dtype=np.int32), _lib.SP_METHOD_FLATTENING)
+    except NotImplementedError:
+        return None
+    return float(scores[0])
 
 
 def flattening_rank_1_approximation_divergence(flattening):

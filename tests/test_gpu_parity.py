@@ -621,6 +621,14 @@ def test_config5_shape_12_taxa(sp):
         # the multi-alignment entry point + hand-back on the same table
         again = sp.score_splits(dev, splits[1900:2035])
         assert np.array_equal(again, scores[1900:2035])
+        # the drop-in per-call form in the reference's default (sparse dok) format: a 4096 x 4096 matrix, beyond the
+        # dense route - split_score re-expresses it as a table for the sparse kernel
+        if length == 20_000:
+            table = dict(dev.items())
+            F = sp.flattening(splits[2034], table)
+            assert F.shape == (4096, 4096)
+            got = sp.split_score(F)
+            assert isinstance(got, float) and abs(got - scores[2034]) <= 1e-12
 
 
 def test_sparse_kernel_edge_tables(sp):
