@@ -41,6 +41,11 @@ def split_score(matrix, return_singular_values=False, force_frob_norm_on_dense=F
     m = np.ascontiguousarray(np.array(matrix), dtype=np.float64)
     if m.ndim != 2:
         raise ValueError("split_score expects a 2-D matrix")
+    if min(m.shape) > 1024:      # a reduced flattening of 12+ taxa: beyond the dense route, try the sparse kernel
+        nz_r, nz_c = np.nonzero(m)
+        big = _score_big_sparse(nz_r.astype(np.int64), nz_c.astype(np.int64), m[nz_r, nz_c], m.shape)
+        if big is not None:
+            return np.float64(big)
     _lib.check(lib.sp_score_matrix_f64(ctx.handle, _lib._ptr(m, C.c_double), m.shape[0], m.shape[1], m.shape[1],
                                        C.byref(out)))
     return np.float64(out.value)

@@ -629,6 +629,12 @@ def test_config5_shape_12_taxa(sp):
             assert F.shape == (4096, 4096)
             got = sp.split_score(F)
             assert isinstance(got, float) and abs(got - scores[2034]) <= 1e-12
+        else:   # ... and the reduced (dense ndarray) format: 1812 x 1863 used rows / columns
+            table = dict(dev.items())
+            Fr = sp.flattening(splits[2034], table, sp.FlatFormat.reduced)
+            assert min(Fr.shape) > 1024
+            got = sp.split_score(Fr)
+            assert isinstance(got, np.float64) and abs(got - scores[2034]) <= 1e-12
 
 
 def test_sparse_kernel_edge_tables(sp):
