@@ -651,7 +651,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     // a-priori bounds on the matrix sizes (the actual sizes of compacted sides are known only after ranking)
     const int kc_cap = raw_c ? (1 << (2 * nc)) : (int)min((long long)D, nc >= 8 ? (long long)D : (1ll << (2 * nc)));
     const int r_cap = raw_r ? (1 << (2 * nr)) : (int)min((long long)D, nr >= 8 ? (long long)D : (1ll << (2 * nr)));
-    const bool small_sure = r_cap <= SPK_SMALL_R;   // then no CSR list is needed
+    // (a table with split counts - several rows per pattern - can have more than R entries in a column, which the 8-bit
+    // sort counters of the small path do not hold: such tables take the general path)
+    const bool small_sure = r_cap <= SPK_SMALL_R && (u32)Di == sh.ntab;   // then no CSR list is needed
     const size_t need_build = off + (size_t)(D + 8) * (small_sure ? 4 : 8) + (size_t)D * 6 + (size_t)W * 12 + 4096 + 256;
     if (D > 65535 || n > 16 || need_build + 2048 > cap) {
         if (threadIdx.x == 0) {
@@ -818,7 +820,11 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     // build-time start of every group (general path): columns - in the not yet written CSR list; rows - right behind
     // the row counters
     const size_t grp_r_bytes = small ? 0 : (((size_t)R + 1) * 2 + 15) & ~(size_t)15;
-    if (need_iter > top || build_end + cw_c > top || build_end + cw_r + grp_r_bytes + 16 > top || Kc > 65535) {
+    // (a raw column side of a tiny table has more ids than the CSR list has bytes: then behind the column counters)
+    const bool grp_c_in_csr = !small && ((size_t)Kc + 1) * 2 <= ((size_t)D + 8) * 4;
+    const size_t grp_c_bytes = (small || grp_c_in_csr) ? 0 : (((size_t)Kc + 1) * 2 + 15) & ~(size_t)15;
+    if (need_iter > top || build_end + cw_c + grp_c_bytes + 16 > top || build_end + cw_r + grp_r_bytes + 16 > top ||
+        Kc > 65535) {
         if (threadIdx.x == 0) {
             scores[sid] = 0.0;
             status[sid] = 2;
@@ -826,7 +832,8 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         return;
     }
     u32* cwbuf = reinterpret_cast<u32*>(base + build_end);
-    unsigned short* grp_c = reinterpret_cast<unsigned short*>(csr_ent);
+    unsigned short* grp_c = grp_c_in_csr ? reinterpret_cast<unsigned short*>(csr_ent)
+                                         : reinterpret_cast<unsigned short*>(base + ((build_end + cw_c + 15) & ~(size_t)15));
     unsigned short* grp_r = reinterpret_cast<unsigned short*>(base + ((build_end + cw_r + 15) & ~(size_t)15));
     if (small)
         spk_build_list<true, 8, false>(pc, cnt, Di, Kc, csc_ptr, nullptr, csc_ent, nullptr, nullptr, nullptr, nullptr, &sh.used_c,

@@ -681,3 +681,37 @@ def test_sparse_kernel_edge_tables(sp):
         M = O.reduced_flattening_packed(keys, counts.astype(np.float64), 16, [g_names.index(t) for t in spl[0]],
                                         [g_names.index(t) for t in spl[1]])[0]
         assert abs(O.dense_split_score(M) - s16[i]) <= SCORE_TOL, (i, M.shape)
+
+
+def test_sparse_kernel_random_tables(sp):
+    """Randomised sweep: tables of 4..9 taxa, 30..4000 sites, short and long branches (few / many patterns, huge and unit
+    counts), every split, batched sparse route against the oracle's dense SVD on the reduced flattening (exactly 0 where
+    min(shape) <= 4, like the reference)."""
+    from splitp_amd import synthetic as syn
+
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for trial in range(24):
+        n = int(rng.integers(4, 10))
+        if n % 2:
+            n += 1 if n < 9 else -1
+        length = int(rng.choice([30, 200, 1500, 4000]))
+        branch = float(rng.choice([0.002, 0.05, 0.4, 2.0]))
+        names = taxa_names(n)
+        keys, counts = syn.pattern_table(syn.simulate_sites(n, length, branch, seed=100 + trial))
+        if trial % 5 == 0:
+            counts = counts * 70_000            # counts beyond 16 bits: entered as several table rows
+        dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=int(counts.sum()), taxa=names)
+        splits = list(sp.all_splits(names))
+        got, st = sp.score_splits(dev, splits, return_status=True)
+        assert np.all((st & 1) == 0)
+        for i, spl in enumerate(splits):
+            M = O.reduced_flattening_packed(keys, counts.astype(np.float64), n, [names.index(t) for t in spl[0]],
+                                            [names.index(t) for t in spl[1]])[0]
+            want = 0.0 if min(M.shape) <= 4 else O.dense_split_score(M)
+            if np.isnan(want):          # the reference's unclamped dense path: operand rounded below zero
+                want = 0.0
+            err = abs(want - got[i]) if want > 1e-6 or got[i] > 1e-6 else abs(want ** 2 - got[i] ** 2)
+            worst = max(worst, err)
+            assert err <= SCORE_TOL, (trial, n, length, branch, i, M.shape, want, got[i])
+    assert worst <= SCORE_TOL
