@@ -38,7 +38,9 @@
 #ifndef SPK_ROW_MAX
 #define SPK_ROW_MAX 128     // ... and with more than this by the 64 lanes of a wave
 #endif
-#define SPK_MAXIT 40
+#define SPK_MAXIT 40        // dense products of the small-side path (cheap)
+#define SPK_MAXHALF 16      // sparse half products of the general path; a block without a spectral gap behind it goes to
+                            // the dense route long before (spk_converged)
 #define SPK_LDS_BYTES 163840
 #define SPK_SMALL_R 64
 
@@ -63,7 +65,7 @@ extern "C" int sp_debug_spk_stamps(long long* out) {
 struct SpkShared {
     double red[SPK_WAVES * 16];
     double S[16];        // X^T X of the current block (full symmetric 4 x 4, row-major)
-    double L[12];        // its Cholesky factor: 1 / l_jj (4), l_10 l_20 l_30 l_21 l_31 l_32, pivot ratio
+    double L[12];        // its Cholesky factor: 1 / l_jj (4), l_10 l_20 l_30 l_21 l_31 l_32, pivot ratio, eigenvalue bound
     double top4;
     unsigned long long trace;
     int R, Kc, nw_c, nr_c, nq_c, nw_r, nr_r, nq_r, used_c, used_r, pad0, pad1;   // nw_* / nr_*: groups handled by a whole wave / by a 16-lane row
@@ -158,8 +160,11 @@ __device__ __forceinline__ void spk_gram(const double* X, int rows, int rs, int 
 // Cholesky-QR step: S = L L^T (sh.S, factored by wave 0, broadcast through sh.L), X <- X L^-T by forward substitution per
 // row, so that X^T X = I.  A pivot below 1e-28 of the largest diagonal marks a dead direction (rank < 4): its column
 // becomes zero and stays zero.  Returns min pivot / max pivot (conditioning indicator).  Ends with a barrier.
-__device__ __forceinline__ double spk_chol_apply(double* X, int rows, int rs, int cs, SpkShared& sh) {
-    if (threadIdx.x < 64) {   // wave 0 factors S (64 lanes redundantly, no divergence); everyone else just reads L
+// Factor: wave 0 (64 lanes redundantly, no divergence) -> sh.L = 1 / l_jj (4), l_10 l_20 l_30 l_21 l_31 l_32, the pivot
+// ratio, and a lower bound of the smallest eigenvalue of S: 1 / trace(S^-1) = 1 / |L^-1|_F^2 (within a factor 4 of it).
+// Ends with a barrier.
+__device__ __forceinline__ void spk_chol_factor(SpkShared& sh) {
+    if (threadIdx.x < 64) {
         const double s00 = sh.S[0], s10 = sh.S[4], s20 = sh.S[8], s30 = sh.S[12];
         const double s11 = sh.S[5], s21 = sh.S[9], s31 = sh.S[13], s22 = sh.S[10], s32 = sh.S[14], s33 = sh.S[15];
         const double dmax = fmax(fmax(s00, s11), fmax(s22, s33));
@@ -176,13 +181,25 @@ __device__ __forceinline__ double spk_chol_apply(double* X, int rows, int rs, in
         const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33)));
         const double i3 = d3 > tiny ? spk_rsqrt(d3) : 0.0;
         const double pmin = fmin(fmin(d0 > tiny ? d0 : dmax, d1 > tiny ? d1 : dmax), fmin(d2 > tiny ? d2 : dmax, d3 > tiny ? d3 : dmax));
+        // M = L^-1 (lower triangular); a dead pivot makes S singular: bound 0
+        const double m10 = -l10 * i0 * i1, m21 = -l21 * i1 * i2, m32 = -l32 * i2 * i3;
+        const double m20 = -(l20 * i0 + l21 * m10) * i2;
+        const double m31 = -(l31 * i1 + l32 * m21) * i3;
+        const double m30 = -(l30 * i0 + l31 * m10 + l32 * m20) * i3;
+        const double tinv = i0 * i0 + i1 * i1 + i2 * i2 + i3 * i3 + m10 * m10 + m21 * m21 + m32 * m32 + m20 * m20 + m31 * m31 + m30 * m30;
+        const bool full = i0 > 0 && i1 > 0 && i2 > 0 && i3 > 0;
         if (threadIdx.x == 0) {
             sh.L[0] = i0; sh.L[1] = i1; sh.L[2] = i2; sh.L[3] = i3;
             sh.L[4] = l10; sh.L[5] = l20; sh.L[6] = l30; sh.L[7] = l21; sh.L[8] = l31; sh.L[9] = l32;
             sh.L[10] = dmax > 0 ? pmin / dmax : 1.0;
+            sh.L[11] = full && tinv > 0 ? 1.0 / tinv : 0.0;
         }
     }
     __syncthreads();
+}
+
+// Apply: X <- X L^-T by forward substitution per row (sh.L).  Returns the pivot ratio.  Ends with a barrier.
+__device__ __forceinline__ double spk_chol_apply(double* X, int rows, int rs, int cs, SpkShared& sh) {
     const double i0 = sh.L[0], i1 = sh.L[1], i2 = sh.L[2], i3 = sh.L[3];
     const double l10 = sh.L[4], l20 = sh.L[5], l30 = sh.L[6], l21 = sh.L[7], l31 = sh.L[8], l32 = sh.L[9];
     const double ratio = sh.L[10];
@@ -201,10 +218,12 @@ __device__ __forceinline__ double spk_chol_apply(double* X, int rows, int rs, in
 // Orthonormalise the block in place (its Gram matrix is already in sh.S).  One Cholesky-QR pass leaves
 // |X^T X - I| ~ eps * cond(S); count flattenings have four leading singular values of one magnitude (cond < 100), so
 // one pass is enough; an ill-conditioned block (pivot ratio < 0.05) gets up to two more passes (CholeskyQR2/3).
+// (the caller has run spk_gram + spk_chol_factor on the block)
 __device__ __forceinline__ void spk_orth(double* X, int rows, int rs, int cs, SpkShared& sh) {
     double ratio = spk_chol_apply(X, rows, rs, cs, sh);
     for (int pass = 0; pass < 2 && ratio < 0.05; ++pass) {
         spk_gram(X, rows, rs, cs, sh);
+        spk_chol_factor(sh);
         ratio = spk_chol_apply(X, rows, rs, cs, sh);
     }
 }
@@ -561,13 +580,21 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
     __syncthreads();
 }
 
-// Stop when the Ritz sum has settled.  s_1, s_2, ... increase monotonically towards the limit with an (eventually)
-// constant error ratio rho = (sigma_5 / sigma_4)^2, so delta_k = s_k - s_(k-1) ~ the error of s_(k-1) and the error left
-// after s_k is the geometric tail delta_k rho / (1 - rho).  rho is taken as the LARGER of the last two measured ratios
-// delta_k / delta_(k-1): early ratios are optimistic (the start block's stray components die faster than the
-// asymptotic rate - with a single ratio 20 % of the splits stopped one product early with 3e-11 left in the score).
+// Stop when the Ritz sum has settled AND the spectrum behind the block is known to be separated from it.
+// s_1, s_2, ... increase monotonically towards the limit with an (eventually) constant error ratio
+// rho = (sigma_5 / sigma_4)^2, so delta_k = s_k - s_(k-1) ~ the error of s_(k-1) and the error left after s_k is the
+// geometric tail delta_k rho / (1 - rho).  rho is taken as the LARGER of the last two measured ratios (early ratios are
+// optimistic: with a single ratio 20 % of the splits stopped one product early with 3e-11 left in the score).
+// The sums alone cannot tell "converged" from "stalled": when sigma_4 ~ sigma_5 the block finds three directions and a
+// mix of the 4th / 5th, and the sum stops moving with the error (lambda_4 - lambda_5) sin^2 still in it (found by the
+// randomised tests: 6e-5 in a score).  Hence the guard: everything outside the block weighs trace - s, so
+// lambda_5 <= trace - s; accept only if that is at most half of `lam_lb`, a lower bound of the smallest Ritz value in the
+// block (1 / trace(S^-1) of the Gram matrix just factored) - then lambda_5 / lambda_4 <= 1/2, no stall is possible and
+// the measured ratios are real - or if trace - s is itself below the tolerance.  A block that fails the guard
+// SPK_GUARD_IT times is handed to the dense route (16-wide block), where clusters are at home.
 // Tolerance: the score is sqrt(1 - s / trace); 1e-13 relative in s is < 1e-11 in any score >= 0.005.
-__device__ __forceinline__ bool spk_converged(double s4, int k, double& prev_sum, double& prev_delta, double& prev_ratio) {
+__device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double trace, int k, double& prev_sum,
+                                              double& prev_delta, double& prev_ratio) {
     bool conv = false;
     const double delta = fabs(s4 - prev_sum);
     double ratio = 1.0;
@@ -577,8 +604,10 @@ __device__ __forceinline__ bool spk_converged(double s4, int k, double& prev_sum
         if (k >= 4) {
             const double r = fmax(ratio, prev_ratio);
             const double tail = delta * r / (1.0 - r);
+            const double rest = trace - s4;                    // >= lambda_5 + lambda_6 + ...
+            const bool gap = rest <= 0.5 * lam_lb || rest <= 1e-13 * trace;
             // (the Ritz sum itself carries ~2e-15 of rounding noise: a change below 2e-14 is at the floor)
-            if (delta <= 2e-14 * s4 || tail <= 1e-13 * s4) conv = true;
+            if (gap && (delta <= 2e-14 * s4 || tail <= 1e-13 * s4)) conv = true;
         }
     }
     prev_ratio = ratio;
@@ -1003,6 +1032,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         }
         __syncthreads();
         spk_gram(V, R, v_rs, v_cs, sh);
+        spk_chol_factor(sh);
         spk_orth(V, R, v_rs, v_cs, sh);
     } else {
         const double nscale = 0.01 * spk_rsqrt((double)Kc / 3.0);
@@ -1034,6 +1064,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         }
         __syncthreads();
         spk_gram(Wb, Kc, w_rs, w_cs, sh);
+        spk_chol_factor(sh);
         spk_orth(Wb, Kc, w_rs, w_cs, sh);
     }
     SSTAMP(5);
@@ -1056,16 +1087,17 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             top4 = 0;
 #pragma unroll
             for (int ww = 0; ww < SPK_WAVES; ++ww) top4 += sh.red[ww];
-            if (spk_converged(top4, it, prev_sum, prev_delta, prev_ratio)) {
+            spk_gram(V, R, v_rs, v_cs, sh);                  // Y^T Y = V^T G^2 V: its eigenvalues are the squared Ritz values
+            spk_chol_factor(sh);
+            if (spk_converged(top4, sqrt(sh.L[11]), trace, it, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
                 break;
             }
-            spk_gram(V, R, v_rs, v_cs, sh);
             spk_orth(V, R, v_rs, v_cs, sh);
         }
     } else {
         SSTAMP(7);
-        for (it = 2; it <= 2 * SPK_MAXIT; ++it) {
+        for (it = 2; it <= SPK_MAXHALF; ++it) {
             // (one call site: the product code is inlined once, the kernel has to stay inside the 64 KB instruction cache)
             const bool odd = it & 1;                          // odd: W = C^T V (CSC)   even: Y = C W (CSR)
             double* X = odd ? Wb : V;
@@ -1078,7 +1110,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             spk_gram(X, rows, xrs, xcs, sh);
             if (it == 2) SSTAMP(40);
             top4 = (sh.S[0] + sh.S[5]) + (sh.S[10] + sh.S[15]);
-            if (spk_converged(top4, it - 1, prev_sum, prev_delta, prev_ratio)) {   // (the first real Ritz sum is that of half product 2)
+            spk_chol_factor(sh);
+            // (the first real Ritz sum is that of half product 2)
+            if (spk_converged(top4, sh.L[11], trace, it - 1, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
                 break;
             }

@@ -715,3 +715,56 @@ def test_sparse_kernel_random_tables(sp):
             worst = max(worst, err)
             assert err <= SCORE_TOL, (trial, n, length, branch, i, M.shape, want, got[i])
     assert worst <= SCORE_TOL
+
+
+def _copy_mutate_table(rng, n, length, letters):
+    """Random alignment that is not tree-shaped like the simulator's: taxon t copies a random earlier taxon with its own
+    per-site mutation probability; `letters` of the 4 states in use."""
+    sites = np.empty((length, n), dtype=np.uint8)
+    sites[:, 0] = rng.integers(0, letters, size=length)
+    for t in range(1, n):
+        src = sites[:, int(rng.integers(0, t))]
+        p = float(rng.choice([0.001, 0.02, 0.15, 0.5]))
+        mut = rng.random(length) < p
+        sites[:, t] = np.where(mut, rng.integers(0, letters, size=length), src)
+    keys = np.zeros(length, dtype=np.uint64)
+    for t in range(n):
+        keys = (keys << np.uint64(2)) | sites[:, t].astype(np.uint64)
+    uk, cnt = np.unique(keys, return_counts=True)
+    return uk, cnt.astype(np.int64)
+
+
+def test_sparse_kernel_random_shapes(sp):
+    """Second randomised sweep: 5..13 taxa (odd counts too), restricted alphabets (many unused ids on raw sides, ranks 1..4),
+    random split sizes; LDS form, small-side path and global-memory form against the oracle."""
+    rng = np.random.default_rng(77)
+    checked = 0
+    for trial in range(30):
+        n = int(rng.integers(5, 14))
+        length = int(rng.choice([20, 150, 900, 6000]))
+        letters = int(rng.choice([2, 3, 4, 4]))
+        keys, counts = _copy_mutate_table(rng, n, length, letters)
+        names = taxa_names(n)
+        dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=int(counts.sum()), taxa=names)
+        if n <= 8:
+            splits = list(sp.all_splits(names))
+        else:
+            splits = []
+            for _ in range(24):
+                k = int(rng.integers(2, n - 1))
+                left = sorted(rng.choice(n, size=k, replace=False).tolist())
+                splits.append((tuple(names[t] for t in left), tuple(names[t] for t in range(n) if t not in left)))
+        got, st = sp.score_splits(dev, splits, return_status=True)
+        assert np.all((st & 1) == 0)
+        for i, spl in enumerate(splits):
+            M = O.reduced_flattening_packed(keys, counts.astype(np.float64), n, [names.index(t) for t in spl[0]],
+                                            [names.index(t) for t in spl[1]])[0]
+            if min(M.shape) > 500:
+                continue
+            want = 0.0 if min(M.shape) <= 4 else O.dense_split_score(M)
+            if np.isnan(want):
+                want = 0.0
+            err = abs(want - got[i]) if want > 1e-6 or got[i] > 1e-6 else abs(want ** 2 - got[i] ** 2)
+            assert err <= SCORE_TOL, (trial, n, length, letters, len(keys), i, M.shape, want, got[i], hex(st[i]))
+            checked += 1
+    assert checked > 500
