@@ -123,7 +123,11 @@ __device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, do
     c = 1.0;
     s = 0.0;
     if (apq * apq > 1e-40 * fabs(app * aqq) && apq != 0.0) {
-        const float num = (float)(aqq - app), den = 2.0f * (float)apq;
+        // (both operands brought to O(1) by an exact power of two first: the entries of nearly dead directions - 1e-45 on
+        // a probability-scaled table - are below the f32 range and gave 0 / 0 = nan, found by the randomised tests)
+        const double d = aqq - app;
+        const int ex = -ilogb(fmax(fabs(d), fabs(apq)));
+        const float num = (float)scalbn(d, ex), den = 2.0f * (float)scalbn(apq, ex);
         float tf;
         if (fabsf(num) > 1e18f * fabsf(den)) {
             tf = den / (2.0f * num);  // tiny angle; avoids inf / nan in the f32 quotient
@@ -218,7 +222,7 @@ __device__ __forceinline__ void jacobi_nb(EigShared& sh) {
 //     X <- X P D^-1/2                  (MFMA; columns = orthonormal Ritz vectors of G^2 on span(V), images under G)
 //     polish: X <- X (1.5 I - 0.5 X^T X) until ||X^T X - I||_max <= 2e-15   (Newton-Schulz, MFMA)
 // sqrt(D_i) are Ritz values of G (from G^2 on the same subspace: lower bounds, second-order accurate like
-// the ones of V^T G V); sh.top4 = sum of the four largest.  Directions with D_i <= 1e-28 D_max are dead
+// the ones of V^T G V); sh.top4 = sum of the four largest.  Directions with D_i <= 1e-13 D_max are dead
 // (zero columns: exactly singular input, or R < 16).  No Cholesky, no serial 16-step chains, and no
 // data-dependent fallback path.  When `values_only` the block is left untouched after the Jacobi.
 template <int NB, int VP>
@@ -246,7 +250,11 @@ __device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh) {
         if (threadIdx.x < 256) {
             const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
             const double dj = sh.theta[j];
-            const double rj = (dj > 1e-28 * dmax && dj > 0) ? rsqrt_nr(dj) : 0.0;
+            // S = Y^T Y carries absolute rounding errors of ~1e-16 dmax, so an eigenvalue below ~1e-14 dmax is noise;
+            // normalising a column by the square root of noise made X^T X explode in the polish below (nan scores on a
+            // probability-scaled table - found by the randomised tests).  Such a direction (lambda_i < 3e-7 lambda_1 of
+            // G) is dropped from the block; it could only matter for a matrix of numerical rank < 4.
+            const double rj = (dj > 1e-13 * dmax && dj > 0) ? rsqrt_nr(dj) : 0.0;
             sh.T[i * EIG_VP + j] = (i < NB && j < NB) ? sh.Q[i * EIG_VP + j] * rj : 0.0;
         }
         __syncthreads();

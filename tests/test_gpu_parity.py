@@ -756,6 +756,18 @@ def test_sparse_kernel_random_shapes(sp):
                 splits.append((tuple(names[t] for t in left), tuple(names[t] for t in range(n) if t not in left)))
         got, st = sp.score_splits(dev, splits, return_status=True)
         assert np.all((st & 1) == 0)
+        if n <= 10 and trial % 3 == 0:       # the dense route (int8-limb Gram) and the float-weight table (fp64 Gram) too
+            def close(a, b):   # scores near 0 are square roots of rounding noise: compare their squares there
+                small = (a < 1e-6) & (b < 1e-6)
+                return np.where(small, np.abs(a * a - b * b), np.abs(a - b)).max() <= SCORE_TOL
+            assert close(sp.score_splits(dev, splits, route="dense"), got)
+            dev_w = sp.DeviceAlignment.from_arrays(keys, counts / float(counts.sum()), n, taxa=names, exact=False)
+            assert close(sp.score_splits(dev_w, splits), got)
+            mi = sp.score_splits(dev, splits[:6], method=sp.Method.mutual_information)
+            for i in range(min(6, len(splits))):
+                oa = [names.index(t) for t in splits[i][0]]
+                ob = [names.index(t) for t in splits[i][1]]
+                assert abs(O.rank1_divergence_packed(keys, counts / float(counts.sum()), n, oa, ob) - mi[i]) <= SCORE_TOL
         for i, spl in enumerate(splits):
             M = O.reduced_flattening_packed(keys, counts.astype(np.float64), n, [names.index(t) for t in spl[0]],
                                             [names.index(t) for t in spl[1]])[0]
