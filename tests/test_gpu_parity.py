@@ -780,3 +780,52 @@ def test_sparse_kernel_random_shapes(sp):
             assert err <= SCORE_TOL, (trial, n, length, letters, len(keys), i, M.shape, want, got[i], hex(st[i]))
             checked += 1
     assert checked > 500
+
+
+def test_subflattening_and_histogram_random(sp):
+    """Randomised sweep of the other two routes: batched subflattening scores and matrices against the oracle (exact
+    integer moments), and the device histogram of random sequences with invalid / lower-case characters against a NumPy
+    count of the valid sites (reference splitp/parsers/fasta.py:48-63)."""
+    rng = np.random.default_rng(31)
+    for trial in range(10):
+        n = int(rng.integers(4, 12))
+        length = int(rng.choice([40, 700, 5000]))
+        keys, counts = _copy_mutate_table(rng, n, length, int(rng.choice([3, 4])))
+        names = taxa_names(n)
+        total = int(counts.sum())
+        dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=total, taxa=names)
+        splits = []
+        for _ in range(12):
+            k = int(rng.integers(1, n))
+            left = sorted(rng.choice(n, size=k, replace=False).tolist())
+            splits.append((tuple(names[t] for t in left), tuple(names[t] for t in range(n) if t not in left)))
+        got = sp.score_splits(dev, splits, method=sp.Method.subflattening)
+        for i, spl in enumerate(splits):
+            oa = [names.index(t) for t in spl[0]]
+            ob = [names.index(t) for t in spl[1]]
+            want_m = O.subflattening_packed(keys, counts / float(total), n, oa, ob)
+            got_m = sp.subflattening(spl, dev)
+            assert np.array_equal(np.rint(got_m * total), np.rint(want_m * total))
+            want = 0.0 if min(want_m.shape) <= 4 else O.dense_split_score(want_m)
+            if np.isnan(want):
+                want = 0.0
+            err = abs(want - got[i]) if want > 1e-6 or got[i] > 1e-6 else abs(want ** 2 - got[i] ** 2)
+            assert err <= SCORE_TOL, (trial, n, length, i, want_m.shape, want, got[i])
+    for trial in range(6):
+        n = int(rng.integers(2, 15))
+        length = int(rng.choice([1, 63, 1000, 70_000]))
+        alphabet = np.frombuffer(b"ACGTacgtN-?X", dtype=np.uint8)
+        p = np.array([20, 20, 20, 20, 3, 3, 3, 3, 1, 1, 0.5, 0.5])
+        seqs = alphabet[rng.choice(len(alphabet), size=(n, length), p=p / p.sum())]
+        dev = sp.DeviceAlignment.from_sequences(seqs)
+        code = np.full(256, 255, dtype=np.uint8)
+        for ch, d in zip(b"ACGTacgt", (0, 1, 2, 3, 0, 1, 2, 3)):
+            code[ch] = d
+        digits = code[seqs]                                   # (n, L)
+        valid = (digits != 255).all(axis=0)
+        k64 = np.zeros(length, dtype=np.uint64)
+        for t in range(n):
+            k64 = (k64 << np.uint64(2)) | (digits[t] & 3).astype(np.uint64)
+        uk, uc = np.unique(k64[valid], return_counts=True)
+        keys, w, cnt = dev.fetch()
+        assert np.array_equal(keys, uk) and np.array_equal(cnt, uc) and dev.info()["N"] == int(valid.sum())
