@@ -773,6 +773,21 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
     if (rc == SP_OK) rc = run_dense_route(al, sub, false);
     ctx->cache = saved;
     pc.valid = false;  // the device copy of the cached sparse plan was overwritten
+    if (rc == SP_ELIMIT) {
+        // The dense route cannot take this shape (a side beyond its compaction / block limits, e.g. 12 taxa).  Splits
+        // the sparse kernel iterated on keep its last Ritz estimate (an upper estimate of the score), flagged with
+        // status bit 0 = "iteration cap hit, not certified"; a split that never ran has nothing to keep.
+        for (int i : redo)
+            if ((st[i] >> 8) == 0) return bail(rc);
+        for (int i : redo) st[i] = (st[i] & ~2) | 1;
+        if (hipMemcpyAsync(ctx->scores.p, keep_scores.p, (size_t)S * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(ctx->status.p, st.data(), (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            sp_set_error("sparse route hand-back: restoring the estimates failed");
+            return bail(SP_EHIP);
+        }
+        return bail(SP_OK);
+    }
     if (rc != SP_OK) return bail(rc);
     hipLaunchKernelGGL(k_patch_scores, dim3((unsigned)((redo.size() + 255) / 256)), dim3(256), 0, ctx->stream,
                        idx.as<int>(), (int)redo.size(), ctx->scores.as<double>(), ctx->status.as<int>(),

@@ -222,7 +222,7 @@ __device__ __forceinline__ void jacobi_nb(EigShared& sh) {
 //     X <- X P D^-1/2                  (MFMA; columns = orthonormal Ritz vectors of G^2 on span(V), images under G)
 //     polish: X <- X (1.5 I - 0.5 X^T X) until ||X^T X - I||_max <= 2e-15   (Newton-Schulz, MFMA)
 // sqrt(D_i) are Ritz values of G (from G^2 on the same subspace: lower bounds, second-order accurate like
-// the ones of V^T G V); sh.top4 = sum of the four largest.  Directions with D_i <= 1e-13 D_max are dead
+// the ones of V^T G V); sh.top4 = sum of the four largest.  Directions with D_i <= 3e-15 D_max are dead
 // (zero columns: exactly singular input, or R < 16).  No Cholesky, no serial 16-step chains, and no
 // data-dependent fallback path.  When `values_only` the block is left untouched after the Jacobi.
 template <int NB, int VP>
@@ -250,11 +250,11 @@ __device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh) {
         if (threadIdx.x < 256) {
             const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
             const double dj = sh.theta[j];
-            // S = Y^T Y carries absolute rounding errors of ~1e-16 dmax, so an eigenvalue below ~1e-14 dmax is noise;
+            // S = Y^T Y carries absolute rounding errors of ~1e-16 dmax, so an eigenvalue below ~3e-15 dmax is noise;
             // normalising a column by the square root of noise made X^T X explode in the polish below (nan scores on a
             // probability-scaled table - found by the randomised tests).  Such a direction (lambda_i < 3e-7 lambda_1 of
-            // G) is dropped from the block; it could only matter for a matrix of numerical rank < 4.
-            const double rj = (dj > 1e-13 * dmax && dj > 0) ? rsqrt_nr(dj) : 0.0;
+            // G) is dropped from the block (lambda_i < 6e-8 lambda_1 of G); it could only matter for a matrix of numerical rank < 4.
+            const double rj = (dj > 3e-15 * dmax && dj > 0) ? rsqrt_nr(dj) : 0.0;
             sh.T[i * EIG_VP + j] = (i < NB && j < NB) ? sh.Q[i * EIG_VP + j] * rj : 0.0;
         }
         __syncthreads();

@@ -39,7 +39,7 @@
 #define SPK_ROW_MAX 128     // ... and with more than this by the 64 lanes of a wave
 #endif
 #define SPK_MAXIT 40        // dense products of the small-side path (cheap)
-#define SPK_MAXHALF 16      // sparse half products of the general path; a block without a spectral gap behind it goes to
+#define SPK_MAXHALF 40      // sparse half products of the general path; a block without a spectral gap behind it goes to
                             // the dense route long before (spk_converged)
 #define SPK_LDS_BYTES 163840
 #define SPK_SMALL_R 64
@@ -161,7 +161,7 @@ __device__ __forceinline__ void spk_gram(const double* X, int rows, int rs, int 
 // row, so that X^T X = I.  A pivot below 1e-28 of the largest diagonal marks a dead direction (rank < 4): its column
 // becomes zero and stays zero.  Returns min pivot / max pivot (conditioning indicator).  Ends with a barrier.
 // Factor: wave 0 (64 lanes redundantly, no divergence) -> sh.L = 1 / l_jj (4), l_10 l_20 l_30 l_21 l_31 l_32, the pivot
-// ratio, and a lower bound of the smallest eigenvalue of S: 1 / trace(S^-1) = 1 / |L^-1|_F^2 (within a factor 4 of it).
+// ratio, and an estimate of the smallest eigenvalue of S (inverse iteration).
 // Ends with a barrier.
 __device__ __forceinline__ void spk_chol_factor(SpkShared& sh) {
     if (threadIdx.x < 64) {
@@ -181,18 +181,38 @@ __device__ __forceinline__ void spk_chol_factor(SpkShared& sh) {
         const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33)));
         const double i3 = d3 > tiny ? spk_rsqrt(d3) : 0.0;
         const double pmin = fmin(fmin(d0 > tiny ? d0 : dmax, d1 > tiny ? d1 : dmax), fmin(d2 > tiny ? d2 : dmax, d3 > tiny ? d3 : dmax));
-        // M = L^-1 (lower triangular); a dead pivot makes S singular: bound 0
-        const double m10 = -l10 * i0 * i1, m21 = -l21 * i1 * i2, m32 = -l32 * i2 * i3;
-        const double m20 = -(l20 * i0 + l21 * m10) * i2;
-        const double m31 = -(l31 * i1 + l32 * m21) * i3;
-        const double m30 = -(l30 * i0 + l31 * m10 + l32 * m20) * i3;
-        const double tinv = i0 * i0 + i1 * i1 + i2 * i2 + i3 * i3 + m10 * m10 + m21 * m21 + m32 * m32 + m20 * m20 + m31 * m31 + m30 * m30;
+        // smallest eigenvalue of S by three steps of inverse iteration through the factor (x <- S^-1 x = L^-T L^-1 x from
+        // x = 1): the Rayleigh quotient approaches it from above, fast unless it sits in a cluster (then any value of
+        // the cluster will do); a dead pivot makes S singular: 0
+        double lam_min = 0.0;
+        {
+            double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0, mu = 0.0;
+#pragma unroll
+            for (int itv = 0; itv < 3; ++itv) {
+                // y = L^-1 x (forward), z = L^-T y (backward)
+                const double y0 = x0 * i0;
+                const double y1 = fma(-l10, y0, x1) * i1;
+                const double y2 = fma(-l21, y1, fma(-l20, y0, x2)) * i2;
+                const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, x3))) * i3;
+                const double z3 = y3 * i3;
+                const double z2 = fma(-l32, z3, y2) * i2;
+                const double z1 = fma(-l31, z3, fma(-l21, z2, y1)) * i1;
+                const double z0 = fma(-l30, z3, fma(-l20, z2, fma(-l10, z1, y0))) * i0;
+                const double xx = x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
+                const double xz = x0 * z0 + x1 * z1 + x2 * z2 + x3 * z3;      // x^T S^-1 x
+                mu = xz > 0 ? xx / xz : 0.0;                                   // Rayleigh quotient of S at x
+                const double nz = spk_rsqrt(z0 * z0 + z1 * z1 + z2 * z2 + z3 * z3 + 1e-300);
+                x0 = z0 * nz; x1 = z1 * nz; x2 = z2 * nz; x3 = z3 * nz;
+            }
+            lam_min = mu;
+        }
         const bool full = i0 > 0 && i1 > 0 && i2 > 0 && i3 > 0;
+        const double tinv = full ? 1.0 / lam_min : 0.0;
         if (threadIdx.x == 0) {
             sh.L[0] = i0; sh.L[1] = i1; sh.L[2] = i2; sh.L[3] = i3;
             sh.L[4] = l10; sh.L[5] = l20; sh.L[6] = l30; sh.L[7] = l21; sh.L[8] = l31; sh.L[9] = l32;
             sh.L[10] = dmax > 0 ? pmin / dmax : 1.0;
-            sh.L[11] = full && tinv > 0 ? 1.0 / tinv : 0.0;
+            sh.L[11] = full && tinv > 0 ? lam_min : 0.0;
         }
     }
     __syncthreads();
@@ -588,10 +608,10 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
 // The sums alone cannot tell "converged" from "stalled": when sigma_4 ~ sigma_5 the block finds three directions and a
 // mix of the 4th / 5th, and the sum stops moving with the error (lambda_4 - lambda_5) sin^2 still in it (found by the
 // randomised tests: 6e-5 in a score).  Hence the guard: everything outside the block weighs trace - s, so
-// lambda_5 <= trace - s; accept only if that is at most half of `lam_lb`, a lower bound of the smallest Ritz value in the
-// block (1 / trace(S^-1) of the Gram matrix just factored) - then lambda_5 / lambda_4 <= 1/2, no stall is possible and
-// the measured ratios are real - or if trace - s is itself below the tolerance.  A block that fails the guard
-// SPK_GUARD_IT times is handed to the dense route (16-wide block), where clusters are at home.
+// lambda_5 <= trace - s; accept only if that is at most 0.6 of `lam_lb`, the smallest Ritz value in the block (smallest
+// eigenvalue of the Gram matrix just factored, by inverse iteration) - then lambda_5 / lambda_4 <= 0.6, no stall is
+// possible and the measured ratios are real - or if trace - s is itself below the tolerance.  A block that never
+// passes the guard runs out of half products and is handed to the dense route (16-wide block), where clusters are at home.
 // Tolerance: the score is sqrt(1 - s / trace); 1e-13 relative in s is < 1e-11 in any score >= 0.005.
 __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double trace, int k, double& prev_sum,
                                               double& prev_delta, double& prev_ratio) {
@@ -605,9 +625,11 @@ __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double t
             const double r = fmax(ratio, prev_ratio);
             const double tail = delta * r / (1.0 - r);
             const double rest = trace - s4;                    // >= lambda_5 + lambda_6 + ...
-            const bool gap = rest <= 0.5 * lam_lb || rest <= 1e-13 * trace;
-            // (the Ritz sum itself carries ~2e-15 of rounding noise: a change below 2e-14 is at the floor)
-            if (gap && (delta <= 2e-14 * s4 || tail <= 1e-13 * s4)) conv = true;
+            const bool gap = rest <= 0.6 * lam_lb || rest <= 1e-13 * trace;
+            // Tolerance on s: 1e-13 relative, tightened for tiny scores (d score = d s / (2 score trace): keep it
+            // below 2e-11) down to the rounding floor of the Ritz sum (~2e-15 relative, so 4e-15 is the least asked).
+            const double tol = fmax(fmin(1e-13 * s4, 4e-11 * sqrt(fmax(rest, 0.0) * trace)), 4e-15 * s4);
+            if (gap && (delta <= 0.2 * tol || tail <= tol)) conv = true;
         }
     }
     prev_ratio = ratio;
@@ -1087,6 +1109,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             top4 = 0;
 #pragma unroll
             for (int ww = 0; ww < SPK_WAVES; ++ww) top4 += sh.red[ww];
+            __syncthreads();   // spk_gram reuses sh.red: nobody may still be summing it (a rare race, caught after 36 rounds)
             spk_gram(V, R, v_rs, v_cs, sh);                  // Y^T Y = V^T G^2 V: its eigenvalues are the squared Ritz values
             spk_chol_factor(sh);
             if (spk_converged(top4, sqrt(sh.L[11]), trace, it, prev_sum, prev_delta, prev_ratio)) {
@@ -1127,8 +1150,12 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             scores[sid] = sqrt(op > 0 ? op : 0.0);
             status[sid] = it << 8;
         } else {
-            scores[sid] = 0.0;
-            status[sid] = 2 | (it << 8);  // no spectral gap behind the 4th value: let the 16-wide dense route do it
+            // no spectral gap behind the 4th value: let the 16-wide dense route do it.  The Ritz sum so far is a lower
+            // bound of the top-4 sum, so this is an upper estimate of the score: the host keeps it (status bit 0) for
+            // shapes the dense route cannot take.
+            const double op = 1.0 - top4 / trace;
+            scores[sid] = sqrt(op > 0 ? op : 0.0);
+            status[sid] = 2 | (it << 8);
         }
     }
 }
