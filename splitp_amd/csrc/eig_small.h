@@ -19,7 +19,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 struct EigShared {
     double H[EIG_B * EIG_VP];
     double Q[EIG_B * EIG_VP];
-    double L[EIG_B * EIG_VP];
+    double G1[EIG_B * EIG_VP];  // V^T G V of the current block (first power of G: the values the score is taken from)
     double T[EIG_B * EIG_VP];   // L^-T (upper triangular), dead columns zeroed
     double top4;
     double part[(EIG_WAVES / 2) * 256];  // cross-wave reduction buffer (two waves share a slot)
@@ -283,8 +283,59 @@ __device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh) {
     }
 }
 
+// First-power Rayleigh-Ritz for the final score.  The iteration itself works on G^2 (ritz_orth_nb): its Ritz values
+// sqrt(D_i) carry the rounding of S = Y^T Y, i.e. ~1e-16 lambda_1^2 absolute, which is nothing for a well separated
+// spectrum but ruins an eigenvalue lambda_4 ~ 1e-7 lambda_1 (scores ~1e-4 off by 5e-5 on nearly rank-4 flattenings -
+// found by the randomised tests).  The same subspace span(V) also gives G1 = V^T (G V) = V^T Y at the cost of one more
+// R x 16 x 16 MFMA product, and its eigenvalues are Ritz values of G with absolute error ~1e-16 lambda_1.
+// proj_first_power: Y in LDS (pitch VP), V^T in global memory (16 x vp, store_vt layout) -> sh.G1.  Ends with a barrier.
+template <int VP>
+__device__ __forceinline__ void proj_first_power(const double* Y, int Rp, const double* __restrict__ Vt, int vp,
+                                                 EigShared& sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    double4_t acc = {0, 0, 0, 0};
+    for (int r0 = w * 4; r0 < Rp; r0 += EIG_WAVES * 4) {
+        const double a = Vt[(int64_t)fr * vp + r0 + fk];
+        const double b = Y[(r0 + fk) * VP + fr];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    reduce16(acc, sh, sh.G1);
+}
+
+// sh.top4 = sum of the four largest eigenvalues of the symmetric 16 x 16 matrix in sh.H (destroyed; sh.Q too).
+// Ends with a barrier.
+__device__ __forceinline__ void top4_of_H(EigShared& sh) {
+    jacobi_nb<EIG_B>(sh);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const double th = lane < EIG_B ? sh.theta[lane] : -1e300;
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < EIG_B; ++j) {
+            const double o = __shfl(th, j, 64);
+            rank += (o > th || (o == th && j < lane)) ? 1 : 0;
+        }
+        double pick = (lane < EIG_B && rank < 4) ? fmax(th, 0.0) : 0.0;
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) pick += __shfl_xor(pick, d, 64);
+        if (lane == 0) sh.top4 = pick;
+    }
+    __syncthreads();
+}
+
+// sh.top4 = sum of the four largest eigenvalues of the (symmetrised) sh.G1.
+__device__ __forceinline__ void first_power_top4(EigShared& sh) {
+    if (threadIdx.x < 256) {
+        const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+        sh.H[i * EIG_VP + j] = 0.5 * (sh.G1[i * EIG_VP + j] + sh.G1[j * EIG_VP + i]);
+    }
+    __syncthreads();
+    top4_of_H(sh);
+}
+
 struct EigState {
-    double trace, prev_sum, prev_delta, top4;
+    double trace, prev_sum, prev_delta, prev_ratio, top4;
     int it, done, R, pad;
 };
 
@@ -303,15 +354,21 @@ __device__ __forceinline__ double block_sum(double v, EigShared& sh) {
 }
 
 // Convergence bookkeeping shared by k_eig_rr and k_eig_finish (uniform across the block).
-__device__ __forceinline__ bool update_convergence(double s4, int it, double& prev_sum, double& prev_delta) {
+// The tail is priced with the LARGER of the last two error ratios: successive ratios of a sum of decaying components
+// can only grow, and a single early ratio stopped some splits with 1e-8 left in the score (randomised tests).
+__device__ __forceinline__ bool update_convergence(double s4, int it, double& prev_sum, double& prev_delta,
+                                                   double& prev_ratio) {
     bool conv = false;
     const double delta = fabs(s4 - prev_sum);
+    double ratio = 1.0;
     if (it >= 2) {
-        double ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
+        ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
         ratio = fmin(fmax(ratio, 0.0), 0.9999);
-        const double tail = delta * ratio / (1.0 - ratio);
-        if (delta <= 4e-16 * s4 || (it >= 3 && tail <= 1e-14 * s4)) conv = true;
+        const double r = fmax(ratio, prev_ratio);
+        const double tail = delta * r / (1.0 - r);
+        if (delta <= 4e-16 * s4 || (it >= 4 && tail <= 1e-14 * s4)) conv = true;
     }
+    prev_ratio = ratio;
     prev_delta = delta;
     prev_sum = s4;
     return conv;

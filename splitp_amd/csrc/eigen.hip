@@ -11,7 +11,8 @@
 //     V = Y P D^-1/2     next orthonormal block (+ one Newton-Schulz polish step)
 // until the sum of the four largest Ritz values stops moving (geometric-tail estimate below
 // 1e-14 relative).  Phylogenetic flattenings have lambda_17 / lambda_4 < 1e-3, so this takes 3-4
-// products.
+// products.  The score itself is then taken from the FIRST-power projection G1 = V^T Y of the same
+// subspace (one more 16 x 16 Jacobi, once per split): G^2 values lose eigenvalues below ~1e-7 lambda_1.
 //
 // Launch structure: the product Y = G V is the only heavy step and G (up to 1024^2 doubles per
 // split) has to stream from HBM once per product, so it runs as its own kernel over ALL splits
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_init(const SplitDev* __rest
     for (int i = threadIdx.x; i < R; i += EIG_THREADS) tr += (double)G[(int64_t)i * gp + i];
     tr = block_sum(tr, sh);
     EigState st;
-    st.trace = tr; st.prev_sum = 0; st.prev_delta = 0; st.top4 = 0; st.it = 0; st.done = 0; st.R = R; st.pad = 0;
+    st.trace = tr; st.prev_sum = 0; st.prev_delta = 0; st.prev_ratio = 1.0; st.top4 = 0; st.it = 0; st.done = 0; st.R = R; st.pad = 0;
     if (R <= 4 || !(tr > 0)) {
         // min(shape) <= 4: the reference computes 1 - x/x = 0 exactly; all-zero matrix: 0/0 = nan
         if (threadIdx.x == 0) {
@@ -71,6 +72,23 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_init(const SplitDev* __rest
             status[sid] = 0;
             st.done = 1;
             states[sid] = st;
+        }
+        return;
+    }
+    if (R <= EIG_B) {
+        // The whole Gram matrix fits the 16 x 16 Jacobi: eigenvalues directly, to full relative accuracy (an iteration
+        // on G^2 drops eigenvalues below ~1e-7 lambda_1, which on a nearly rank-4 flattening IS the score)
+        if (threadIdx.x < 256) {
+            const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+            sh.H[i * EIG_VP + j] = (i < R && j < R) ? (double)G[(int64_t)i * gp + j] : 0.0;
+        }
+        __syncthreads();
+        top4_of_H(sh);
+        if (threadIdx.x == 0) {
+            st.done = 1;
+            st.top4 = sh.top4;
+            states[sid] = st;
+            write_score(st.top4, st.trace, 1, true, scores, status, sid);
         }
         return;
     }
@@ -181,12 +199,15 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_rr(const SplitDev* __restri
     for (int e = threadIdx.x; e < Rp * EIG_B; e += EIG_THREADS) V[(e >> 4) * EIG_VP + (e & 15)] = Y[e];
     __syncthreads();
     STAMP(1);
+    proj_first_power<EIG_VP>(V, Rp, Vt, vp, sh);  // G1 = V^T G V on the block that produced Y (kept for the final score)
     ritz_orth16(V, Rp, sh);  // Ritz values (sh.top4) + next orthonormal block in one pass
     STAMP(2);
     st.it += 1;
     st.top4 = sh.top4;
-    const bool conv = update_convergence(sh.top4, st.it, st.prev_sum, st.prev_delta);
+    const bool conv = update_convergence(sh.top4, st.it, st.prev_sum, st.prev_delta, st.prev_ratio);
     if (conv) {
+        first_power_top4(sh);  // the score comes from the first-power Ritz values of the same subspace
+        st.top4 = sh.top4;
         if (threadIdx.x == 0) {
             st.done = 1;
             states[sid] = st;
@@ -223,7 +244,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_finish(const SplitDev* __re
     load_vt(V, Rp, vt_pool + sp.ev_off, sp.rcap);
     __syncthreads();
     const int ntile = Rp >> 4;
-    int converged = 0;
+    int converged = 0, ran = 0;
     while (st.it < EIG_MAXIT) {
         // ---- Y = G V : wave w owns row tiles w, w+8, ... ; k outer so one V fragment feeds all tiles
         double4_t acc[EIG_MAXT];
@@ -241,6 +262,19 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_finish(const SplitDev* __re
                 }
             }
         }
+        // G1 = V^T Y while V is still in LDS and Y in the accumulators: accumulator r of a tile holds rows 4r + fk of
+        // Y - exactly the B operand of an MFMA whose 4 k's are those rows
+        double4_t h1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < EIG_MAXT; ++t) {
+            const int tile = w + t * EIG_WAVES;
+            if (tile < ntile) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    h1 = __builtin_amdgcn_mfma_f64_16x16x4f64(V[(tile * 16 + 4 * r + fk) * EIG_VP + fr], acc[t][r], h1,
+                                                              0, 0, 0);
+            }
+        }
         __syncthreads();  // every wave is done reading V
 #pragma unroll
         for (int t = 0; t < EIG_MAXT; ++t) {
@@ -250,14 +284,19 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_finish(const SplitDev* __re
                 for (int r = 0; r < 4; ++r) V[(tile * 16 + fk + 4 * r) * EIG_VP + fr] = acc[t][r];
             }
         }
-        __syncthreads();
+        reduce16(h1, sh, sh.G1);  // (starts with the barrier that publishes V)
         ritz_orth16(V, Rp, sh);
         st.it += 1;
         st.top4 = sh.top4;
-        if (update_convergence(sh.top4, st.it, st.prev_sum, st.prev_delta)) {
+        ran = 1;
+        if (update_convergence(sh.top4, st.it, st.prev_sum, st.prev_delta, st.prev_ratio)) {
             converged = 1;
             break;
         }
+    }
+    if (ran) {
+        first_power_top4(sh);
+        st.top4 = sh.top4;
     }
     if (threadIdx.x == 0) {
         st.done = 1;
