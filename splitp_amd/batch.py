@@ -78,6 +78,11 @@ def score_encoded(al, split_taxa, split_a, method_code, scores_dev_ptr=None, wan
         al.handle, _lib._ptr(split_taxa, C.c_int32), _lib._ptr(split_a, C.c_int32), n, method_code,
         _lib._ptr(scores, C.c_double), C.c_void_p(scores_dev_ptr) if scores_dev_ptr else None,
         _lib._ptr(status, C.c_int32)))
+    if want_host and np.any(status & 1):
+        import warnings
+
+        warnings.warn(f"{int(np.sum((status & 1) != 0))} of {n} splits hit the iteration cap of their eigen-solver: "
+                      "their scores are upper estimates (status bit 0)", RuntimeWarning, stacklevel=2)
     return scores, status
 
 

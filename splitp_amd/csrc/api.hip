@@ -739,8 +739,53 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
             if (redo.empty()) return SP_OK;
         }
     }
-    // dense route on the handed-back subset (overwrites the context pools, hence the parking buffer)
     const int n = al->n_taxa;
+    {   // Splits the 4-wide block could not finish (status 2 with half products on the clock) whose smaller side is beyond
+        // the dense route's 1024-row eigen kernels: the same kernel with the 8-wide fallback block, arrays in global memory.
+        // Its answer is final (status bit 0 if even that ran into its cap).
+        std::vector<int> widev;
+        int64_t bmw = 0;
+        for (int i : redo) {
+            const SplitDev& sd = plan.splits[i];
+            const int64_t rmax = std::min<int64_t>(pow4(std::min(sd.nr, sd.nc)), std::max<int64_t>(al->D, 1));
+            if ((st[i] >> 8) != 0 && round_up(rmax, 64) > EIG_MAXR) {
+                widev.push_back(i);
+                bmw = std::max<int64_t>(bmw, (int64_t)sd.rw + sd.cw);
+            }
+        }
+        if (!widev.empty() && al->spk_D <= 65535) {
+            const size_t slab = (sparse_slab_bytes(al->spk_D, bmw, true) + 255) & ~(size_t)255;
+            const size_t chunk = std::max<size_t>(1, std::min<size_t>(widev.size(), ((size_t)2 << 30) / slab));
+            DevBuf widx;
+            DevBuf& slabs = ctx->slabs;
+            int rc2 = SP_OK;
+            if ((rc2 = slabs.ensure(chunk * slab)) || (rc2 = widx.ensure(widev.size() * 4))) {
+                widx.release();
+                return rc2;
+            }
+            hipError_t e = hipMemcpyAsync(widx.p, widev.data(), widev.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+            for (size_t k0 = 0; k0 < widev.size() && e == hipSuccess && rc2 == SP_OK; k0 += chunk) {
+                const size_t cnt = std::min(chunk, widev.size() - k0);
+                rc2 = launch_sparse_score_hbm(ctx, ctx->aldescs.as<AlDesc>(), al->n_taxa, ctx->splits.as<SplitDev>(),
+                                              widx.as<int>() + k0, (int64_t)cnt, S, ctx->scores.as<double>(),
+                                              ctx->status.as<int>(), slabs.as<unsigned char>(), slab, true);
+            }
+            if (e == hipSuccess && rc2 == SP_OK)
+                e = hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            widx.release();
+            if (rc2 != SP_OK) return rc2;
+            if (e != hipSuccess) {
+                sp_set_error("sparse route (wide block): %s", hipGetErrorString(e));
+                return SP_EHIP;
+            }
+            redo.clear();
+            for (int64_t i = 0; i < S; ++i)
+                if (st[i] & 2) redo.push_back((int)i);
+            if (redo.empty()) return SP_OK;
+        }
+    }
+    // dense route on the handed-back subset (overwrites the context pools, hence the parking buffer)
     std::vector<int32_t> t2(redo.size() * (size_t)n), a2(redo.size());
     for (size_t k = 0; k < redo.size(); ++k) {
         memcpy(&t2[k * n], split_taxa + (size_t)redo[k] * n, (size_t)n * 4);

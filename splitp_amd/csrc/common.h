@@ -175,6 +175,7 @@ struct PhaseScope {
     ~PhaseScope();
 };
 
+#define EIG_MAXR 1024   // rows of the smaller side the dense route's eigen kernels hold in LDS (eig_small.h: 8 waves x 8 tiles x 16)
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int64_t pow4(int k) { return (int64_t)1 << (2 * k); }
 
@@ -199,10 +200,10 @@ int launch_gram_i8(sp_ctx* ctx, int nl, bool g_i32, const SplitDev* splits_dev, 
 int launch_divergence(sp_ctx* ctx, bool exact, int64_t D, int64_t S, const u32* rr, const u32* cc, const u32* counts,
                       const double* weights, double n_total, unsigned long long* marg, double* out);
 int launch_divergence_matrix(sp_ctx* ctx, const double* m_dev, int64_t rows, int64_t cols, double* scratch, double* out);
-size_t sparse_slab_bytes(int64_t D, int64_t bm_words);
+size_t sparse_slab_bytes(int64_t D, int64_t bm_words, bool wide = false);
 int launch_sparse_score_hbm(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, const SplitDev* splits_dev,
                             const int* order_dev, int64_t S_sub, int64_t S, double* scores, int* status,
-                            unsigned char* slabs, size_t slab_bytes);
+                            unsigned char* slabs, size_t slab_bytes, bool wide = false);
 int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta,
                        unsigned long long trace_override, int64_t orig_rows);
 int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,

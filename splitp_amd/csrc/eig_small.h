@@ -13,7 +13,6 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #define EIG_B 16
 #define EIG_VP 17        // V row pitch in doubles (odd pitch: row-wise and tile-wise reads conflict-free)
 #define EIG_MAXT 8       // row tiles of 16 per wave -> R_pad <= 8 * 8 * 16 = 1024
-#define EIG_MAXR 1024
 #define EIG_MAXIT 400
 
 struct EigShared {

@@ -26,6 +26,8 @@
 // a slab of global memory (HBM = true); one that has not converged after SPK_MAXIT products goes to the dense route.
 #include "common.h"
 
+#include "eig_small.h"   // jacobi_nb / EigShared for the wide fallback block
+
 #ifndef SPK_THREADS
 #define SPK_THREADS 1024
 #endif
@@ -647,6 +649,144 @@ __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double t
     return conv;
 }
 
+
+// ---- wide fallback block (HBM form only) ---------------------------------------------------------------------------
+// A 4-wide block converges by lambda_5 / lambda_4 per half product: tables whose flattenings have a cluster or a slowly
+// decaying spectrum behind the 4th value (found by the randomised tests at 12 taxa, where the dense route cannot take
+// over) run out of half products.  Such splits are re-run with SPK_WB = 8 columns: the same lists and the same product
+// code (two 4-column passes), but the Ritz values are the eigenvalues of the 8 x 8 Gram matrix of the fresh block
+// (one-wave Jacobi, eig_small.h) - the top-4 sum then converges by lambda_9 / lambda_4 and a cluster at the 4th value
+// sits inside the block - and the block is re-orthonormalised as X Q D^-1/2 plus Newton-Schulz polish.
+#define SPK_WB 8
+#define SPK_MAXHALF_WIDE 600
+
+// esh.H (16 x EIG_VP, first 8 x 8 used) = X^T X of the rows x 8 column-major block X: one (i, j >= i) pair per wave and
+// turn, lanes stride the rows, fixed shuffle tree.  Ends with a barrier.
+__device__ __forceinline__ void spk_wide_gram(const double* X, int rows, int cs, EigShared& esh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int p = w; p < SPK_WB * (SPK_WB + 1) / 2; p += SPK_WAVES) {
+        int i = 0, q = p;
+        while (q >= SPK_WB - i) { q -= SPK_WB - i; ++i; }
+        const int j = i + q;
+        const double* xi = X + (size_t)i * cs;
+        const double* xj = X + (size_t)j * cs;
+        double a = 0;
+        for (int r = lane; r < rows; r += 64) a = fma(xi[r], xj[r], a);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+        if (lane == 0) {
+            esh.H[i * EIG_VP + j] = a;
+            esh.H[j * EIG_VP + i] = a;
+        }
+    }
+    __syncthreads();
+}
+
+// X <- X T for the 8 x 8 matrix esh.T (row-major, pitch EIG_VP): one row per thread and turn.  Ends with a barrier.
+__device__ __forceinline__ void spk_wide_apply(double* X, int rows, int cs, const EigShared& esh) {
+    for (int r = threadIdx.x; r < rows; r += SPK_THREADS) {
+        double x[SPK_WB], y[SPK_WB];
+#pragma unroll
+        for (int k = 0; k < SPK_WB; ++k) x[k] = X[(size_t)k * cs + r];
+#pragma unroll
+        for (int j = 0; j < SPK_WB; ++j) {
+            double a = 0;
+#pragma unroll
+            for (int k = 0; k < SPK_WB; ++k) a = fma(x[k], esh.T[k * EIG_VP + j], a);
+            y[j] = a;
+        }
+#pragma unroll
+        for (int j = 0; j < SPK_WB; ++j) X[(size_t)j * cs + r] = y[j];
+    }
+    __syncthreads();
+}
+
+// Rayleigh-Ritz + orthonormalisation of the fresh block X = op(X_in), X_in orthonormal: eigenvalues of X^T X are the
+// Ritz values of the operator's Gram form on span(X_in).  Out: sum of the 4 largest (top4), the 4th largest (th4), the
+// sum of all 8 (sum8).  X becomes orthonormal (dead directions - eigenvalue <= 1e-24 of the largest - become zero columns).
+__device__ __forceinline__ void spk_wide_ritz_orth(double* X, int rows, int cs, EigShared& esh, double& top4, double& th4,
+                                                   double& sum8) {
+    spk_wide_gram(X, rows, cs, esh);
+    jacobi_nb<SPK_WB>(esh);
+    double th[SPK_WB];
+    double tmax = 0;
+#pragma unroll
+    for (int k = 0; k < SPK_WB; ++k) {
+        th[k] = fmax(esh.theta[k], 0.0);
+        tmax = fmax(tmax, th[k]);
+    }
+    sum8 = 0;
+    top4 = 0;
+    th4 = 0;
+#pragma unroll
+    for (int k = 0; k < SPK_WB; ++k) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < SPK_WB; ++j) rank += (th[j] > th[k] || (th[j] == th[k] && j < k)) ? 1 : 0;
+        sum8 += th[k];
+        if (rank < 4) top4 += th[k];
+        if (rank == 3) th4 = th[k];
+    }
+    if (threadIdx.x < SPK_WB * SPK_WB) {
+        const int i = threadIdx.x / SPK_WB, j = threadIdx.x % SPK_WB;
+        const double rj = (esh.theta[j] > 1e-24 * tmax && esh.theta[j] > 0) ? 1.0 / sqrt(esh.theta[j]) : 0.0;
+        esh.T[i * EIG_VP + j] = esh.Q[i * EIG_VP + j] * rj;
+    }
+    __syncthreads();
+    spk_wide_apply(X, rows, cs, esh);
+    for (int pass = 0; pass < 6; ++pass) {   // Newton-Schulz polish: X <- X (1.5 I - 0.5 X^T X)
+        spk_wide_gram(X, rows, cs, esh);
+        double err = 0;
+#pragma unroll
+        for (int i = 0; i < SPK_WB; ++i) {
+            const bool live = esh.H[i * EIG_VP + i] > 0.25;
+#pragma unroll
+            for (int j = 0; j < SPK_WB; ++j)
+                err = fmax(err, fabs(esh.H[i * EIG_VP + j] - ((i == j && live) ? 1.0 : 0.0)));
+        }
+        __syncthreads();   // everybody has read H
+        if (err <= 4e-15) break;
+        if (threadIdx.x < SPK_WB * SPK_WB) {
+            const int i = threadIdx.x / SPK_WB, j = threadIdx.x % SPK_WB;
+            esh.T[i * EIG_VP + j] = (i == j ? 1.5 : 0.0) - 0.5 * esh.H[i * EIG_VP + j];
+        }
+        __syncthreads();
+        spk_wide_apply(X, rows, cs, esh);
+    }
+}
+
+// Stop rule of the wide block.  The slowest error component decays by lambda_9 / lambda_4 <= (trace - sum8) / th4 per half
+// product; where that bound is useful (< 0.9) it certifies the score to 5e-11 as in spk_converged, otherwise (heavy
+// tails: thousands of small eigenvalues outweigh lambda_4) the two-ratio estimate has to meet a ten times tighter tolerance.
+__device__ __forceinline__ bool spk_wide_converged(double s4, double th4, double sum8, double trace, int k, double& prev_sum,
+                                                   double& prev_delta, double& prev_ratio) {
+    bool conv = false;
+    const double delta = fabs(s4 - prev_sum);
+    double ratio = 1.0;
+    if (k >= 3) {
+        ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
+        ratio = fmin(fmax(ratio, 0.0), 0.9999);
+        if (k >= 4) {
+            const double rest = trace - s4;
+            const double r = fmax(ratio, prev_ratio);
+            const double tail = delta * r / (1.0 - r);
+            const double sx = sqrt(fmax(rest, 0.0) * trace);
+            const double tol = fmax(fmin(1e-13 * s4, 4e-11 * sx), 4e-15 * s4);
+            const double rho_b = th4 > 0 ? fmax(trace - sum8, 0.0) / th4 : 1.0;
+            if (rho_b < 0.9) {
+                const bool bounded = delta * rho_b / (1.0 - rho_b) <= fmax(1e-10 * sx, 4e-15 * s4);
+                conv = bounded && (delta <= 0.2 * tol || tail <= tol);
+            } else {
+                conv = k >= 6 && (delta <= 0.1 * tol || tail <= 0.1 * tol);
+            }
+        }
+    }
+    prev_ratio = ratio;
+    prev_delta = delta;
+    prev_sum = s4;
+    return conv;
+}
+
 // status: bit 0 = iteration cap hit (score written but flagged), bit 1 = not handled here (re-score on the
 // dense route), bits 8.. = number of operator applications.
 
@@ -659,7 +799,7 @@ __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double t
 // column sides of ~1800 ids).  Communication inside the workgroup then goes through global memory: plain stores are
 // coherent at workgroup scope after __syncthreads(); words that were updated by ATOMICS (key bitmaps, sort counters, the
 // integer Gram) are read back with agent-scope atomic loads (spk_aload), since device atomics are done in L2 past the L1.
-template <bool HBM>
+template <bool HBM, bool WIDE = false>
 __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __restrict__ als, int n_al, int n,
                                                               const SplitDev* __restrict__ splits,
                                                               const int* __restrict__ order, int S,
@@ -668,6 +808,10 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
                                                               unsigned char* __restrict__ slabs, size_t slab_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SpkShared& sh = *reinterpret_cast<SpkShared*>(smem);
+    // wide fallback block (HBM form only: its LDS holds nothing but SpkShared, so the Jacobi workspace sits behind it)
+    constexpr bool wide_on = HBM && WIDE;   // (its own instantiation: the extra live state must not cost the others registers)
+    EigShared& esh = *reinterpret_cast<EigShared*>(smem + ((sizeof(SpkShared) + 15) & ~(size_t)15));
+    constexpr int NBC = wide_on ? SPK_WB : SPK_NB;
     unsigned char* const base = HBM ? slabs + (size_t)blockIdx.x * slab_bytes : smem;
     const size_t cap = HBM ? slab_bytes : (slab_bytes ? slab_bytes : (size_t)SPK_LDS_BYTES);   // (LDS form: slab_bytes = debug cap)
     const int ai = blockIdx.x % n_al;
@@ -713,7 +857,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     const int r_cap = raw_r ? (1 << (2 * nr)) : (int)min((long long)D, nr >= 8 ? (long long)D : (1ll << (2 * nr)));
     // (a table with split counts - several rows per pattern - can have more than R entries in a column, which the 8-bit
     // sort counters of the small path do not hold: such tables take the general path)
-    const bool small_sure = r_cap <= SPK_SMALL_R && (u32)Di == sh.ntab;   // then no CSR list is needed
+    const bool small_sure = r_cap <= SPK_SMALL_R && (u32)Di == sh.ntab && !wide_on;   // then no CSR list is needed
     const size_t need_build = off + (size_t)(D + 8) * (small_sure ? 4 : 8) + (size_t)D * 6 + (size_t)W * 12 + 4096 + 256;
     if (D > 65535 || n > 16 || need_build + 2048 > cap) {
         if (threadIdx.x == 0) {
@@ -863,9 +1007,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     const int Kcp = ((Kc + 3) & ~3) + 4;
     const int Vp = Rp + 4;
     const int v_rs = 1, v_cs = Vp, w_rs = 1, w_cs = Kcp;
-    const size_t base_iter = off_after_lists + (size_t)Vp * 4 * 8 + 16;
+    const size_t base_iter = off_after_lists + (size_t)Vp * NBC * 8 + 16;
     const int Gp = R | 1;   // odd row pitch of the dense G: a pitch of 64 doubles puts every row on the same LDS bank
-    const size_t need_iter = base_iter + (small ? (size_t)R * Gp * 8 : (size_t)Kcp * 4 * 8);
+    const size_t need_iter = base_iter + (small ? (size_t)R * Gp * 8 : (size_t)Kcp * NBC * 8);
     // small path: column of every CSC position (for the entry-parallel Gram below), carved from the top as well
     unsigned short* colof = small ? reinterpret_cast<unsigned short*>(carve_top((size_t)Di * 2)) : nullptr;
     // counters: rows of 16-bit (8-bit when a group cannot exceed 255 entries) fields
@@ -967,7 +1111,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     SSTAMP(4);
     // V and W / G are laid out over the (now dead) staging area
     off = off_after_lists;
-    double* V = reinterpret_cast<double*>(carve((size_t)Vp * 4 * 8));
+    double* V = reinterpret_cast<double*>(carve((size_t)Vp * NBC * 8));
     double* Wb = reinterpret_cast<double*>(base + off);   // large: W (Kc x 4);  small: G (R x R)
     if (small) {
         // exact Gram G = C C^T: all pairs of entries inside every column, accumulated with integer LDS atomics (exact,
@@ -1076,6 +1220,13 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
 #pragma unroll
             for (int k = 0; k < SPK_NB; ++k)
                 Wb[c * w_rs + k * w_cs] = amp[k] * (double)((float)((int)(h << (8 * k)) >> 24) * (1.0f / 128.0f));
+            if (wide_on) {   // columns 4..7 of the wide block: noise only
+                u32 g = h * 0x85EBCA77u + 0x165667B1u;
+                g ^= g >> 13; g *= 0xC2B2AE3Du; g ^= g >> 16;
+#pragma unroll
+                for (int k = 0; k < SPK_NB; ++k)
+                    Wb[c * w_rs + (SPK_NB + k) * w_cs] = (double)((float)((int)(g << (8 * k)) >> 24) * (1.0f / 128.0f));
+            }
         }
         for (int idx = threadIdx.x; idx < R; idx += SPK_THREADS) {   // where do the 4 rows sit in the CSR layout?
             const int m = perm_r[idx];
@@ -1094,9 +1245,14 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             }
         }
         __syncthreads();
-        spk_gram(Wb, Kc, w_rs, w_cs, sh);
-        spk_chol_factor(sh);
-        spk_orth(Wb, Kc, w_rs, w_cs, sh);
+        if (wide_on) {
+            double t0, t1, t2;
+            spk_wide_ritz_orth(Wb, Kc, w_cs, esh, t0, t1, t2);   // here only as an orthonormaliser
+        } else {
+            spk_gram(Wb, Kc, w_rs, w_cs, sh);
+            spk_chol_factor(sh);
+            spk_orth(Wb, Kc, w_rs, w_cs, sh);
+        }
     }
     SSTAMP(5);
     SSTAMP(6);
@@ -1129,14 +1285,27 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         }
     } else {
         SSTAMP(7);
-        for (it = 2; it <= SPK_MAXHALF; ++it) {
-            // (one call site: the product code is inlined once, the kernel has to stay inside the 64 KB instruction cache)
+        const int maxhalf = wide_on ? SPK_MAXHALF_WIDE : SPK_MAXHALF;
+        for (it = 2; it <= maxhalf; ++it) {
+            // (one call site: the product code is inlined once, the kernel has to stay inside the 64 KB instruction cache;
+            // the wide block makes two 4-column passes)
             const bool odd = it & 1;                          // odd: W = C^T V (CSC)   even: Y = C W (CSR)
             double* X = odd ? Wb : V;
             const int rows = odd ? Kc : R, xrs = odd ? w_rs : v_rs, xcs = odd ? w_cs : v_cs;
-            spk_spmm(odd ? desc_c : desc_r, odd ? csc_ent : csr_ent, rows, odd ? perm_c : perm_r, odd ? sh.nw_c : sh.nw_r,
-                     odd ? sh.nr_c : sh.nr_r, odd ? sh.nq_c : sh.nq_r, odd ? V : Wb, odd ? v_rs : w_rs, odd ? v_cs : w_cs, X,
-                     xrs, xcs, it == 3 ? 20 : -1);
+            const int ics = odd ? v_cs : w_cs;
+            for (int cb = 0; cb < NBC; cb += SPK_NB)
+                spk_spmm(odd ? desc_c : desc_r, odd ? csc_ent : csr_ent, rows, odd ? perm_c : perm_r, odd ? sh.nw_c : sh.nw_r,
+                         odd ? sh.nr_c : sh.nr_r, odd ? sh.nq_c : sh.nq_r, (odd ? V : Wb) + (size_t)cb * ics, odd ? v_rs : w_rs,
+                         ics, X + (size_t)cb * xcs, xrs, xcs, it == 3 ? 20 : -1);
+            if (wide_on) {
+                double th4, sum8;
+                spk_wide_ritz_orth(X, rows, xcs, esh, top4, th4, sum8);
+                if (spk_wide_converged(top4, th4, sum8, trace, it - 1, prev_sum, prev_delta, prev_ratio)) {
+                    conv = 1;
+                    break;
+                }
+                continue;
+            }
             if (it == 2) SSTAMP(9);
             if (it == 3) SSTAMP(8);
             spk_gram(X, rows, xrs, xcs, sh);
@@ -1164,7 +1333,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             // shapes the dense route cannot take.
             const double op = 1.0 - top4 / trace;
             scores[sid] = sqrt(op > 0 ? op : 0.0);
-            status[sid] = 2 | (it << 8);
+            status[sid] = (wide_on ? 1 : 2) | (it << 8);   // (the wide block is the last resort: flagged, not handed on)
         }
     }
 }
@@ -1251,21 +1420,26 @@ int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa
 
 // Bytes of global memory one workgroup of the HBM form needs for a table of D patterns whose bitmaps take `bm_words`
 // 64-bit words: the same carve as the LDS form with every size at its a-priori bound (sides <= max(D, 1024) ids).
-size_t sparse_slab_bytes(int64_t D, int64_t bm_words) {
+size_t sparse_slab_bytes(int64_t D, int64_t bm_words, bool wide) {
     const size_t d1 = (size_t)std::max<int64_t>(D, 1024) + 16;
-    return (size_t)(D + 8) * 8 + (size_t)D * 6 + (size_t)bm_words * 12 + d1 * (16 + 16 + 2 * 48) + (size_t)D * 2 + 65536;
+    return (size_t)(D + 8) * 8 + (size_t)D * 6 + (size_t)bm_words * 12 + d1 * (16 + 16 + 2 * (wide ? 96 : 48)) +
+           (size_t)D * 2 + 65536;
 }
 
 // The splits listed in order_dev[0 .. S_sub) (indices into the split / score arrays), one alignment, HBM form.
 int launch_sparse_score_hbm(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, const SplitDev* splits_dev,
                             const int* order_dev, int64_t S_sub, int64_t S, double* scores, int* status,
-                            unsigned char* slabs, size_t slab_bytes) {
+                            unsigned char* slabs, size_t slab_bytes, bool wide) {
     if (S_sub == 0) return SP_OK;
     if (ctx->upload_ev) SP_HIP(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
     PhaseScope ps(ctx, SP_PHASE_SPARSE);
-    const size_t lds = (sizeof(SpkShared) + 31) & ~(size_t)15;
-    hipLaunchKernelGGL(k_sparse_score<true>, dim3((unsigned)S_sub), dim3(SPK_THREADS), lds, ctx->stream, als_dev, 1, n_taxa,
-                       splits_dev, order_dev, (int)S, scores, status, slabs, slab_bytes);
+    const size_t lds = ((sizeof(SpkShared) + 31) & ~(size_t)15) + sizeof(EigShared) + 16;
+    if (wide)
+        hipLaunchKernelGGL((k_sparse_score<true, true>), dim3((unsigned)S_sub), dim3(SPK_THREADS), lds, ctx->stream, als_dev,
+                           1, n_taxa, splits_dev, order_dev, (int)S, scores, status, slabs, slab_bytes);
+    else
+        hipLaunchKernelGGL((k_sparse_score<true, false>), dim3((unsigned)S_sub), dim3(SPK_THREADS), lds, ctx->stream, als_dev,
+                           1, n_taxa, splits_dev, order_dev, (int)S, scores, status, slabs, slab_bytes);
     SP_HIP(hipGetLastError());
     return SP_OK;
 }

@@ -829,3 +829,34 @@ def test_subflattening_and_histogram_random(sp):
         uk, uc = np.unique(k64[valid], return_counts=True)
         keys, w, cnt = dev.fetch()
         assert np.array_equal(keys, uk) and np.array_equal(cnt, uc) and dev.info()["N"] == int(valid.sum())
+
+
+def test_wide_block_fallback_12_taxa(sp):
+    """12-taxon tables whose flattenings have a slowly decaying spectrum behind the 4th value: the 4-wide block runs out of
+    half products, the dense route cannot take sides beyond 1024 rows, so the kernel's 8-wide fallback block has to finish
+    them (api.hip run_sparse_route; status shows > 41 half products).  Found by the randomised hunt (tools/gpu_fuzz_long.py)."""
+    went_wide = 0
+    for seed in (1, 3):
+        rng = np.random.default_rng(seed)
+        n = 12
+        keys, counts = _copy_mutate_table(rng, n, 20000, 3)
+        names = taxa_names(n)
+        dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=int(counts.sum()), taxa=names)
+        splits = []
+        for _ in range(16):
+            k = int(rng.integers(2, n - 1))
+            left = sorted(rng.choice(n, size=k, replace=False).tolist())
+            splits.append((tuple(names[t] for t in left), tuple(names[t] for t in range(n) if t not in left)))
+        got, st = sp.score_splits(dev, splits, return_status=True)
+        assert not np.any(np.asarray(st) & 3), [hex(x) for x in st]
+        went_wide += int(np.sum((np.asarray(st) >> 8) > 41))
+        again = sp.score_splits(dev, splits)
+        assert np.array_equal(got, again)                    # reproducible bit for bit, fallback included
+        for i, spl in enumerate(splits):
+            m = O.reduced_flattening_packed(keys, counts.astype(np.float64), n, [names.index(t) for t in spl[0]],
+                                            [names.index(t) for t in spl[1]])[0]
+            if min(m.shape) > 400:
+                continue
+            want = 0.0 if min(m.shape) <= 4 else O.dense_split_score(m)
+            assert abs(want - got[i]) <= SCORE_TOL, (seed, i, m.shape, want, got[i], hex(st[i]))
+    assert went_wide > 0   # (if this fires the tables no longer reach the fallback: pick harder ones)
