@@ -165,7 +165,7 @@ __device__ __forceinline__ void spk_gram(const double* X, int rows, int rs, int 
 // Factor: wave 0 (64 lanes redundantly, no divergence) -> sh.L = 1 / l_jj (4), l_10 l_20 l_30 l_21 l_31 l_32, the pivot
 // ratio, and an estimate of the smallest eigenvalue of S (inverse iteration).
 // Ends with a barrier.
-__device__ __forceinline__ void spk_chol_factor(SpkShared& sh) {
+__device__ __forceinline__ void spk_chol_factor(SpkShared& sh, bool want_lam = true) {
     if (threadIdx.x < 64) {
         const double s00 = sh.S[0], s10 = sh.S[4], s20 = sh.S[8], s30 = sh.S[12];
         const double s11 = sh.S[5], s21 = sh.S[9], s31 = sh.S[13], s22 = sh.S[10], s32 = sh.S[14], s33 = sh.S[15];
@@ -187,7 +187,7 @@ __device__ __forceinline__ void spk_chol_factor(SpkShared& sh) {
         // x = 1): the Rayleigh quotient approaches it from above, fast unless it sits in a cluster (then any value of
         // the cluster will do); a dead pivot makes S singular: 0
         double lam_min = 0.0;
-        {
+        if (want_lam) {   // (uniform; only the convergence test reads it, from its 4th sum on)
             double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0, mu = 0.0;
 #pragma unroll
             for (int itv = 0; itv < 3; ++itv) {
@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             for (int ww = 0; ww < SPK_WAVES; ++ww) top4 += sh.red[ww];
             __syncthreads();   // spk_gram reuses sh.red: nobody may still be summing it (a rare race, caught after 36 rounds)
             spk_gram(V, R, v_rs, v_cs, sh);                  // Y^T Y = V^T G^2 V: its eigenvalues are the squared Ritz values
-            spk_chol_factor(sh);
+            spk_chol_factor(sh, it >= 4);
             if (spk_converged(top4, sqrt(sh.L[11]), trace, it, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
                 break;
@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             spk_gram(X, rows, xrs, xcs, sh);
             if (it == 2) SSTAMP(40);
             top4 = (sh.S[0] + sh.S[5]) + (sh.S[10] + sh.S[15]);
-            spk_chol_factor(sh);
+            spk_chol_factor(sh, it >= 5);
             // (the first real Ritz sum is that of half product 2)
             if (spk_converged(top4, sh.L[11], trace, it - 1, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
