@@ -228,6 +228,7 @@ template <int NB, int VP>
 __device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh) {
     gram_nb<NB, VP>(X, Rp, sh, sh.H);
     jacobi_nb<NB>(sh);
+    bool weak;
     // top-4 sum + T = P D^-1/2 (256 threads)
     {
         double dmax = 0;
@@ -246,19 +247,40 @@ __device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh) {
             for (int d = 8; d >= 1; d >>= 1) pick += __shfl_xor(pick, d, 64);
             if (lane == 0) sh.top4 = pick;
         }
+        // S = Y^T Y carries absolute rounding errors of ~1e-16 dmax, so an eigenvalue below ~3e-15 dmax is noise, and
+        // normalising a column by the square root of noise made X^T X explode in the polish below (nan scores on a
+        // probability-scaled table - found by the randomised tests).  The COLUMN Y q_j itself is fine, though: it is a
+        // sum of O(|Y|) terms, good to ~1e-16 lambda_1 absolute, i.e. it still carries the direction of an eigenvalue
+        // lambda_j ~ 1e-9 lambda_1 of G with 7 digits - and on a matrix of numerical rank < 4 such a direction decides
+        // the score.  So a weak column is scaled by the clamped factor only (its norm stays < 1) and, when there are
+        // weak columns, the block is orthonormalised a second time from ITS OWN Gram matrix, which sees them at their
+        // own scale (CholeskyQR2 in Jacobi form).  Directions that are still < 1e-6 after the clamped scaling are dead.
+        weak = false;
+        for (int k = 0; k < NB; ++k) weak = weak || !(sh.theta[k] > 1e-10 * dmax);
         if (threadIdx.x < 256) {
             const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
-            const double dj = sh.theta[j];
-            // S = Y^T Y carries absolute rounding errors of ~1e-16 dmax, so an eigenvalue below ~3e-15 dmax is noise;
-            // normalising a column by the square root of noise made X^T X explode in the polish below (nan scores on a
-            // probability-scaled table - found by the randomised tests).  Such a direction (lambda_i < 3e-7 lambda_1 of
-            // G) is dropped from the block (lambda_i < 6e-8 lambda_1 of G); it could only matter for a matrix of numerical rank < 4.
-            const double rj = (dj > 3e-15 * dmax && dj > 0) ? rsqrt_nr(dj) : 0.0;
+            const double dj = fmax(sh.theta[j], 3e-15 * dmax);
+            // (the f32 seed of rsqrt_nr needs its argument inside the f32 range: G^2 values of a matrix scaled by 1e-8 or
+            // 1e+5 are not - 0 or inf came back and the score was 1 - so the exponent is split off first, exactly)
+            const int ej = (dj > 0) ? (ilogb(dj) & ~1) : 0;
+            const double rj = dj > 0 ? scalbn(rsqrt_nr(scalbn(dj, -ej)), -(ej / 2)) : 0.0;
             sh.T[i * EIG_VP + j] = (i < NB && j < NB) ? sh.Q[i * EIG_VP + j] * rj : 0.0;
         }
         __syncthreads();
     }
     rowmul_nb<NB, VP>(X, Rp, sh.T);
+    if (weak) {
+        gram_nb<NB, VP>(X, Rp, sh, sh.H);
+        jacobi_nb<NB>(sh);
+        if (threadIdx.x < 256) {
+            const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+            const double dj = sh.theta[j];
+            const double rj = dj > 1e-12 ? 1.0 / sqrt(dj) : 0.0;
+            sh.T[i * EIG_VP + j] = (i < NB && j < NB) ? sh.Q[i * EIG_VP + j] * rj : 0.0;
+        }
+        __syncthreads();
+        rowmul_nb<NB, VP>(X, Rp, sh.T);
+    }
     for (int iter = 0; iter < 10; ++iter) {
         gram_nb<NB, VP>(X, Rp, sh, sh.H);
         double err = 0;
@@ -335,7 +357,8 @@ __device__ __forceinline__ void first_power_top4(EigShared& sh) {
 
 struct EigState {
     double trace, prev_sum, prev_delta, prev_ratio, top4;
-    int it, done, R, pad;
+    double f_prev_sum, f_prev_delta, f_prev_ratio;   // the same bookkeeping on the first-power sums (fp_it > 0)
+    int it, done, R, fp_it;
 };
 
 #define EIG_NFAST 5
@@ -370,6 +393,27 @@ __device__ __forceinline__ bool update_convergence(double s4, int it, double& pr
     prev_ratio = ratio;
     prev_delta = delta;
     prev_sum = s4;
+    return conv;
+}
+
+// Final acceptance, shared by k_eig_rr and k_eig_finish (uniform).  `g2_conv`: the G^2 sums have settled this round.
+// The first-power sum f of the same subspace (sh.G1) is then evaluated: if it agrees with the G^2 sum to 1e-13 the G^2
+// iteration resolved all four values and f is final.  If not, the 4th value is below what G^2 can see (a matrix of
+// numerical rank < 4: lambda_4 inside the cluster of its noise eigenvalues) and the G^2 sums are blind to its
+// convergence: from then on f is evaluated every round and judged by the two-ratio rule itself.
+__device__ __forceinline__ bool accept_first_power(bool g2_conv, double g2_sum, EigState& st, EigShared& sh) {
+    // (also from the 6th product on: G^2 sums of a moderately ill-conditioned spectrum sit on their rounding floor, above
+    // the tolerance, and would never settle)
+    if (!g2_conv && st.fp_it == 0 && st.it < 6) return false;
+    first_power_top4(sh);
+    const double f = sh.top4;
+    if (st.fp_it == 0 && g2_conv && fabs(f - g2_sum) <= 1e-13 * g2_sum) {
+        st.top4 = f;
+        return true;
+    }
+    st.fp_it += 1;
+    const bool conv = update_convergence(f, st.fp_it, st.f_prev_sum, st.f_prev_delta, st.f_prev_ratio);
+    st.top4 = f;
     return conv;
 }
 

@@ -64,7 +64,8 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_init(const SplitDev* __rest
     for (int i = threadIdx.x; i < R; i += EIG_THREADS) tr += (double)G[(int64_t)i * gp + i];
     tr = block_sum(tr, sh);
     EigState st;
-    st.trace = tr; st.prev_sum = 0; st.prev_delta = 0; st.prev_ratio = 1.0; st.top4 = 0; st.it = 0; st.done = 0; st.R = R; st.pad = 0;
+    st.trace = tr; st.prev_sum = 0; st.prev_delta = 0; st.prev_ratio = 1.0; st.top4 = 0; st.it = 0; st.done = 0; st.R = R; st.fp_it = 0;
+    st.f_prev_sum = 0; st.f_prev_delta = 0; st.f_prev_ratio = 1.0;
     if (R <= 4 || !(tr > 0)) {
         // min(shape) <= 4: the reference computes 1 - x/x = 0 exactly; all-zero matrix: 0/0 = nan
         if (threadIdx.x == 0) {
@@ -204,10 +205,10 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_rr(const SplitDev* __restri
     STAMP(2);
     st.it += 1;
     st.top4 = sh.top4;
-    const bool conv = update_convergence(sh.top4, st.it, st.prev_sum, st.prev_delta, st.prev_ratio);
-    if (conv) {
-        first_power_top4(sh);  // the score comes from the first-power Ritz values of the same subspace
-        st.top4 = sh.top4;
+    const double g2_sum = sh.top4;
+    const bool g2_conv = update_convergence(g2_sum, st.it, st.prev_sum, st.prev_delta, st.prev_ratio);
+    // (the score comes from the first-power Ritz values of the same subspace; sets st.top4)
+    if (accept_first_power(g2_conv, g2_sum, st, sh)) {
         if (threadIdx.x == 0) {
             st.done = 1;
             states[sid] = st;
@@ -289,12 +290,14 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_finish(const SplitDev* __re
         st.it += 1;
         st.top4 = sh.top4;
         ran = 1;
-        if (update_convergence(sh.top4, st.it, st.prev_sum, st.prev_delta, st.prev_ratio)) {
+        const double g2_sum = sh.top4;
+        const bool g2_conv = update_convergence(g2_sum, st.it, st.prev_sum, st.prev_delta, st.prev_ratio);
+        if (accept_first_power(g2_conv, g2_sum, st, sh)) {
             converged = 1;
             break;
         }
     }
-    if (ran) {
+    if (ran && !converged) {   // cap hit: the flagged estimate comes from the first power as well
         first_power_top4(sh);
         st.top4 = sh.top4;
     }

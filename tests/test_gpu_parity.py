@@ -207,6 +207,18 @@ def test_degenerate_and_generic_matrices(sp, golden):
     # hard spectrum (no gap after the 4th singular value): slow convergence must still be correct
     M = rng.standard_normal((120, 400))
     assert abs(sp.split_score(M) - O.dense_split_score(M)) <= 1e-9
+    # scale invariance far outside the f32 range of the squared Gram values (tools/gpu_fuzz_matrix.py: the score was 1.0)
+    M = np.where(rng.random((300, 500)) < 0.1, rng.integers(1, 1000, (300, 500)), 0).astype(np.float64)
+    want = O.dense_split_score(M)
+    for scale in (1e-8, 1e5, 1e-30, 1e30):
+        assert abs(sp.split_score(M * scale) - want) <= SCORE_TOL, scale
+        assert abs(sp.split_score(scipy.sparse.csr_matrix(M * scale)) - want) <= SCORE_TOL, scale
+    # numerical rank 3 + noise: the 4th singular value sits inside the cluster of noise values, 1e-9 below the first -
+    # invisible to the squared iteration; the first-power acceptance has to find it.  1 - top4/trace is ~1e-10 here and
+    # good to ~5e-14 (rounding floor of an fp64 Gram matrix), i.e. the score to a few 1e-10
+    M = rng.standard_normal((130, 3)) @ rng.standard_normal((3, 257)) + 1e-5 * rng.standard_normal((130, 257))
+    want, got = O.dense_split_score(M), sp.split_score(M)
+    assert abs(want ** 2 - got ** 2) <= 5e-14 and abs(want - got) <= 5e-9, (want, got)
 
 
 def test_histogram_from_sequences(sp):
