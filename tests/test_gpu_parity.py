@@ -872,3 +872,40 @@ def test_wide_block_fallback_12_taxa(sp):
             want = 0.0 if min(m.shape) <= 4 else O.dense_split_score(m)
             assert abs(want - got[i]) <= SCORE_TOL, (seed, i, m.shape, want, got[i], hex(st[i]))
     assert went_wide > 0   # (if this fires the tables no longer reach the fallback: pick harder ones)
+
+
+def test_flattening_api_random_tables(sp):
+    """flattening() on random small tables in the reference's own input form (dict of pattern string -> probability),
+    both formats, every split form, bit-exact against the loops-level port of constructions.py:31-102."""
+    rng = np.random.default_rng(77)
+    for trial in range(30):
+        n = int(rng.integers(2, 8))
+        length = int(rng.choice([7, 50, 400]))
+        letters = int(rng.choice([2, 4, 4]))
+        keys, counts = _copy_mutate_table(rng, n, length, letters)
+        total = int(counts.sum())
+        table = {}
+        for k, c in zip(keys.tolist(), counts.tolist()):
+            table["".join("ACGT"[(k >> (2 * (n - 1 - t))) & 3] for t in range(n))] = c / total
+        names = [str(t) for t in range(n)]
+        perm = rng.permutation(n)
+        a = int(rng.integers(1, n))
+        left, right = sorted(perm[:a].tolist()), sorted(perm[a:].tolist())
+        forms = [(tuple(str(t) for t in left), tuple(str(t) for t in right)),
+                 ({str(t) for t in left}, {str(t) for t in right})]
+        if n <= 10:
+            forms.append("".join(map(str, left)) + "|" + "".join(map(str, right)))
+        for split in forms:
+            want_r = O.flattening(split, table, "reduced")
+            got_r = sp.flattening(split, table, sp.FlatFormat.reduced)
+            assert got_r.shape == want_r.shape and np.array_equal(got_r, want_r), (trial, split)
+            want_s = O.flattening(split, table, "sparse")
+            got_s = sp.flattening(split, table, sp.FlatFormat.sparse)
+            assert got_s.shape == want_s.shape and (abs(got_s.tocoo() - want_s.tocoo())).nnz == 0, (trial, split)
+            w = O.split_score(want_r)
+            g = sp.split_score(got_r)
+            if np.isnan(w):
+                assert np.isnan(g) or g * g <= 1e-13
+            else:
+                assert abs(w - g) <= SCORE_TOL or abs(w * w - g * g) <= 5e-14, (trial, split, w, g)
+        assert names
