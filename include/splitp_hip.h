@@ -178,8 +178,12 @@ int sp_divergence_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, int64_t
  *                             (flattening + flattening_rank_1_approximation_divergence instead of split_score)
  *   scores_host               may be NULL; if given, the stream is synchronised
  *   scores_dev                may be NULL; device buffer of n_splits doubles
- *   status_host               may be NULL; per-split flags (bit 0: eigen iteration hit its cap; bits 8..: number
- *                             of operator applications) */
+ *   status_host               may be NULL; per-split flags (bit 0: eigen iteration hit its cap - the score is then
+ *                             an upper estimate; bits 8..: number of operator applications).
+ * Hand-back chain of SP_METHOD_FLATTENING on a count table (every stage bit-reproducible): in-LDS kernel -> the same
+ * kernel with its entry lists in global memory -> with all arrays in global memory (tables beyond ~9 k patterns) ->
+ * for a split whose 4-wide block finds no certified spectral gap in 40 half products: the dense route (smaller side
+ * <= 1024 rows) or the kernel's 8-wide fallback block (larger sides, 12+ taxa). */
 #define SP_METHOD_FLATTENING 0
 #define SP_METHOD_SUBFLATTENING 1
 #define SP_METHOD_FLATTENING_DENSE 2
@@ -193,8 +197,9 @@ int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, const int32_t* 
  * enqueues the scoring of the splits on the context's stream and returns without any host synchronisation.
  *   scores_dev[n_splits] (double) and status_dev[n_splits] (int32) are device buffers written by the kernels.
  * No hand-back is performed: with SP_METHOD_FLATTENING / _SPARSE a split the in-LDS kernel cannot take has
- * status bit 1 set and an undefined score - the caller re-scores those with SP_METHOD_FLATTENING_DENSE after its
- * own synchronisation (splitp_amd/batch.py does). */
+ * status bit 1 set (score: undefined if the status is exactly 2, an uncertified upper estimate otherwise) - the
+ * caller re-scores those with the synchronous sp_score_splits(SP_METHOD_FLATTENING) after its own synchronisation
+ * (splitp_amd/batch.py finish_async does). */
 int sp_score_splits_async(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
                           int method, void* scores_dev, void* status_dev);
 

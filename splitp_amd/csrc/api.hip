@@ -699,7 +699,41 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
                "sparse route: %zu of %lld splits were handed back by the in-LDS kernel (first: split %d, status 0x%x: "
                "%s)", redo.size(), (long long)S, redo[0], st[redo[0]],
                (st[redo[0]] >> 8) ? "no convergence with the 4-wide block" : "lists / blocks do not fit LDS");
-    {   // splits that only lacked LDS space: the same kernel with its arrays in a global-memory slab per workgroup
+    {   // splits that only lacked LDS space, first resort: the LDS form with its two entry lists in global memory
+        // (everything the products gather from stays in LDS; 13.5 k patterns with ~1800 ids a side fit)
+        std::vector<int> fit;
+        for (int i : redo)
+            if ((st[i] >> 8) == 0) fit.push_back(i);
+        if (!fit.empty() && al->spk_D <= 65535) {
+            const size_t slab = sparse_list_slab_bytes(al->spk_D);
+            DevBuf fidx;
+            DevBuf& slabs = ctx->slabs;
+            int rc2 = SP_OK;
+            if ((rc2 = slabs.ensure(fit.size() * slab)) || (rc2 = fidx.ensure(fit.size() * 4))) {
+                fidx.release();
+                return rc2;
+            }
+            hipError_t e = hipMemcpyAsync(fidx.p, fit.data(), fit.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess)
+                rc2 = launch_sparse_score_lists(ctx, ctx->aldescs.as<AlDesc>(), al->n_taxa, ctx->splits.as<SplitDev>(),
+                                                fidx.as<int>(), (int64_t)fit.size(), S, ctx->scores.as<double>(),
+                                                ctx->status.as<int>(), slabs.as<unsigned char>(), slab);
+            if (e == hipSuccess && rc2 == SP_OK)
+                e = hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            fidx.release();
+            if (rc2 != SP_OK) return rc2;
+            if (e != hipSuccess) {
+                sp_set_error("sparse route (lists in global memory): %s", hipGetErrorString(e));
+                return SP_EHIP;
+            }
+            redo.clear();
+            for (int64_t i = 0; i < S; ++i)
+                if (st[i] & 2) redo.push_back((int)i);
+            if (redo.empty()) return SP_OK;
+        }
+    }
+    {   // still no room: the same kernel with ALL its arrays in a global-memory slab per workgroup
         std::vector<int> fit;
         int64_t bmw = 0;
         for (int i : redo)

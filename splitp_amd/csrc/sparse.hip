@@ -799,7 +799,7 @@ __device__ __forceinline__ bool spk_wide_converged(double s4, double th4, double
 // column sides of ~1800 ids).  Communication inside the workgroup then goes through global memory: plain stores are
 // coherent at workgroup scope after __syncthreads(); words that were updated by ATOMICS (key bitmaps, sort counters, the
 // integer Gram) are read back with agent-scope atomic loads (spk_aload), since device atomics are done in L2 past the L1.
-template <bool HBM, bool WIDE = false>
+template <bool HBM, bool WIDE = false, bool LISTS_GLOBAL = false>
 __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __restrict__ als, int n_al, int n,
                                                               const SplitDev* __restrict__ splits,
                                                               const int* __restrict__ order, int S,
@@ -813,7 +813,11 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     EigShared& esh = *reinterpret_cast<EigShared*>(smem + ((sizeof(SpkShared) + 15) & ~(size_t)15));
     constexpr int NBC = wide_on ? SPK_WB : SPK_NB;
     unsigned char* const base = HBM ? slabs + (size_t)blockIdx.x * slab_bytes : smem;
-    const size_t cap = HBM ? slab_bytes : (slab_bytes ? slab_bytes : (size_t)SPK_LDS_BYTES);   // (LDS form: slab_bytes = debug cap)
+    // (LDS form: slab_bytes = debug cap;  LISTS_GLOBAL: the LDS form with its two entry lists - written once, read
+    // sequentially - in a small slab of global memory, which is what lets a 13 k-pattern table keep its staging arrays,
+    // counters and the V / W blocks in LDS)
+    static_assert(!(HBM && LISTS_GLOBAL), "LISTS_GLOBAL is a variant of the LDS form");
+    const size_t cap = HBM ? slab_bytes : ((slab_bytes && !LISTS_GLOBAL) ? slab_bytes : (size_t)SPK_LDS_BYTES);
     const int ai = blockIdx.x % n_al;
     const int sid = order[blockIdx.x / n_al];
     const u32* __restrict__ keys = als[ai].keys32;
@@ -858,7 +862,8 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     // (a table with split counts - several rows per pattern - can have more than R entries in a column, which the 8-bit
     // sort counters of the small path do not hold: such tables take the general path)
     const bool small_sure = r_cap <= SPK_SMALL_R && (u32)Di == sh.ntab && !wide_on;   // then no CSR list is needed
-    const size_t need_build = off + (size_t)(D + 8) * (small_sure ? 4 : 8) + (size_t)D * 6 + (size_t)W * 12 + 4096 + 256;
+    const size_t need_build = off + (LISTS_GLOBAL ? 0 : (size_t)(D + 8) * (small_sure ? 4 : 8)) + (size_t)D * 6 +
+                              (size_t)W * 12 + 4096 + 256;
     if (D > 65535 || n > 16 || need_build + 2048 > cap) {
         if (threadIdx.x == 0) {
             scores[sid] = 0.0;
@@ -870,8 +875,19 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     SSTAMP(0);
     // region A (persistent): CSC list, CSR list.  Region B: staging + bitmaps while building, then V and W (or G).
     // Sizes that depend on R / Kc are carved after the ranks are known.
-    u32* csc_ent = reinterpret_cast<u32*>(carve((size_t)(D + 8) * 4));   // + 8: the unpredicated tail reads of the products
-    u32* csr_ent = small_sure ? nullptr : reinterpret_cast<u32*>(carve((size_t)(D + 8) * 4));
+    const size_t list_bytes = ((size_t)(D + 8) * 4 + 15) & ~(size_t)15;   // + 8: the unpredicated tail reads of the products
+    unsigned char* const lslab = LISTS_GLOBAL ? slabs + (size_t)blockIdx.x * slab_bytes : nullptr;
+    if (LISTS_GLOBAL && 2 * list_bytes > slab_bytes) {
+        if (threadIdx.x == 0) {
+            scores[sid] = 0.0;
+            status[sid] = 2;
+        }
+        return;
+    }
+    u32* csc_ent = LISTS_GLOBAL ? reinterpret_cast<u32*>(lslab) : reinterpret_cast<u32*>(carve((size_t)(D + 8) * 4));
+    u32* csr_ent = small_sure ? nullptr
+                              : (LISTS_GLOBAL ? reinterpret_cast<u32*>(lslab + list_bytes)
+                                              : reinterpret_cast<u32*>(carve((size_t)(D + 8) * 4)));
     if (threadIdx.x < 8) {
         csc_ent[D + threadIdx.x] = 0;
         if (csr_ent) csr_ent[D + threadIdx.x] = 0;
@@ -1025,7 +1041,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     // the row counters
     const size_t grp_r_bytes = small ? 0 : (((size_t)R + 1) * 2 + 15) & ~(size_t)15;
     // (a raw column side of a tiny table has more ids than the CSR list has bytes: then behind the column counters)
-    const bool grp_c_in_csr = !small && ((size_t)Kc + 1) * 2 <= ((size_t)D + 8) * 4;
+    const bool grp_c_in_csr = !small && !LISTS_GLOBAL && ((size_t)Kc + 1) * 2 <= ((size_t)D + 8) * 4;
     const size_t grp_c_bytes = (small || grp_c_in_csr) ? 0 : (((size_t)Kc + 1) * 2 + 15) & ~(size_t)15;
     if (need_iter > top || build_end + cw_c + grp_c_bytes + 16 > top || build_end + cw_r + grp_r_bytes + 16 > top ||
         Kc > 65535) {
@@ -1414,6 +1430,28 @@ int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa
     hipLaunchKernelGGL(k_sparse_score<false>, dim3((unsigned)(S * n_al)), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream,
                        als_dev, n_al, n_taxa, splits_dev, order_dev, (int)S, scores, status, (unsigned char*)nullptr,
                        getenv("SPLITP_DEBUG_LDS_CAP") ? (size_t)atol(getenv("SPLITP_DEBUG_LDS_CAP")) : (size_t)0);
+    SP_HIP(hipGetLastError());
+    return SP_OK;
+}
+
+// The LDS form with its entry lists in global memory (k_sparse_score<false, false, true>): the splits listed in
+// order_dev[0 .. S_sub), one alignment; slab_bytes >= sparse_list_slab_bytes(D) per workgroup.
+size_t sparse_list_slab_bytes(int64_t D) { return ((((size_t)(D + 8) * 4 + 15) & ~(size_t)15) * 2 + 255) & ~(size_t)255; }
+
+int launch_sparse_score_lists(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, const SplitDev* splits_dev,
+                              const int* order_dev, int64_t S_sub, int64_t S, double* scores, int* status,
+                              unsigned char* slabs, size_t slab_bytes) {
+    if (S_sub == 0) return SP_OK;
+    if (ctx->upload_ev) SP_HIP(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
+    PhaseScope ps(ctx, SP_PHASE_SPARSE);
+    static bool attr = false;
+    if (!attr) {
+        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_score<false, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_BYTES));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_sparse_score<false, false, true>), dim3((unsigned)S_sub), dim3(SPK_THREADS), SPK_LDS_BYTES,
+                       ctx->stream, als_dev, 1, n_taxa, splits_dev, order_dev, (int)S, scores, status, slabs, slab_bytes);
     SP_HIP(hipGetLastError());
     return SP_OK;
 }
