@@ -877,7 +877,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     // Sizes that depend on R / Kc are carved after the ranks are known.
     const size_t list_bytes = ((size_t)(D + 8) * 4 + 15) & ~(size_t)15;   // + 8: the unpredicated tail reads of the products
     unsigned char* const lslab = LISTS_GLOBAL ? slabs + (size_t)blockIdx.x * slab_bytes : nullptr;
-    if (LISTS_GLOBAL && 2 * list_bytes > slab_bytes) {
+    // (LISTS_GLOBAL: the group descriptors / permutations of both lists - read in sequence by the products - go there too)
+    const size_t gdesc_bytes = (((size_t)max((long long)D, 1024ll) + 2) * 2 + 15) & ~(size_t)15;
+    if (LISTS_GLOBAL && 2 * list_bytes + 4 * gdesc_bytes > slab_bytes) {
         if (threadIdx.x == 0) {
             scores[sid] = 0.0;
             status[sid] = 2;
@@ -1011,10 +1013,14 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         top = (top - bytes) & ~(size_t)15;
         return base + top;
     };
-    unsigned short* desc_c = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)(Kc + 1) * 2));
-    unsigned short* desc_r = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)(R + 1) * 2));
-    unsigned short* perm_c = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)Kc * 2));
-    unsigned short* perm_r = small ? nullptr : reinterpret_cast<unsigned short*>(carve_top((size_t)R * 2));
+    auto carve_desc = [&](int which, size_t bytes) {
+        return reinterpret_cast<unsigned short*>(LISTS_GLOBAL ? lslab + 2 * list_bytes + (size_t)which * gdesc_bytes
+                                                              : carve_top(bytes));
+    };
+    unsigned short* desc_c = small ? nullptr : carve_desc(0, (size_t)(Kc + 1) * 2);
+    unsigned short* desc_r = small ? nullptr : carve_desc(1, (size_t)(R + 1) * 2);
+    unsigned short* perm_c = small ? nullptr : carve_desc(2, (size_t)Kc * 2);
+    unsigned short* perm_r = small ? nullptr : carve_desc(3, (size_t)R * 2);
     unsigned short* csc_ptr = small ? reinterpret_cast<unsigned short*>(carve_top((size_t)(Kc + 1) * 2)) : nullptr;
     const size_t build_end = reinterpret_cast<unsigned char*>(bm) - base;
     // V and W are column-major: four arrays of Rp / Kcp doubles.  A lane's four gathers then go to four arrays -
@@ -1436,7 +1442,11 @@ int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa
 
 // The LDS form with its entry lists in global memory (k_sparse_score<false, false, true>): the splits listed in
 // order_dev[0 .. S_sub), one alignment; slab_bytes >= sparse_list_slab_bytes(D) per workgroup.
-size_t sparse_list_slab_bytes(int64_t D) { return ((((size_t)(D + 8) * 4 + 15) & ~(size_t)15) * 2 + 255) & ~(size_t)255; }
+size_t sparse_list_slab_bytes(int64_t D) {
+    const size_t list_bytes = ((size_t)(D + 8) * 4 + 15) & ~(size_t)15;
+    const size_t gdesc_bytes = (((size_t)std::max<int64_t>(D, 1024) + 2) * 2 + 15) & ~(size_t)15;
+    return (2 * list_bytes + 4 * gdesc_bytes + 255) & ~(size_t)255;
+}
 
 int launch_sparse_score_lists(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, const SplitDev* splits_dev,
                               const int* order_dev, int64_t S_sub, int64_t S, double* scores, int* status,
