@@ -909,3 +909,32 @@ def test_flattening_api_random_tables(sp):
             else:
                 assert abs(w - g) <= SCORE_TOL or abs(w * w - g * g) <= 5e-14, (trial, split, w, g)
         assert names
+
+
+def test_config4_size_subflattening(sp):
+    """BASELINE config 4 size (20 taxa, 1M bp: 40-bit pattern keys, 61 x 61 moment matrix, blocks up to 31 x 31):
+    exact moment identity and oracle spot checks on splits of every size class."""
+    from splitp_amd import synthetic as syn
+
+    n, length = 20, 1_000_000
+    sites = syn.simulate_sites(n, length, 0.05, seed=4)
+    keys, counts = syn.pattern_table(sites)
+    assert int(keys.max()) >= 1 << 32                       # the keys really need more than 32 bits
+    names = syn.taxa_names(n)
+    dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=length, taxa=names)
+    rng = np.random.default_rng(4)
+    splits = []
+    for k in range(2, 11):
+        for _ in range(40):
+            left = sorted(rng.choice(n, size=k, replace=False).tolist())
+            splits.append((tuple(names[t] for t in left), tuple(names[t] for t in range(n) if t not in left)))
+    got, st = sp.score_splits(dev, splits, method=sp.Method.subflattening, return_status=True)
+    assert not np.any(st & 3)
+    M = O.moment_matrix(keys, counts, n)
+    for i in range(0, len(splits), 17):
+        oa = [names.index(t) for t in splits[i][0]]
+        ob = [names.index(t) for t in splits[i][1]]
+        S = M[np.ix_(O.subflattening_index(oa, n), O.subflattening_index(ob, n))] / float(length)
+        m_gpu = sp.subflattening(splits[i], dev)
+        assert np.array_equal(np.rint(m_gpu * length), np.rint(S * length))
+        assert abs(O.dense_split_score(S) - got[i]) <= SCORE_TOL
