@@ -337,6 +337,198 @@ __global__ __launch_bounds__(SUB_WAVES * 64) void k_subscore(const void* __restr
     }
 }
 
+
+// ---- batched score, fast form (n <= 20: moment matrix <= 61 x 61, smaller side <= 31 rows) ---------------------------
+// Same Gram matrix as k_subscore, but the moment matrix is staged once per workgroup in LDS (the Jacobi kernel re-reads
+// it from L2 for every product term), the Gram matrix is formed by fp64 MFMA, every wave walks splits in a grid-stride
+// loop, and the eigenvalues come from the classical dense symmetric route instead of cyclic Jacobi: Householder
+// tridiagonalisation (two lanes per row; ~3 r^2 LDS operations a lane instead of ~14 r^2 for 7 Jacobi sweeps) followed by
+// multisection on the Sturm count of the tridiagonal matrix - 4 groups of 16 lanes, one group per wanted eigenvalue, 16
+// shifts a pass, 14 passes (17^14 > 2^53).  Both steps are backward stable: eigenvalues good to a few eps * lambda_1,
+// which is what 1 - top4 / trace needs.  No iteration that could fail to converge.
+#define SUBT_WAVES 4
+#define SUBT_MMAX 61
+#define SUBT_P 33        // row pitch of G (odd)
+#define SUBT_PASSES 14
+
+struct SubtWave {
+    double G[32 * SUBT_P];
+    double d[32], e2[32], v[32], w[32];
+    int urow[32], vcol[64];
+};
+
+template <bool EXACT>
+__global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __restrict__ Mv, int n,
+                                                                  const int8_t* __restrict__ split_taxa,
+                                                                  const int* __restrict__ split_a, int64_t S,
+                                                                  double* __restrict__ scores, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
+    const int m = 3 * n + 1;
+    double* Ms = reinterpret_cast<double*>(smem_t);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    SubtWave& sw = *reinterpret_cast<SubtWave*>(smem_t + (((size_t)m * m * 8 + 15) & ~(size_t)15) + (size_t)w * sizeof(SubtWave));
+    for (int e = threadIdx.x; e < m * m; e += SUBT_WAVES * 64)
+        Ms[e] = EXACT ? (double)reinterpret_cast<const long long*>(Mv)[e] : reinterpret_cast<const double*>(Mv)[e];
+    __syncthreads();
+    const int64_t nwaves = (int64_t)gridDim.x * SUBT_WAVES;
+    for (int64_t sid = (int64_t)blockIdx.x * SUBT_WAVES + w; sid < S; sid += nwaves) {
+        const int8_t* taxa = split_taxa + sid * n;
+        const int a = split_a[sid], b = n - a;
+        const bool swap = a > b;   // rows = smaller side
+        const int8_t* rt = swap ? taxa + a : taxa;
+        const int8_t* ct = swap ? taxa : taxa + a;
+        const int nr = swap ? b : a, nc = swap ? a : b;
+        const int r = 3 * nr + 1, c = 3 * nc + 1;
+        wave_sync_lds2();   // the previous split's reads of the tables are done
+        if (lane < r) sw.urow[lane] = sub_index(rt, nr, n, lane) * m;
+        if (lane < c) sw.vcol[lane] = sub_index(ct, nc, n, lane);
+        wave_sync_lds2();
+        // Gram over the rows on the matrix cores: G = B B^T, B[i][k] = M[urow_i + vcol_k] gathered straight from the
+        // staged moment matrix.  v_mfma_f64_16x16x4: lane (fr = lane & 15, fk = lane >> 4) supplies B[16 I + fr][4 s + fk]
+        // as A and B[16 J + fr][4 s + fk] as B operand of tile (I, J); accumulator q holds G[16 I + fk + 4 q][16 J + fr].
+        // (count tables: every term and sum is an integer below 2^53, so the result does not depend on the order)
+        {
+            typedef double d4 __attribute__((ext_vector_type(4)));
+            const int fr = lane & 15, fk = lane >> 4;
+            const bool two = r > 16;
+            const int u0 = fr < r ? sw.urow[fr] : -1, u1 = (two && 16 + fr < r) ? sw.urow[16 + fr] : -1;
+            d4 g00 = {0, 0, 0, 0}, g01 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
+            for (int k0 = 0; k0 < c; k0 += 4) {
+                const int k = k0 + fk;
+                const int v = k < c ? sw.vcol[k] : -1;
+                const double x0 = (v >= 0 && u0 >= 0) ? Ms[u0 + v] : 0.0;
+                g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, g00, 0, 0, 0);
+                if (two) {
+                    const double x1 = (v >= 0 && u1 >= 0) ? Ms[u1 + v] : 0.0;
+                    g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, g01, 0, 0, 0);
+                    g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, g11, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = fk + 4 * q;
+                sw.G[i * SUBT_P + fr] = g00[q];
+                if (two) {
+                    sw.G[i * SUBT_P + 16 + fr] = g01[q];
+                    sw.G[(16 + fr) * SUBT_P + i] = g01[q];
+                    sw.G[(16 + i) * SUBT_P + 16 + fr] = g11[q];
+                }
+            }
+        }
+        wave_sync_lds2();
+        double tr = 0;
+        for (int i = lane; i < r; i += 64) tr += sw.G[i * SUBT_P + i];
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) tr += __shfl_xor(tr, dd, 64);
+        if (r <= 4 || !(tr > 0)) {
+            if (lane == 0) {
+                scores[sid] = (tr > 0) ? 0.0 : __builtin_nan("");
+                status[sid] = 0;
+            }
+            continue;
+        }
+        // ---- Householder tridiagonalisation: d (diagonal), e2 (squared off-diagonal) -----------------------------------
+        // step k annihilates column k below the sub-diagonal with H = I - beta v v^T on the trailing block A (L x L):
+        // A <- H A H = A - v w^T - w v^T,  p = beta A v,  w = p - (beta v^T p / 2) v.   Lane pair (2i, 2i+1) owns row i.
+        const int row = lane >> 1, par = lane & 1;
+        for (int k = 0; k < r - 2; ++k) {
+            const int L = r - k - 1, o = k + 1;
+            const double x = (lane < L) ? sw.G[(o + lane) * SUBT_P + k] : 0.0;
+            double sig = x * x, tail = lane >= 1 ? x * x : 0.0;
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) {
+                sig += __shfl_xor(sig, dd, 64);
+                tail += __shfl_xor(tail, dd, 64);
+            }
+            const double x0 = __shfl(x, 0, 64);
+            if (lane == 0) sw.d[k] = sw.G[k * SUBT_P + k];
+            if (!(tail > 0)) {   // already tridiagonal in this column
+                if (lane == 0) sw.e2[k] = x0 * x0;
+                continue;
+            }
+            const double alpha = x0 >= 0 ? -sqrt(sig) : sqrt(sig);
+            const double beta = 1.0 / (sig - alpha * x0);    // 2 / (v^T v)
+            const double vi = (lane == 0) ? x0 - alpha : x;   // v (lane < L)
+            if (lane == 0) sw.e2[k] = sig;                    // alpha^2
+            if (lane < 32) sw.v[lane] = lane < L ? vi : 0.0;
+            wave_sync_lds2();
+            double p = 0;
+            if (row < L) {
+                const double* g = sw.G + (o + row) * SUBT_P + o;
+                for (int j = par; j < L; j += 2) p += g[j] * sw.v[j];
+            }
+            p += __shfl_xor(p, 1, 64);
+            p *= beta;
+            const double vr = row < L ? sw.v[row] : 0.0;
+            double kk = (par == 0 && row < L) ? vr * p : 0.0;
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) kk += __shfl_xor(kk, dd, 64);
+            const double wr = p - 0.5 * beta * kk * vr;
+            if (par == 0 && row < 32) sw.w[row] = row < L ? wr : 0.0;
+            wave_sync_lds2();
+            if (row < L) {
+                double* g = sw.G + (o + row) * SUBT_P + o;
+                for (int j = par; j < L; j += 2) g[j] -= vr * sw.w[j] + wr * sw.v[j];
+            }
+            wave_sync_lds2();
+        }
+        if (lane == 0) {
+            const double eo = sw.G[(r - 1) * SUBT_P + (r - 2)];
+            sw.d[r - 2] = sw.G[(r - 2) * SUBT_P + (r - 2)];
+            sw.d[r - 1] = sw.G[(r - 1) * SUBT_P + (r - 1)];
+            sw.e2[r - 2] = eo * eo;
+        }
+        wave_sync_lds2();
+        // ---- four largest eigenvalues of the tridiagonal matrix by multisection on the Sturm count ---------------------
+        double gl = 1e300, gu = -1e300, emax = 0;
+        if (lane < r) {
+            const double el = lane > 0 ? sqrt(sw.e2[lane - 1]) : 0.0, er = lane < r - 1 ? sqrt(sw.e2[lane]) : 0.0;
+            gl = sw.d[lane] - el - er;
+            gu = sw.d[lane] + el + er;
+            emax = lane < r - 1 ? sw.e2[lane] : 0.0;
+        }
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            gl = fmin(gl, __shfl_xor(gl, dd, 64));
+            gu = fmax(gu, __shfl_xor(gu, dd, 64));
+            emax = fmax(emax, __shfl_xor(emax, dd, 64));
+        }
+        const double pivmin = 2.3e-308 * fmax(1.0, emax);
+        const double span = fmax(gu - gl, 0.0);
+        double lo = gl - 1e-15 * span - pivmin, hi = gu + 1e-15 * span + pivmin;   // (per group of 16 lanes)
+        const int grp = lane >> 4, t = lane & 15;
+        const int want = r - 1 - grp;                     // ascending index of this group's eigenvalue
+        for (int pass = 0; pass < SUBT_PASSES; ++pass) {
+            const double sigma = lo + (hi - lo) * ((double)(t + 1) * (1.0 / 17.0));
+            double q = sw.d[0] - sigma;
+            int cnt = q < 0 ? 1 : 0;
+            for (int i = 1; i < r; ++i) {
+                if (fabs(q) < pivmin) q = -pivmin;
+                q = sw.d[i] - sigma - sw.e2[i - 1] / q;
+                cnt += q < 0 ? 1 : 0;
+            }
+            // cnt = eigenvalues below sigma; the wanted one is below sigma iff cnt > want
+            const unsigned long long above = __ballot(cnt > want);
+            const unsigned int mine = (unsigned int)((above >> (16 * grp)) & 0xFFFFull);
+            const int first = mine ? __builtin_ctz(mine) : 16;   // first shift of the group that is above the eigenvalue
+            const double s_hi = __shfl(sigma, 16 * grp + (first < 16 ? first : 15), 64);
+            const double s_lo = __shfl(sigma, 16 * grp + (first > 0 ? first - 1 : 0), 64);
+            const double nlo = first > 0 ? s_lo : lo, nhi = first < 16 ? s_hi : hi;
+            lo = nlo;
+            hi = nhi;
+        }
+        const double lam = 0.5 * (lo + hi);
+        double top = (t == 0) ? fmax(lam, 0.0) : 0.0;
+        top += __shfl_xor(top, 16, 64);
+        top += __shfl_xor(top, 32, 64);
+        if (lane == 0) {
+            const double op = 1.0 - top / tr;
+            scores[sid] = sqrt(op > 0 ? op : 0.0);
+            status[sid] = SUBT_PASSES << 8;
+        }
+    }
+}
+
 int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S) {
     sp_ctx* ctx = al->ctx;
     const int n = al->n_taxa;
@@ -366,6 +558,30 @@ int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t
     SP_HIP(hipMemcpyAsync(da, split_a, (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));  // taxa8 is a host temporary
     PhaseScope ps(ctx, SP_PHASE_SUBSCORE);
+    const int mdim = 3 * n + 1;
+    if (mdim <= SUBT_MMAX && rmax <= 32 && !getenv("SPLITP_SUBSCORE_JACOBI")) {   // fast form (the env switch keeps the Jacobi kernel testable)
+        const size_t lds_t = (((size_t)mdim * mdim * 8 + 15) & ~(size_t)15) + (size_t)SUBT_WAVES * sizeof(SubtWave);
+        int dev_cus = 256;
+        hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const int64_t want_blocks = (S + SUBT_WAVES - 1) / SUBT_WAVES;
+        const unsigned blocks_t = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)dev_cus * 2));   // 2 workgroups fit a CU (LDS): persistent waves, grid-stride over the splits
+        static bool attr_t = false;
+        if (!attr_t) {
+            SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+            SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+            attr_t = true;
+        }
+        if (al->exact)
+            hipLaunchKernelGGL(k_subscore_tri<true>, dim3(blocks_t), dim3(SUBT_WAVES * 64), lds_t, ctx->stream,
+                               al->moments.p, n, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
+        else
+            hipLaunchKernelGGL(k_subscore_tri<false>, dim3(blocks_t), dim3(SUBT_WAVES * 64), lds_t, ctx->stream,
+                               al->moments.p, n, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
+        SP_HIP(hipGetLastError());
+        return SP_OK;
+    }
     const size_t lds = ((size_t)SUB_WAVES * rmax * (rmax + 1) + (size_t)SUB_WAVES * rmax) * 8;
     const unsigned blocks = (unsigned)((S + SUB_WAVES - 1) / SUB_WAVES);
     if (al->exact)
