@@ -11,6 +11,7 @@
 // then per split a gather and a tiny symmetric eigenproblem (k_subscore, one wave per split).
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -349,26 +350,54 @@ __global__ __launch_bounds__(SUB_WAVES * 64) void k_subscore(const void* __restr
 #define SUBT_WAVES 4
 #define SUBT_MMAX 61
 #define SUBT_P 33        // row pitch of G (odd)
+#ifndef SUBT_PASSES
 #define SUBT_PASSES 14
+#endif
+#define SPK_LDS_TOTAL 163840   // LDS of a CU
+
+// Sum over the 64 lanes, returned to all of them: two quad steps and two row shifts on the DPP path (no LDS crossbar),
+// then the four row totals through scalar registers.  Fixed order.
+template <int CTRL>
+__device__ __forceinline__ double subt_dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double subt_readlane(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ double subt_wave_sum(double x) {
+    x += subt_dpp<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += subt_dpp<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += subt_dpp<0x114>(x);   // row_shr:4
+    x += subt_dpp<0x118>(x);   // row_shr:8  -> lanes 12..15 of every row hold the row total
+    return (subt_readlane(x, 15) + subt_readlane(x, 31)) + (subt_readlane(x, 47) + subt_readlane(x, 63));
+}
 
 struct SubtWave {
     double G[32 * SUBT_P];
     double d[32], e2[32], v[32], w[32];
-    int urow[32], vcol[64];
+    unsigned short urow[32];   // row offset u * m into the staged matrix (< 61 * 61)
+    unsigned char vcol[64];    // column index (< 61)
 };
 
-template <bool EXACT>
+// M32: count table with fewer than 2^31 sites - every moment fits an int32, the staged matrix takes half the LDS and a
+// third workgroup fits the CU (3 waves per SIMD instead of 2: the eigenvalue steps are dependency chains).
+template <bool EXACT, bool M32>
 __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __restrict__ Mv, int n,
                                                                   const int8_t* __restrict__ split_taxa,
                                                                   const int* __restrict__ split_a, int64_t S,
                                                                   double* __restrict__ scores, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
     const int m = 3 * n + 1;
-    double* Ms = reinterpret_cast<double*>(smem_t);
+    typedef typename std::conditional<M32, int, double>::type MsT;
+    MsT* Ms = reinterpret_cast<MsT*>(smem_t);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    SubtWave& sw = *reinterpret_cast<SubtWave*>(smem_t + (((size_t)m * m * 8 + 15) & ~(size_t)15) + (size_t)w * sizeof(SubtWave));
+    SubtWave& sw = *reinterpret_cast<SubtWave*>(smem_t + (((size_t)m * m * sizeof(MsT) + 15) & ~(size_t)15) +
+                                                (size_t)w * sizeof(SubtWave));
     for (int e = threadIdx.x; e < m * m; e += SUBT_WAVES * 64)
-        Ms[e] = EXACT ? (double)reinterpret_cast<const long long*>(Mv)[e] : reinterpret_cast<const double*>(Mv)[e];
+        Ms[e] = EXACT ? (MsT) reinterpret_cast<const long long*>(Mv)[e] : (MsT) reinterpret_cast<const double*>(Mv)[e];
     __syncthreads();
     const int64_t nwaves = (int64_t)gridDim.x * SUBT_WAVES;
     for (int64_t sid = (int64_t)blockIdx.x * SUBT_WAVES + w; sid < S; sid += nwaves) {
@@ -380,8 +409,8 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
         const int nr = swap ? b : a, nc = swap ? a : b;
         const int r = 3 * nr + 1, c = 3 * nc + 1;
         wave_sync_lds2();   // the previous split's reads of the tables are done
-        if (lane < r) sw.urow[lane] = sub_index(rt, nr, n, lane) * m;
-        if (lane < c) sw.vcol[lane] = sub_index(ct, nc, n, lane);
+        if (lane < r) sw.urow[lane] = (unsigned short)(sub_index(rt, nr, n, lane) * m);
+        if (lane < c) sw.vcol[lane] = (unsigned char)sub_index(ct, nc, n, lane);
         wave_sync_lds2();
         // Gram over the rows on the matrix cores: G = B B^T, B[i][k] = M[urow_i + vcol_k] gathered straight from the
         // staged moment matrix.  v_mfma_f64_16x16x4: lane (fr = lane & 15, fk = lane >> 4) supplies B[16 I + fr][4 s + fk]
@@ -391,15 +420,15 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
             typedef double d4 __attribute__((ext_vector_type(4)));
             const int fr = lane & 15, fk = lane >> 4;
             const bool two = r > 16;
-            const int u0 = fr < r ? sw.urow[fr] : -1, u1 = (two && 16 + fr < r) ? sw.urow[16 + fr] : -1;
+            const int u0 = fr < r ? (int)sw.urow[fr] : -1, u1 = (two && 16 + fr < r) ? (int)sw.urow[16 + fr] : -1;
             d4 g00 = {0, 0, 0, 0}, g01 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
             for (int k0 = 0; k0 < c; k0 += 4) {
                 const int k = k0 + fk;
-                const int v = k < c ? sw.vcol[k] : -1;
-                const double x0 = (v >= 0 && u0 >= 0) ? Ms[u0 + v] : 0.0;
+                const int v = k < c ? (int)sw.vcol[k] : -1;
+                const double x0 = (v >= 0 && u0 >= 0) ? (double)Ms[u0 + v] : 0.0;
                 g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, g00, 0, 0, 0);
                 if (two) {
-                    const double x1 = (v >= 0 && u1 >= 0) ? Ms[u1 + v] : 0.0;
+                    const double x1 = (v >= 0 && u1 >= 0) ? (double)Ms[u1 + v] : 0.0;
                     g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, g01, 0, 0, 0);
                     g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, g11, 0, 0, 0);
                 }
@@ -434,15 +463,12 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
         for (int k = 0; k < r - 2; ++k) {
             const int L = r - k - 1, o = k + 1;
             const double x = (lane < L) ? sw.G[(o + lane) * SUBT_P + k] : 0.0;
-            double sig = x * x, tail = lane >= 1 ? x * x : 0.0;
-#pragma unroll
-            for (int dd = 32; dd >= 1; dd >>= 1) {
-                sig += __shfl_xor(sig, dd, 64);
-                tail += __shfl_xor(tail, dd, 64);
-            }
-            const double x0 = __shfl(x, 0, 64);
+            const double sig = subt_wave_sum(x * x);
+            const double x0 = subt_readlane(x, 0);
             if (lane == 0) sw.d[k] = sw.G[k * SUBT_P + k];
-            if (!(tail > 0)) {   // already tridiagonal in this column
+            // (rest of the column negligible against its head: nothing to annihilate; alpha and v below have no
+            // cancellation, so the tail's own norm is not needed)
+            if (!(sig - x0 * x0 > 0)) {   // already tridiagonal in this column
                 if (lane == 0) sw.e2[k] = x0 * x0;
                 continue;
             }
@@ -457,12 +483,10 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
                 const double* g = sw.G + (o + row) * SUBT_P + o;
                 for (int j = par; j < L; j += 2) p += g[j] * sw.v[j];
             }
-            p += __shfl_xor(p, 1, 64);
+            p += subt_dpp<0xB1>(p);   // the partner lane of the row
             p *= beta;
             const double vr = row < L ? sw.v[row] : 0.0;
-            double kk = (par == 0 && row < L) ? vr * p : 0.0;
-#pragma unroll
-            for (int dd = 32; dd >= 1; dd >>= 1) kk += __shfl_xor(kk, dd, 64);
+            const double kk = subt_wave_sum((par == 0 && row < L) ? vr * p : 0.0);
             const double wr = p - 0.5 * beta * kk * vr;
             if (par == 0 && row < 32) sw.w[row] = row < L ? wr : 0.0;
             wave_sync_lds2();
@@ -504,7 +528,11 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
             int cnt = q < 0 ? 1 : 0;
             for (int i = 1; i < r; ++i) {
                 if (fabs(q) < pivmin) q = -pivmin;
-                q = sw.d[i] - sigma - sw.e2[i - 1] / q;
+                // 1 / q by v_rcp_f64 + one Newton step (a full IEEE division is ~30 instructions and this recurrence is
+                // half of the kernel); the Sturm count tolerates the last-bit difference like any rounding
+                double y = __builtin_amdgcn_rcp(q);
+                y = fma(fma(-q, y, 1.0), y, y);
+                q = sw.d[i] - sigma - sw.e2[i - 1] * y;
                 cnt += q < 0 ? 1 : 0;
             }
             // cnt = eigenvalues below sigma; the wanted one is below sigma iff cnt > want
@@ -560,24 +588,37 @@ int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t
     PhaseScope ps(ctx, SP_PHASE_SUBSCORE);
     const int mdim = 3 * n + 1;
     if (mdim <= SUBT_MMAX && rmax <= 32 && !getenv("SPLITP_SUBSCORE_JACOBI")) {   // fast form (the env switch keeps the Jacobi kernel testable)
-        const size_t lds_t = (((size_t)mdim * mdim * 8 + 15) & ~(size_t)15) + (size_t)SUBT_WAVES * sizeof(SubtWave);
+        const bool m32 = al->exact && al->N < ((int64_t)1 << 31);
+        const size_t lds_t = (((size_t)mdim * mdim * (m32 ? 4 : 8) + 15) & ~(size_t)15) + (size_t)SUBT_WAVES * sizeof(SubtWave);
         int dev_cus = 256;
-        hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) dev_cus = 256;
+        int per_cu = 0;   // workgroups of this LDS size resident on a CU (allocation granularity included)
+        const void* kfn = m32 ? reinterpret_cast<const void*>(k_subscore_tri<true, true>)
+                              : (al->exact ? reinterpret_cast<const void*>(k_subscore_tri<true, false>)
+                                           : reinterpret_cast<const void*>(k_subscore_tri<false, false>));
         const int64_t want_blocks = (S + SUBT_WAVES - 1) / SUBT_WAVES;
-        const unsigned blocks_t = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)dev_cus * 2));   // 2 workgroups fit a CU (LDS): persistent waves, grid-stride over the splits
         static bool attr_t = false;
         if (!attr_t) {
-            SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<true>),
+            SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-            SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<false>),
+            SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<true, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+            SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<false, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
             attr_t = true;
         }
-        if (al->exact)
-            hipLaunchKernelGGL(k_subscore_tri<true>, dim3(blocks_t), dim3(SUBT_WAVES * 64), lds_t, ctx->stream,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, SUBT_WAVES * 64, lds_t) != hipSuccess || per_cu < 1)
+            per_cu = std::max(1, (int)((size_t)SPK_LDS_TOTAL / (lds_t + 1024)));
+        // as many workgroups as are resident at once: persistent waves, grid-stride over the splits
+        const unsigned blocks_t = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)dev_cus * per_cu));
+        if (m32)
+            hipLaunchKernelGGL((k_subscore_tri<true, true>), dim3(blocks_t), dim3(SUBT_WAVES * 64), lds_t, ctx->stream,
+                               al->moments.p, n, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
+        else if (al->exact)
+            hipLaunchKernelGGL((k_subscore_tri<true, false>), dim3(blocks_t), dim3(SUBT_WAVES * 64), lds_t, ctx->stream,
                                al->moments.p, n, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
         else
-            hipLaunchKernelGGL(k_subscore_tri<false>, dim3(blocks_t), dim3(SUBT_WAVES * 64), lds_t, ctx->stream,
+            hipLaunchKernelGGL((k_subscore_tri<false, false>), dim3(blocks_t), dim3(SUBT_WAVES * 64), lds_t, ctx->stream,
                                al->moments.p, n, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
         SP_HIP(hipGetLastError());
         return SP_OK;

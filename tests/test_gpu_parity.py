@@ -938,3 +938,30 @@ def test_config4_size_subflattening(sp):
         m_gpu = sp.subflattening(splits[i], dev)
         assert np.array_equal(np.rint(m_gpu * length), np.rint(S * length))
         assert abs(O.dense_split_score(S) - got[i]) <= SCORE_TOL
+
+
+def test_subflattening_score_kernels_agree(sp, monkeypatch):
+    """The two eigen-solvers behind the batched subflattening score - Householder tridiagonalisation + Sturm multisection
+    (default up to 20 taxa) and the cyclic Jacobi kernel (larger tables; forced here by SPLITP_SUBSCORE_JACOBI) - on the same
+    Gram matrices: all size classes of a 14-taxon table, a float-weight table, and a degenerate one."""
+    from splitp_amd import synthetic as syn
+
+    n = 14
+    sites = syn.simulate_sites(n, 200_000, 0.05, seed=9)
+    keys, counts = syn.pattern_table(sites)
+    names = syn.taxa_names(n)
+    splits = list(sp.all_splits(names))[::7]
+    tables = [sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=200_000, taxa=names),
+              sp.DeviceAlignment.from_arrays(keys, counts / 200_000.0, n, taxa=names, exact=False),
+              sp.DeviceAlignment.from_arrays(keys[:3], None, n, counts=counts[:3], n_sites=int(counts[:3].sum()), taxa=names)]
+    for dev in tables:
+        monkeypatch.delenv("SPLITP_SUBSCORE_JACOBI", raising=False)
+        fast, st = sp.score_splits(dev, splits, method=sp.Method.subflattening, return_status=True)
+        assert not np.any(st & 3)
+        monkeypatch.setenv("SPLITP_SUBSCORE_JACOBI", "1")
+        slow = sp.score_splits(dev, splits, method=sp.Method.subflattening)
+        monkeypatch.delenv("SPLITP_SUBSCORE_JACOBI", raising=False)
+        both_nan = np.isnan(fast) & np.isnan(slow)
+        err = np.where(both_nan, 0.0, np.abs(fast - slow))
+        err2 = np.where(both_nan, 0.0, np.abs(fast ** 2 - slow ** 2))
+        assert np.all((err <= 1e-11) | (err2 <= 1e-13)), (float(np.nanmax(err)), float(np.nanmax(err2)))
