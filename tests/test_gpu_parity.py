@@ -521,6 +521,14 @@ def test_mutual_information_score(sp, golden):
         oa = [names.index(t) for t in all_splits_[i][0]]
         ob = [names.index(t) for t in all_splits_[i][1]]
         assert abs(O.rank1_divergence_packed(g2["keys"], g2["probs"], 10, oa, ob) - got2[i]) <= SCORE_TOL
+    # the fused kernel (marginals in LDS) against the global-memory form it replaced for count tables: identical sums
+    import os
+    os.environ["SPLITP_DIVERGENCE_GLOBAL"] = "1"
+    try:
+        glob2 = sp.score_splits(dev2, all_splits_, method=sp.Method.mutual_information)
+    finally:
+        del os.environ["SPLITP_DIVERGENCE_GLOBAL"]
+    assert np.array_equal(glob2, got2)
     # the caller: neighbour joining by mutual information
     tree = sp.erickson_SVD(table, method=sp.Method.mutual_information)
     exp = [tuple(tuple(side) for side in s) for s in want["erickson_mutual_information"]]
