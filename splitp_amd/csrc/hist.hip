@@ -23,6 +23,8 @@
 
 #include "common.h"
 
+#include <rocprim/rocprim.hpp>   // radix sort + run-length encode for the sort-based histogram
+
 #define HIST_THREADS 256
 #define HIST_PER_THREAD 8
 #define HIST_TILE (HIST_THREADS * HIST_PER_THREAD)  // sites per workgroup pass
@@ -227,11 +229,115 @@ __global__ void k_counts_to_weights(const u32* __restrict__ counts, int64_t D, d
     if (i < D) w[i] = (double)counts[i] / N;  // counts[k] / float(L): simulation.py:54, fasta.py:66-70
 }
 
+// ---- sort-based histogram: any number of taxa ---------------------------------------------------------------------------
+// The direct bin array costs 3 passes over 4 * 4^n bytes (16 GiB at 16 taxa: 16 ms for a 1 M-site alignment) and does not
+// exist beyond 16 taxa.  When the bins outweigh the sites (4^n > 32 L) or n > 16 the site words are radix-sorted on the
+// bits in use (rocPRIM) and run-length encoded instead: unique keys come out ascending like the bins' compaction, the
+// invalid-site marker (all ones: bit 2n set) sorts last and is cut off.
+template <typename KT>
+__global__ void k_widen_keys(const KT* __restrict__ in, int64_t D, u64* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D) out[i] = (u64)in[i];
+}
+
+template <typename KT>
+static int build_sorted(sp_ctx* ctx, const KT* dkeys, int64_t L, int n_taxa, sp_alignment** out) {
+    SP_REQUIRE(L < ((int64_t)1 << 32), SP_ELIMIT, "sort-based histogram: at most 2^32 - 1 sites per call (got %lld)", (long long)L);
+    DevBuf sorted, uniq, cnts, nruns, tmp;
+    auto cleanup = [&]() { sorted.release(); uniq.release(); cnts.release(); nruns.release(); tmp.release(); };
+    auto fail = [&](int code) { cleanup(); return code; };
+    const size_t l1 = (size_t)std::max<int64_t>(L, 1);
+    int rc;
+    if ((rc = sorted.ensure(l1 * sizeof(KT))) || (rc = uniq.ensure(l1 * sizeof(KT))) || (rc = cnts.ensure(l1 * 4)) ||
+        (rc = nruns.ensure(16)))
+        return fail(rc);
+    const unsigned end_bit = (unsigned)std::min<int>(2 * n_taxa + 1, 8 * (int)sizeof(KT));   // + 1: the marker's bit
+    u32 nr = 0;
+    if (L > 0) {
+        PhaseScope ps(ctx, SP_PHASE_HIST);
+        size_t t1 = 0, t2 = 0;
+        hipError_t e = rocprim::radix_sort_keys(nullptr, t1, dkeys, sorted.as<KT>(), (size_t)L, 0u, end_bit, ctx->stream);
+        if (e == hipSuccess)
+            e = rocprim::run_length_encode(nullptr, t2, sorted.as<KT>(), (unsigned int)L, uniq.as<KT>(), cnts.as<u32>(),
+                                           nruns.as<u32>(), ctx->stream);
+        if (e != hipSuccess) {
+            sp_set_error("rocPRIM size query failed: %s", hipGetErrorString(e));
+            return fail(SP_EHIP);
+        }
+        if ((rc = tmp.ensure(std::max<size_t>(std::max(t1, t2), 16)))) return fail(rc);
+        e = rocprim::radix_sort_keys(tmp.p, t1, dkeys, sorted.as<KT>(), (size_t)L, 0u, end_bit, ctx->stream);
+        if (e == hipSuccess)
+            e = rocprim::run_length_encode(tmp.p, t2, sorted.as<KT>(), (unsigned int)L, uniq.as<KT>(), cnts.as<u32>(),
+                                           nruns.as<u32>(), ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&nr, nruns.p, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            sp_set_error("sort-based histogram failed: %s", hipGetErrorString(e));
+            return fail(SP_EHIP);
+        }
+    }
+    int64_t D = nr, dropped = 0;
+    if (nr > 0) {   // the last run is the invalid-site marker if there were invalid sites
+        KT lastk = 0;
+        u32 lastc = 0;
+        hipError_t e = hipMemcpy(&lastk, uniq.as<KT>() + (nr - 1), sizeof(KT), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&lastc, cnts.as<u32>() + (nr - 1), 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            sp_set_error("sort-based histogram: %s", hipGetErrorString(e));
+            return fail(SP_EHIP);
+        }
+        if (lastk == (KT)~(KT)0 && 2 * n_taxa < 8 * (int)sizeof(KT)) {
+            D -= 1;
+            dropped = lastc;
+        }
+    }
+    sp_alignment* al = new sp_alignment();
+    al->ctx = ctx;
+    al->n_taxa = n_taxa;
+    al->D = D;
+    al->N = L - dropped;
+    al->exact = true;
+    const size_t d1 = (size_t)std::max<int64_t>(D, 1);
+    if ((rc = al->keys.ensure(d1 * 8)) || (rc = al->weights.ensure(d1 * 8)) || (rc = al->counts.ensure(d1 * 4))) {
+        sp_alignment_destroy(al);
+        return fail(rc);
+    }
+    hipError_t e = hipSuccess;
+    if (D > 0) {
+        PhaseScope ps(ctx, SP_PHASE_HIST);
+        hipLaunchKernelGGL(k_widen_keys<KT>, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, uniq.as<KT>(), D,
+                           al->keys.as<u64>());
+        e = hipMemcpyAsync(al->counts.p, cnts.p, (size_t)D * 4, hipMemcpyDeviceToDevice, ctx->stream);
+        hipLaunchKernelGGL(k_counts_to_weights, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream,
+                           al->counts.as<u32>(), D, (double)al->N, al->weights.as<double>());
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) {   // largest count -> limb count of the int8 Gram (one-time)
+            std::vector<u32> hc((size_t)D);
+            e = hipMemcpy(hc.data(), al->counts.p, (size_t)D * 4, hipMemcpyDeviceToHost);
+            for (u32 c : hc) al->max_count = std::max(al->max_count, c);
+        }
+    }
+    cleanup();
+    if (e != hipSuccess) {
+        sp_alignment_destroy(al);
+        sp_set_error("sort-based histogram (compaction): %s", hipGetErrorString(e));
+        return SP_EHIP;
+    }
+    *out = al;
+    return SP_OK;
+}
+
 static int build_from_device_keys(sp_ctx* ctx, const void* dkeys, bool keys32, int64_t L, int n_taxa,
                                   sp_alignment** out) {
-    SP_REQUIRE(n_taxa <= 16, SP_ELIMIT,
-               "device histogram uses a direct 4^n bin array and supports n_taxa <= 16 (got %d); pass a "
-               "de-duplicated table to sp_alignment_create instead", n_taxa);
+    {
+        const char* force = getenv("SPLITP_HIST_SORT");   // "1" / "0": force / forbid the sort-based form (tests)
+        const bool big_bins = n_taxa > 16 || pow4(n_taxa) > 32 * std::max<int64_t>(L, 1);
+        const bool use_sort = n_taxa > 16 || (force ? force[0] == '1' : big_bins);
+        if (use_sort)
+            return keys32 ? build_sorted<u32>(ctx, (const u32*)dkeys, L, n_taxa, out)
+                          : build_sorted<u64>(ctx, (const u64*)dkeys, L, n_taxa, out);
+    }
     const int64_t nbins = pow4(n_taxa);
     DevBuf bins, blk, off;
     const int64_t nblocks = (nbins + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS;

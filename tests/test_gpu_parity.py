@@ -237,6 +237,17 @@ def test_histogram_from_sequences(sp):
     assert dev.info()["N"] == int(valid.sum())
     assert np.array_equal(gk, k2) and np.array_equal(gc, c2)
     assert np.array_equal(gw, c2 / float(valid.sum()))
+    # the two histogram forms (direct 4^n bins / radix sort + run-length encode) on the same input
+    import os
+    for force in ("1", "0"):
+        os.environ["SPLITP_HIST_SORT"] = force
+        try:
+            d3 = sp.DeviceAlignment.from_sequences(seqs)
+        finally:
+            del os.environ["SPLITP_HIST_SORT"]
+        fk, fw, fc = d3.fetch()
+        assert d3.info()["N"] == int(valid.sum()) and np.array_equal(fk, k2) and np.array_equal(fc, c2)
+        assert np.array_equal(fw, gw)
     dev2 = sp.DeviceAlignment.from_site_keys(syn.site_keys(sites), 10)
     gk, gw, gc = dev2.fetch()
     assert np.array_equal(gk, keys) and np.array_equal(gc, counts)
@@ -831,8 +842,8 @@ def test_subflattening_and_histogram_random(sp):
                 want = 0.0
             err = abs(want - got[i]) if want > 1e-6 or got[i] > 1e-6 else abs(want ** 2 - got[i] ** 2)
             assert err <= SCORE_TOL, (trial, n, length, i, want_m.shape, want, got[i])
-    for trial in range(6):
-        n = int(rng.integers(2, 15))
+    for trial in range(10):
+        n = int(rng.integers(2, 15)) if trial < 6 else int(rng.choice([16, 17, 20, 24]))   # > 16 taxa: sort-based form only
         length = int(rng.choice([1, 63, 1000, 70_000]))
         alphabet = np.frombuffer(b"ACGTacgtN-?X", dtype=np.uint8)
         p = np.array([20, 20, 20, 20, 3, 3, 3, 3, 1, 1, 0.5, 0.5])
