@@ -535,7 +535,7 @@ extern "C" int sp_simulate_alignment(sp_ctx* ctx, int n_nodes, const int32_t* pa
                                      const double* transition, int n_taxa, int64_t L, uint64_t seed,
                                      sp_alignment** out) {
     SP_REQUIRE(ctx && parent && leaf_taxon && transition && out, SP_EINVAL, "NULL argument");
-    SP_REQUIRE(n_taxa >= 2 && n_taxa <= 16, SP_ELIMIT, "device simulator supports 2..16 taxa (got %d)", n_taxa);
+    SP_REQUIRE(n_taxa >= 2 && n_taxa <= 31, SP_ELIMIT, "device simulator supports 2..31 taxa (got %d)", n_taxa);
     SP_REQUIRE(n_nodes >= n_taxa && n_nodes <= SIM_MAX_NODES, SP_ELIMIT, "tree has %d nodes (supported: n_taxa..%d)",
                n_nodes, SIM_MAX_NODES);
     SP_REQUIRE(L >= 0, SP_EINVAL, "L < 0");

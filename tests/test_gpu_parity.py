@@ -984,3 +984,39 @@ def test_subflattening_score_kernels_agree(sp, monkeypatch):
         err = np.where(both_nan, 0.0, np.abs(fast - slow))
         err2 = np.where(both_nan, 0.0, np.abs(fast ** 2 - slow ** 2))
         assert np.all((err <= 1e-11) | (err2 <= 1e-13)), (float(np.nanmax(err)), float(np.nanmax(err2)))
+
+
+def test_device_simulator_20_taxa(sp):
+    """The device simulator beyond 16 taxa (40-bit site words, sort-based histogram): reproducible, every site counted,
+    and the pairwise mismatch fractions of the 20-taxon balanced tree match Jukes-Cantor along the path between the
+    leaves (1 / 2 / 4 branches of 0.05 for taxa 0-1, 0-2, 0-3: 3/4 (1 - exp(-4 d / 3)))."""
+    from splitp_amd import simulation as sim
+    from splitp_amd import synthetic as syn
+
+    n, length = 20, 400_000
+    tree = syn.balanced_tree(n)
+    dev = sim.generate_device_alignment(tree, sim.JukesCantor(), length, seed=11, branch_length=0.05)
+    keys, w, cnt = dev.fetch()
+    assert dev.info()["N"] == length and int(cnt.sum()) == length and np.all(np.diff(keys.astype(np.int64)) > 0)
+    again = sim.generate_device_alignment(tree, sim.JukesCantor(), length, seed=11, branch_length=0.05).fetch()
+    assert np.array_equal(again[0], keys) and np.array_equal(again[2], cnt)
+    digit = lambda t: (keys >> np.uint64(2 * (n - 1 - t))) & np.uint64(3)
+    # path lengths in the balanced tree ((((0,1),2),(3,4)),...): derive them from the nested tuples
+    def depth_paths(node, path, out):
+        if isinstance(node, tuple):
+            for i, ch in enumerate(node):
+                depth_paths(ch, path + [(id(node), i)], out)
+        else:
+            out[node] = path
+    paths = {}
+    depth_paths(tree, [], paths)
+    for other in (1, 2, 3, 10, 19):
+        pa, pb = paths[0], paths[other]
+        common = 0
+        while common < min(len(pa), len(pb)) and pa[common] == pb[common]:
+            common += 1
+        # the root has no branch of its own: its two children hang on it directly
+        d = 0.05 * ((len(pa) - common) + (len(pb) - common))
+        p = 0.75 * (1.0 - np.exp(-4.0 * d / 3.0))
+        frac = float(cnt[digit(0) != digit(other)].sum()) / length
+        assert abs(frac - p) <= 5.0 * np.sqrt(p * (1 - p) / length), (other, d, frac, p)
