@@ -83,7 +83,7 @@ int sp_ctx_set_gram_mode(sp_ctx* ctx, int mode);
 #define SP_PHASE_GRAM 2     /* fp64 MFMA Gram over the smaller side                       */
 #define SP_PHASE_EIGEN 3    /* top-4 eigenvalues + score                                  */
 #define SP_PHASE_MOMENT 4   /* signed second-moment matrix (subflattening path)           */
-#define SP_PHASE_SUBSCORE 5 /* gather + one-sided Jacobi SVD of the (3a+1)x(3b+1) blocks  */
+#define SP_PHASE_SUBSCORE 5 /* Gram + top-4 eigenvalues of the (3a+1)x(3b+1) blocks        */
 #define SP_PHASE_HIST 6     /* site-pattern histogram (alignment columns -> pattern table) */
 #define SP_PHASE_DENSE 7    /* full 4^a x 4^b dense scatter (sp_flatten_dense)             */
 #define SP_PHASE_SPARSE 8   /* sparse route: one workgroup per split, everything in LDS     */
@@ -107,7 +107,9 @@ int sp_alignment_create(sp_ctx* ctx, const uint64_t* keys, const double* weights
 /* Build the pattern table on the device from alignment columns: the site-pattern histogram
  * that precedes the path (splitp/parsers/fasta.py:48-63 get_pattern_counts; sites containing a
  * character outside ACGT, either case, are skipped, :54-57).  seqs is n_taxa rows of L ASCII
- * characters (row stride `stride` bytes, host memory). */
+ * characters (row stride `stride` bytes, host memory).  Up to 12 taxa or so the sites are counted into a direct 4^n bin
+ * array; beyond that (4^n > 32 L, or more than 16 taxa) they are radix-sorted and run-length encoded; the table is the
+ * same either way (keys ascending).  Up to 31 taxa (at 32 the invalid-site marker would coincide with a pattern). */
 int sp_alignment_from_sequences(sp_ctx* ctx, const uint8_t* seqs, int n_taxa, int64_t L, int64_t stride,
                                 sp_alignment** out);
 /* Same, from already packed site keys resident on the host (one key per site). */
@@ -118,7 +120,7 @@ int sp_alignment_from_site_keys(sp_ctx* ctx, const uint64_t* site_keys, int64_t 
  * -1 for an internal node; transition[i] = row-major 4 x 4 matrix M of node i's branch with M[new][old] (a state is
  * drawn from column `old`, simulation.py:17-18; ignored for the root, whose state is uniform, :28).  Sites are
  * independent; the same seed gives the same table.  The result is the pattern table of the L simulated sites
- * (counts / L), resident on the device like every other alignment. */
+ * (counts / L), resident on the device like every other alignment.  2..31 taxa, up to 64 tree nodes. */
 int sp_simulate_alignment(sp_ctx* ctx, int n_nodes, const int32_t* parent, const int32_t* leaf_taxon,
                           const double* transition, int n_taxa, int64_t L, uint64_t seed, sp_alignment** out);
 
