@@ -165,7 +165,7 @@ __device__ __forceinline__ void spk_gram(const double* X, int rows, int rs, int 
 // Factor: wave 0 (64 lanes redundantly, no divergence) -> sh.L = 1 / l_jj (4), l_10 l_20 l_30 l_21 l_31 l_32, the pivot
 // ratio, and an estimate of the smallest eigenvalue of S (inverse iteration).
 // Ends with a barrier.
-__device__ __forceinline__ void spk_chol_factor(SpkShared& sh, bool want_lam = true) {
+__device__ __forceinline__ void spk_chol_factor(SpkShared& sh, bool want_lam = true, double rest = 1e300) {
     if (threadIdx.x < 64) {
         const double s00 = sh.S[0], s10 = sh.S[4], s20 = sh.S[8], s30 = sh.S[12];
         const double s11 = sh.S[5], s21 = sh.S[9], s31 = sh.S[13], s22 = sh.S[10], s32 = sh.S[14], s33 = sh.S[15];
@@ -186,8 +186,15 @@ __device__ __forceinline__ void spk_chol_factor(SpkShared& sh, bool want_lam = t
         // smallest eigenvalue of S by three steps of inverse iteration through the factor (x <- S^-1 x = L^-T L^-1 x from
         // x = 1): the Rayleigh quotient approaches it from above, fast unless it sits in a cluster (then any value of
         // the cluster will do); a dead pivot makes S singular: 0
-        double lam_min = 0.0;
-        if (want_lam) {   // (uniform; only the convergence test reads it, from its 4th sum on)
+        // A lower bound first, free of the serial chain below: lambda_min = det / (lambda_1 lambda_2 lambda_3) >=
+        // det (3 / trace)^3 (AM-GM), det = product of the pivots.  On real alignments it is ~0.4 lambda_min and the
+        // stop rule's tests (rest <= 0.6 lam, error bound) pass with it; only when `rest` is not clearly below it is the
+        // estimate sharpened by inverse iteration.
+        const double tr4 = (s00 + s11) + (s22 + s33);
+        const double cheap = (d0 > tiny && d1 > tiny && d2 > tiny && d3 > tiny && tr4 > 0)
+                                 ? ((d0 * d1) * (d2 * d3)) * (27.0 / (tr4 * tr4 * tr4)) : 0.0;
+        double lam_min = cheap;
+        if (want_lam && !(rest <= 0.3 * cheap)) {   // (uniform; only the convergence test reads it, from its 4th sum on)
             double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0, mu = 0.0;
 #pragma unroll
             for (int itv = 0; itv < 3; ++itv) {
@@ -1333,7 +1340,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             spk_gram(X, rows, xrs, xcs, sh);
             if (it == 2) SSTAMP(40);
             top4 = (sh.S[0] + sh.S[5]) + (sh.S[10] + sh.S[15]);
-            spk_chol_factor(sh, it >= 5);
+            spk_chol_factor(sh, it >= 5, trace - top4);
             // (the first real Ritz sum is that of half product 2)
             if (spk_converged(top4, sh.L[11], trace, it - 1, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
