@@ -214,9 +214,18 @@ def main():
 
     # untimed spin-up: a fresh box needs a few hundred ms of load before clocks, queues and the RCCL channel settle
     # (a 60 ms measurement taken cold is bimodal); then the W warmup steps the contract asks for
+    # (the number of spin-up batches is agreed between the ranks: a rank that ran one batch more than its peers would
+    # leave 50 all-gathers nobody answers)
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.spinup:
+    while args.spinup > 0:
         run(50)
+        go = time.perf_counter() - t_spin < args.spinup
+        if dist is not None:
+            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=dev_t)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            go = bool(int(flag.item()))
+        if not go:
+            break
     run(args.warmup)
     ctx.enable_timing(True)
     ctx.reset_timing()
