@@ -29,6 +29,7 @@ import numpy as np
 # hardware queues two of those streams can share a queue and serialise, so ask the HIP runtime for 8 (read at HIP
 # initialisation, hence before torch is imported).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool's host driver
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
