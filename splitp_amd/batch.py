@@ -37,6 +37,45 @@ def encode_splits(splits, table, n_taxa):
     return taxa_arr, a_arr
 
 
+def encode_all_splits(n_taxa, trivial=False, size=None):
+    """(split_taxa, split_a) of `all_splits(taxa)` - same splits, same order (reference splits.py:39-59) - built with
+    NumPy instead of one Python tuple pair per split: the 32 751 splits of a 16-taxon alignment take 18 ms instead of
+    the 170 ms of `encode_splits(list(all_splits(taxa)))`, the 524 267 of 20 taxa 1.2 s instead of ~3 s.  Taxa are positions 0 .. n_taxa-1 of the table's taxon list."""
+    from itertools import chain, combinations
+    from math import comb
+
+    n = int(n_taxa)
+    sizes = [size] if size is not None else list(range(1 if trivial else 2, n // 2 + 1))
+    taxa_blocks, a_blocks = [], []
+    everyone = np.arange(n, dtype=np.int32)
+    for bal in sizes:
+        even = 2 * bal == n
+        if even:   # taxon 0 plus every (bal-1)-subset of the others
+            cnt = comb(n - 1, bal - 1)
+            rest = np.fromiter(chain.from_iterable(combinations(range(1, n), bal - 1)), dtype=np.int32,
+                               count=cnt * (bal - 1)).reshape(cnt, bal - 1)
+            chosen = np.concatenate([np.zeros((cnt, 1), dtype=np.int32), rest], axis=1)
+        else:
+            cnt = comb(n, bal)
+            chosen = np.fromiter(chain.from_iterable(combinations(range(n), bal)), dtype=np.int32,
+                                 count=cnt * bal).reshape(cnt, bal)
+        member = np.zeros((cnt, n), dtype=bool)
+        member[np.arange(cnt)[:, None], chosen] = True
+        # the side holding taxon 0 goes first (splits.py:55-56); both sides in taxon order
+        first = member == member[:, :1]
+        a = first.sum(axis=1).astype(np.int32)
+        c_first = np.cumsum(first, axis=1, dtype=np.int32)
+        # position of taxon t in the row: its rank inside its side, the second side shifted behind the first
+        pos = np.where(first, c_first - 1, a[:, None] + (everyone[None, :] - c_first))
+        out = np.empty((cnt, n), dtype=np.int32)
+        np.put_along_axis(out, pos, np.broadcast_to(everyone, (cnt, n)), axis=1)
+        taxa_blocks.append(out)
+        a_blocks.append(a)
+    if not taxa_blocks:
+        return np.zeros((0, n), dtype=np.int32), np.zeros(0, dtype=np.int32)
+    return np.ascontiguousarray(np.concatenate(taxa_blocks)), np.ascontiguousarray(np.concatenate(a_blocks))
+
+
 def split_costs(split_a, n_taxa, method):
     """Relative cost of a split (for balanced sharding): the Gram over the smaller side costs
     ~ 4^k * D on the flattening route; the subflattening route's eigenproblem ~ (3k+1)^3."""
@@ -146,6 +185,16 @@ def gather_scores(local_scores, shards, n_total, group=None, device_tensor=None)
     for r in range(world):
         out[shards[r]] = allv[r, : len(shards[r])]
     return out
+
+
+def score_all_splits(pattern_probabilities, method=Method.flattening, route="auto", trivial=False, size=None,
+                     return_status=False):
+    """Scores of every split of the table's taxa, in `all_splits` order, without building the Python split objects
+    (single process; `score_splits(table, all_splits(taxa))` is the distributed form)."""
+    al = as_device_alignment(pattern_probabilities)
+    taxa_arr, a_arr = encode_all_splits(al.n_taxa, trivial=trivial, size=size)
+    scores, status = score_encoded(al, taxa_arr, a_arr, _method_code(method, route))
+    return (scores, status) if return_status else scores
 
 
 def score_splits(pattern_probabilities, splits, method=Method.flattening, distributed=None, group=None,

@@ -139,6 +139,25 @@ def test_encode_splits_and_resolve():
     assert sorted(oa.tolist()) == [0, 2] and sorted(ob.tolist()) == [1, 3]
 
 
+def test_encode_all_splits_matches_all_splits():
+    """The NumPy enumeration of the candidate splits = encode_splits(all_splits(taxa)) (reference splits.py:39-59 order),
+    for every taxon count and option."""
+    class T:
+        pass
+
+    for n in range(2, 12):
+        names = taxa_names(n)
+        t = T()
+        t.taxa = tuple(names)
+        for kw in ({}, {"trivial": True}, {"size": max(1, n // 2)}, {"size": 1}):
+            lst = list(sp.all_splits(names, **kw))
+            ta, aa = batch.encode_all_splits(n, **kw)
+            assert len(aa) == len(lst), (n, kw)
+            if lst:
+                tb, ab = batch.encode_splits(lst, t, n)
+                assert np.array_equal(ta, tb) and np.array_equal(aa, ab), (n, kw)
+
+
 def test_shard_plan_is_balanced_and_complete():
     a = np.array([len(s[0]) for s in sp.all_splits(taxa_names(10))], dtype=np.int32)
     costs = batch.split_costs(a, 10, _lib.SP_METHOD_FLATTENING)

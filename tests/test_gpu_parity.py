@@ -949,6 +949,12 @@ def test_config4_size_subflattening(sp):
             splits.append((tuple(names[t] for t in left), tuple(names[t] for t in range(n) if t not in left)))
     got, st = sp.score_splits(dev, splits, method=sp.Method.subflattening, return_status=True)
     assert not np.any(st & 3)
+    # the whole candidate set through the NumPy enumeration: 524 267 splits, one call
+    every = sp.score_all_splits(dev, method=sp.Method.subflattening)
+    assert every.shape == (524267,) and np.all(np.isfinite(every)) and every.min() >= 0 and every.max() < 1
+    from itertools import islice
+    head = list(islice(sp.all_splits(names), 64))
+    assert np.array_equal(sp.score_splits(dev, head, method=sp.Method.subflattening), every[:64])
     M = O.moment_matrix(keys, counts, n)
     for i in range(0, len(splits), 17):
         oa = [names.index(t) for t in splits[i][0]]
