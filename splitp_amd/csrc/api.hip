@@ -882,6 +882,33 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
 
 int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S);  // subflat.hip
 
+// Big-table form of the sparse route (sparse.hip: k_sparse_big): count tables beyond the 65535 rows of the list kernels, for
+// the taxon counts the dense route cannot take (12+).  Splits go in chunks so that one segmented sort stays below 2^32
+// entries and ~6 GB of work buffers.
+static int run_sparse_big_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S) {
+    sp_ctx* ctx = al->ctx;
+    const int64_t D = al->D;
+    const int n = al->n_taxa;
+    if (ctx->cache) ctx->cache->valid = false;   // the plan pools are overwritten
+    SP_CHECK(ctx->scores.ensure((size_t)S * 8));
+    SP_CHECK(ctx->status.ensure((size_t)S * 4));
+    const int64_t cap_entries = std::min<int64_t>(((int64_t)1 << 32) - 1, (int64_t)6e9 / 28);
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(S, cap_entries / std::max<int64_t>(D, 1)));
+    for (int64_t s0 = 0; s0 < S; s0 += chunk) {
+        const int64_t cnt = std::min(chunk, S - s0);
+        Plan plan;
+        SP_CHECK(plan_splits(n, D, split_taxa + s0 * n, split_a + s0, cnt, false, false, false, plan));
+        SP_CHECK(upload_plan(ctx, plan, D));
+        SP_CHECK(launch_reindex(ctx, al->keys.as<u64>(), D, n, ctx->splits.as<SplitDev>(), plan.splits, bm_ptr(ctx),
+                                pf_ptr(ctx, plan), ctx->dims.as<int2>(), rr_ptr(ctx), cc_ptr(ctx, (size_t)cnt, D)));
+        SP_CHECK(launch_sparse_big(ctx, D, cnt, rr_ptr(ctx), cc_ptr(ctx, (size_t)cnt, D),
+                                   al->exact ? al->counts.as<u32>() : nullptr, al->weights.as<double>(),
+                                   ctx->dims.as<int2>(), ctx->n_cu, ctx->scores.as<double>() + s0,
+                                   ctx->status.as<int>() + s0));
+    }
+    return SP_OK;
+}
+
 // Mutual-information route (divergence.hip): reindex (compact coordinates per split), marginals, sum.
 static int run_divergence_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S) {
     sp_ctx* ctx = al->ctx;
@@ -910,7 +937,28 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
     SP_HIP(hipSetDevice(ctx->device));
     if (n_splits == 0) return SP_OK;
     SP_REQUIRE(al->D > 0, SP_EINVAL, "empty pattern table");
-    if (method == SP_METHOD_FLATTENING || method == SP_METHOD_FLATTENING_DENSE ||
+    // tables beyond the list kernels' 65535 rows at taxon counts the dense route cannot take: the big-table form
+    bool handled = false;
+    if (method == SP_METHOD_FLATTENING && al->n_taxa <= 16) {
+        const char* fb = getenv("SPLITP_FORCE_BIG");   // "1": every table (tests)
+        bool want = fb && fb[0] == '1';
+        if (!want && al->n_taxa >= 12) {
+            if (!al->exact) {
+                want = true;            // float weights: the list kernels carry integer counts, the dense route ends at 11 taxa
+            } else {
+                int64_t srows = 0;
+                SP_CHECK(sparse_rows(al, &srows));
+                want = srows > 65535;
+            }
+        }
+        if (want) {
+            SP_CHECK(run_sparse_big_route(al, split_taxa, split_a, n_splits));
+            handled = true;
+        }
+    }
+    if (handled) {
+        // (scores and status are in the context's buffers, copied out below)
+    } else if (method == SP_METHOD_FLATTENING || method == SP_METHOD_FLATTENING_DENSE ||
         method == SP_METHOD_FLATTENING_SPARSE) {
         if (!ctx->cache) ctx->cache = new PlanCache();
         PlanCache& pc = *ctx->cache;

@@ -28,6 +28,10 @@
 
 #include "eig_small.h"   // jacobi_nb / EigShared for the wide fallback block
 
+#include <cstring>
+#include <type_traits>
+#include <rocprim/rocprim.hpp>   // segmented radix sort for the big-table form
+
 #ifndef SPK_THREADS
 #define SPK_THREADS 1024
 #endif
@@ -1496,5 +1500,357 @@ int launch_sparse_score_hbm(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, cons
         hipLaunchKernelGGL((k_sparse_score<true, false>), dim3((unsigned)S_sub), dim3(SPK_THREADS), lds, ctx->stream, als_dev,
                            1, n_taxa, splits_dev, order_dev, (int)S, scores, status, slabs, slab_bytes);
     SP_HIP(hipGetLastError());
+    return SP_OK;
+}
+
+
+// =====================================================================================================================
+// Big-table form: count tables with more than 65535 patterns (the 16-bit ids / offsets of the list kernels above end
+// there; 12 taxa beyond ~1 M sites, long branches), any side size, everything in global memory.
+// Per split the dense route's reindex kernel has already produced compact (row, col) for every pattern.  The two list
+// orders come from ONE stable segmented radix sort each (rocPRIM; segments = splits; keys = col resp. row, values =
+// pattern index), so every group is in table order like the counting sort above: reproducible bit for bit.
+// Products walk a sorted order in 1024 thread-chunks: a thread sums the runs inside its chunk; a run that crosses chunk
+// borders leaves partial sums (first / last run of a chunk) in LDS and its head's owner adds them up in chunk order.
+// Work is balanced whatever the group sizes (a 2|10 split has 16 rows of 6 k entries each).  Same block iteration, stop
+// rule and Cholesky-QR as above (V, W column-major in a per-workgroup slab); persistent workgroups loop over splits.
+#define SPKB_MAXHALF 40
+
+struct SpkbPart {
+    double first[SPK_THREADS][4];   // partial sums of a chunk's first run when it continues a previous chunk's run
+    double last[SPK_THREADS][4];    // ... of its last run when that continues into the next chunk
+    unsigned int flags[SPK_THREADS];   // bit 0: chunk starts inside a run; bit 1: the WHOLE chunk is inside that run
+};
+
+// out[key][0..3] = sum over the entries j of the run `key` of count * in[minor][0..3]; keys sorted (stable), perm = pattern
+// index of every sorted position, minor_of / counts indexed by pattern.  out has `nmajor` rows.  Ends with a barrier.
+template <typename CT>
+__device__ __forceinline__ void spkb_product(const u32* __restrict__ keys, const u32* __restrict__ perm,
+                                             const u32* __restrict__ minor_of, const CT* __restrict__ counts, int D,
+                                             const double* __restrict__ in, int ics, double* __restrict__ out, int ocs,
+                                             int nmajor, SpkbPart& pt) {
+    for (int i = threadIdx.x; i < nmajor; i += SPK_THREADS) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[(size_t)k * ocs + i] = 0.0;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    const int chunk = (D + SPK_THREADS - 1) / SPK_THREADS;
+    const int lo = min(D, t * chunk), hi = min(D, lo + chunk);
+    unsigned int fl = 0;
+    int j = lo;
+    if (lo < hi) {
+        double acc[4] = {0, 0, 0, 0};
+        if (lo > 0 && keys[lo] == keys[lo - 1]) {   // continuation of an earlier chunk's run
+            fl = 1;
+            const u32 key = keys[lo];
+            while (j < hi && keys[j] == key) {
+                const u32 p = perm[j];
+                const double c = (double)counts[p];
+                const u32 m = minor_of[p];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = fma(c, in[(size_t)k * ics + m], acc[k]);
+                ++j;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pt.first[t][k] = acc[k];
+            if (j == hi && hi < D && keys[hi] == key) fl |= 2;   // the run goes on: the whole chunk was inside it
+        }
+        while (j < hi) {   // runs whose head is in this chunk
+            const u32 key = keys[j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = 0.0;
+            while (j < hi && keys[j] == key) {
+                const u32 p = perm[j];
+                const double c = (double)counts[p];
+                const u32 m = minor_of[p];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = fma(c, in[(size_t)k * ics + m], acc[k]);
+                ++j;
+            }
+            if (j == hi && hi < D && keys[hi] == key) {   // continues in the next chunk: finished by the fix-up below
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pt.last[t][k] = acc[k];
+                fl |= 4;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) out[(size_t)k * ocs + key] = acc[k];
+            }
+        }
+    }
+    pt.flags[t] = fl;
+    __syncthreads();
+    if (fl & 4) {   // this thread owns the head of a run that crosses chunk borders
+        const u32 key = keys[hi - 1];
+        double acc[4] = {pt.last[t][0], pt.last[t][1], pt.last[t][2], pt.last[t][3]};
+        for (int u = t + 1; u < SPK_THREADS; ++u) {
+            const unsigned int fu = pt.flags[u];
+            if (!(fu & 1)) break;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += pt.first[u][k];
+            if (!(fu & 2)) break;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[(size_t)k * ocs + key] = acc[k];
+    }
+    __syncthreads();
+}
+
+// CT = u32: count table (trace exact in u64);  CT = double: float-weight table (trace summed in a fixed tree).
+template <typename CT>
+__global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, const u32* __restrict__ rr_all,
+                                                            const u32* __restrict__ cc_all,
+                                                            const u32* __restrict__ keyc_all, const u32* __restrict__ permc_all,
+                                                            const u32* __restrict__ keyr_all, const u32* __restrict__ permr_all,
+                                                            const CT* __restrict__ counts, const int2* __restrict__ dims,
+                                                            double* __restrict__ slabs, size_t slab_doubles,
+                                                            double* __restrict__ scores, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    SpkShared& sh = *reinterpret_cast<SpkShared*>(smem_b);
+    SpkbPart& pt = *reinterpret_cast<SpkbPart*>(smem_b + ((sizeof(SpkShared) + 15) & ~(size_t)15));
+    EigShared& esh = *reinterpret_cast<EigShared*>(smem_b + ((sizeof(SpkShared) + 15) & ~(size_t)15) +
+                                                   ((sizeof(SpkbPart) + 15) & ~(size_t)15));
+    const int D = (int)D64;
+    double* slab = slabs + (size_t)blockIdx.x * slab_doubles;
+    // trace = sum count^2 (exact in u64 for counts) and the 4 heaviest patterns, once per workgroup
+    double trace;
+    if (std::is_same<CT, u32>::value) {
+        unsigned long long tr_part = 0;
+        for (int i = threadIdx.x; i < D; i += SPK_THREADS) tr_part += (unsigned long long)counts[i] * (unsigned long long)counts[i];
+        unsigned long long* red64 = reinterpret_cast<unsigned long long*>(pt.first);
+        red64[threadIdx.x] = tr_part;
+        __syncthreads();
+        for (int sft = SPK_THREADS / 2; sft >= 1; sft >>= 1) {
+            if ((int)threadIdx.x < sft) red64[threadIdx.x] += red64[threadIdx.x + sft];
+            __syncthreads();
+        }
+        trace = (double)red64[0];
+    } else {
+        double tr_part = 0;
+        for (int i = threadIdx.x; i < D; i += SPK_THREADS) tr_part += (double)counts[i] * (double)counts[i];
+        double* redd = reinterpret_cast<double*>(pt.first);
+        redd[threadIdx.x] = tr_part;
+        __syncthreads();
+        for (int sft = SPK_THREADS / 2; sft >= 1; sft >>= 1) {
+            if ((int)threadIdx.x < sft) redd[threadIdx.x] += redd[threadIdx.x + sft];
+            __syncthreads();
+        }
+        trace = redd[0];
+    }
+    __syncthreads();
+    int top_idx[4];
+    {   // four rounds of a block arg-max over (weight, lowest index)
+        double* bval = reinterpret_cast<double*>(pt.first);
+        int* bidx = reinterpret_cast<int*>(pt.last);
+        int taken[4] = {-1, -1, -1, -1};
+#pragma unroll
+        for (int round = 0; round < 4; ++round) {
+            double mv = -1.0;
+            int mi = -1;
+            for (int i = threadIdx.x; i < D; i += SPK_THREADS) {
+                const double v = (double)counts[i];
+                if (i != taken[0] && i != taken[1] && i != taken[2] && i != taken[3] && v > mv) {   // (ascending i: ties keep the lowest)
+                    mv = v;
+                    mi = i;
+                }
+            }
+            bval[threadIdx.x] = mv;
+            bidx[threadIdx.x] = mi;
+            __syncthreads();
+            for (int sft = SPK_THREADS / 2; sft >= 1; sft >>= 1) {
+                if ((int)threadIdx.x < sft) {
+                    const double ov = bval[threadIdx.x + sft];
+                    const int oi = bidx[threadIdx.x + sft];
+                    const double cv = bval[threadIdx.x];
+                    const int ci = bidx[threadIdx.x];
+                    if (ov > cv || (ov == cv && oi >= 0 && (ci < 0 || oi < ci))) {
+                        bval[threadIdx.x] = ov;
+                        bidx[threadIdx.x] = oi;
+                    }
+                }
+                __syncthreads();
+            }
+            taken[round] = bidx[0];
+            top_idx[round] = (bval[0] > 0) ? bidx[0] : -1;
+            __syncthreads();
+        }
+    }
+    for (int sid = blockIdx.x; sid < S; sid += gridDim.x) {
+        const int R = dims[sid].x, C = dims[sid].y;
+        if (min(R, C) <= 4 || !(trace > 0)) {
+            if (threadIdx.x == 0) {
+                scores[sid] = trace > 0 ? 0.0 : __builtin_nan("");
+                status[sid] = 0;
+            }
+            continue;
+        }
+        const u32* rr = rr_all + (size_t)sid * D;
+        const u32* cc = cc_all + (size_t)sid * D;
+        const u32* keyc = keyc_all + (size_t)sid * D;
+        const u32* permc = permc_all + (size_t)sid * D;
+        const u32* keyr = keyr_all + (size_t)sid * D;
+        const u32* permr = permr_all + (size_t)sid * D;
+        const int Vp = ((R + 3) & ~3) + 4, Wp = ((C + 3) & ~3) + 4;
+        double* V = slab;                       // (8 columns each: the wide fallback block uses all of them)
+        double* W = slab + (size_t)SPK_WB * Vp;
+        // start block: unit vectors on the rows of the 4 most frequent patterns + hash noise, orthonormalised
+        int top_row[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) top_row[k] = top_idx[k] >= 0 ? (int)rr[top_idx[k]] : -1;
+        for (int i = threadIdx.x; i < Vp; i += SPK_THREADS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double x = 0.0;
+                if (i < R) {
+                    x = 0.02 * spk_hash((unsigned)i, (unsigned)k);
+                    bool hit = top_row[k] == i;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hit = hit && !(q < k && top_row[q] == top_row[k]);   // a row only once
+                    if (hit) x += 1.0;
+                }
+                V[(size_t)k * Vp + i] = x;
+            }
+        }
+        __syncthreads();
+        spk_gram(V, R, 1, Vp, sh);
+        spk_chol_factor(sh, false);
+        spk_orth(V, R, 1, Vp, sh);
+        double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0;
+        int it = 0, conv = 0;
+        for (it = 1; it <= SPKB_MAXHALF; ++it) {
+            const bool odd = it & 1;   // odd: W = C^T V (column order)   even: V = C W (row order)
+            double* X = odd ? W : V;
+            const int rows = odd ? C : R, xcs = odd ? Wp : Vp;
+            if (odd)
+                spkb_product(keyc, permc, rr, counts, D, V, Vp, W, Wp, C, pt);
+            else
+                spkb_product(keyr, permr, cc, counts, D, W, Wp, V, Vp, R, pt);
+            spk_gram(X, rows, 1, xcs, sh);
+            top4 = (sh.S[0] + sh.S[5]) + (sh.S[10] + sh.S[15]);
+            spk_chol_factor(sh, it >= 4, trace - top4);
+            if (spk_converged(top4, sh.L[11], trace, it, prev_sum, prev_delta, prev_ratio)) {
+                conv = 1;
+                break;
+            }
+            spk_orth(X, rows, 1, xcs, sh);
+        }
+        if (!conv) {
+            // no certified gap behind the 4th value after SPKB_MAXHALF half products (clustered / slowly decaying
+            // spectrum): the 8-wide fallback block of the list kernels, on the same sorted orders (two 4-column passes)
+            for (int i = threadIdx.x; i < Vp; i += SPK_THREADS) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) V[(size_t)(4 + k) * Vp + i] = i < R ? spk_hash((unsigned)i, (unsigned)(8 + k)) : 0.0;
+            }
+            __syncthreads();
+            double th4 = 0, sum8 = 0;
+            spk_wide_ritz_orth(V, R, Vp, esh, top4, th4, sum8);   // here only as an orthonormaliser
+            prev_sum = 0; prev_delta = 0; prev_ratio = 1.0;
+            int wit = 1;
+            for (; wit <= SPK_MAXHALF_WIDE; ++wit) {
+                const bool odd = wit & 1;
+                double* X = odd ? W : V;
+                const int rows = odd ? C : R, xcs = odd ? Wp : Vp;
+                for (int cb = 0; cb < SPK_WB; cb += 4) {
+                    if (odd)
+                        spkb_product(keyc, permc, rr, counts, D, V + (size_t)cb * Vp, Vp, W + (size_t)cb * Wp, Wp, C, pt);
+                    else
+                        spkb_product(keyr, permr, cc, counts, D, W + (size_t)cb * Wp, Wp, V + (size_t)cb * Vp, Vp, R, pt);
+                }
+                spk_wide_ritz_orth(X, rows, xcs, esh, top4, th4, sum8);
+                if (spk_wide_converged(top4, th4, sum8, trace, wit, prev_sum, prev_delta, prev_ratio)) {
+                    conv = 1;
+                    break;
+                }
+            }
+            it += wit;
+        }
+        if (threadIdx.x == 0) {
+            const double op = 1.0 - top4 / trace;
+            scores[sid] = sqrt(op > 0 ? op : 0.0);
+            status[sid] = (conv ? 0 : 1) | (it << 8);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_iota_segments(u32* __restrict__ out, int64_t D, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = (u32)(i % D);
+}
+__global__ void k_segment_offsets(u32* __restrict__ off, int64_t D, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= S) off[i] = (u32)((int64_t)i * D);
+}
+
+// rr / cc: compact coordinates of the D patterns for each of the S splits (reindex kernel), dims: matrix sizes.
+int launch_sparse_big(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, const u32* cc, const u32* counts,
+                      const double* weights, const int2* dims, int dev_cus, double* scores, int* status) {
+    if (S == 0) return SP_OK;
+    SP_REQUIRE(D >= 1 && D < ((int64_t)1 << 31) && S * D < ((int64_t)1 << 32), SP_ELIMIT,
+               "big-table form: %lld splits x %lld patterns per call is beyond the 2^32 entries one segmented sort takes",
+               (long long)S, (long long)D);
+    PhaseScope ps(ctx, SP_PHASE_SPARSE);
+    const size_t total = (size_t)S * (size_t)D;
+    DevBuf iota, keyc, permc, keyr, permr, off, tmp, slabs;
+    auto cleanup = [&]() { iota.release(); keyc.release(); permc.release(); keyr.release(); permr.release(); off.release();
+                           tmp.release(); slabs.release(); };
+    auto fail = [&](int code) { cleanup(); return code; };
+    int rc;
+    if ((rc = iota.ensure(total * 4)) || (rc = keyc.ensure(total * 4)) || (rc = permc.ensure(total * 4)) ||
+        (rc = keyr.ensure(total * 4)) || (rc = permr.ensure(total * 4)) || (rc = off.ensure((size_t)(S + 1) * 4)))
+        return fail(rc);
+    hipLaunchKernelGGL(k_iota_segments, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, iota.as<u32>(), D,
+                       (int64_t)total);
+    hipLaunchKernelGGL(k_segment_offsets, dim3((unsigned)((S + 256) / 256)), dim3(256), 0, ctx->stream, off.as<u32>(), D, (int)S);
+    unsigned bits = 1;
+    while (bits < 32 && ((int64_t)1 << bits) < D) ++bits;   // compact ids are < D
+    size_t t1 = 0;
+    hipError_t e = rocprim::segmented_radix_sort_pairs(nullptr, t1, cc, keyc.as<u32>(), iota.as<u32>(), permc.as<u32>(),
+                                                       (unsigned)total, (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits,
+                                                       ctx->stream);
+    if (e != hipSuccess) {
+        sp_set_error("big-table form: rocPRIM size query failed: %s", hipGetErrorString(e));
+        return fail(SP_EHIP);
+    }
+    if ((rc = tmp.ensure(std::max<size_t>(t1, 16)))) return fail(rc);
+    e = rocprim::segmented_radix_sort_pairs(tmp.p, t1, cc, keyc.as<u32>(), iota.as<u32>(), permc.as<u32>(), (unsigned)total,
+                                            (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits, ctx->stream);
+    if (e == hipSuccess)
+        e = rocprim::segmented_radix_sort_pairs(tmp.p, t1, rr, keyr.as<u32>(), iota.as<u32>(), permr.as<u32>(), (unsigned)total,
+                                                (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits, ctx->stream);
+    if (e != hipSuccess) {
+        sp_set_error("big-table form: segmented sort failed: %s", hipGetErrorString(e));
+        return fail(SP_EHIP);
+    }
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(S, dev_cus));
+    const size_t slab_doubles = (size_t)2 * SPK_WB * ((size_t)D + 16);   // V and W: 8 columns of at most D + 8 rows each
+    if ((rc = slabs.ensure((size_t)grid * slab_doubles * 8))) return fail(rc);
+    const size_t lds = ((sizeof(SpkShared) + 15) & ~(size_t)15) + ((sizeof(SpkbPart) + 15) & ~(size_t)15) + sizeof(EigShared) + 16;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_big<u32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_big<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            sp_set_error("big-table form: cannot reserve %zu bytes of LDS", lds);
+            return fail(SP_EHIP);
+        }
+        attr = true;
+    }
+    if (counts)
+        hipLaunchKernelGGL(k_sparse_big<u32>, dim3(grid), dim3(SPK_THREADS), lds, ctx->stream, D, (int)S, rr, cc,
+                           keyc.as<u32>(), permc.as<u32>(), keyr.as<u32>(), permr.as<u32>(), counts, dims, slabs.as<double>(),
+                           slab_doubles, scores, status);
+    else
+        hipLaunchKernelGGL(k_sparse_big<double>, dim3(grid), dim3(SPK_THREADS), lds, ctx->stream, D, (int)S, rr, cc,
+                           keyc.as<u32>(), permc.as<u32>(), keyr.as<u32>(), permr.as<u32>(), weights, dims,
+                           slabs.as<double>(), slab_doubles, scores, status);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the work buffers die at return
+    cleanup();
+    if (e != hipSuccess) {
+        sp_set_error("big-table form: %s", hipGetErrorString(e));
+        return SP_EHIP;
+    }
     return SP_OK;
 }

@@ -1026,3 +1026,59 @@ def test_device_simulator_20_taxa(sp):
         p = 0.75 * (1.0 - np.exp(-4.0 * d / 3.0))
         frac = float(cnt[digit(0) != digit(other)].sum()) / length
         assert abs(frac - p) <= 5.0 * np.sqrt(p * (1 - p) / length), (other, d, frac, p)
+
+
+def test_big_table_form(sp, golden, monkeypatch):
+    """The big-table form of the sparse route (k_sparse_big: stable segmented sorts + chunked segmented sums, everything in
+    global memory) - the only route for 12+ taxa once a table has more than 65535 patterns or float weights.
+    (a) forced on the 10-taxon golden table: the reference's scores, counts and float weights;
+    (b) a 12-taxon 1 M-site table (124 k patterns): oracle on the short-side splits, repeatable, floats = counts;
+    (c) forced on an adversarial 12-taxon table that needs its 8-wide fallback block: agrees with the list kernels."""
+    from splitp_amd import synthetic as syn
+
+    g, names, splits, table = _n10(golden, "n10_L100k")
+    dev = sp.DeviceAlignment.from_table(table, taxa=names)
+    dev_w = sp.DeviceAlignment.from_arrays(g["keys"], g["probs"], 10, taxa=names, exact=False)
+    monkeypatch.setenv("SPLITP_FORCE_BIG", "1")
+    for d in (dev, dev_w):
+        got, st = sp.score_splits(d, splits, return_status=True)
+        assert not np.any(st & 3) and np.abs(got - g["scores"]).max() <= SCORE_TOL
+    monkeypatch.delenv("SPLITP_FORCE_BIG")
+
+    n, length = 12, 1_000_000
+    names12 = syn.taxa_names(n)
+    sites = syn.simulate_sites(n, length, 0.08, seed=2)
+    keys, counts = syn.pattern_table(sites)
+    assert len(keys) > 65535
+    big = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=length, taxa=names12)
+    allsp = list(sp.all_splits(names12))
+    pick = allsp[::29]
+    got, st = sp.score_splits(big, pick, return_status=True)
+    assert not np.any(st & 3)
+    assert np.array_equal(got, sp.score_splits(big, pick))
+    big_w = sp.DeviceAlignment.from_arrays(keys, counts / float(length), n, taxa=names12, exact=False)
+    assert np.abs(sp.score_splits(big_w, pick) - got).max() <= SCORE_TOL
+    checked = 0
+    for i, spl in enumerate(pick):
+        if min(len(spl[0]), len(spl[1])) > 3:
+            continue
+        m = O.reduced_flattening_packed(keys, counts.astype(np.float64), n, [names12.index(t) for t in spl[0]],
+                                        [names12.index(t) for t in spl[1]])[0]
+        assert abs(O.dense_split_score(m) - got[i]) <= SCORE_TOL, (i, m.shape)
+        checked += 1
+    assert checked >= 5
+
+    rng = np.random.default_rng(1)
+    keys2, counts2 = _copy_mutate_table(rng, 12, 20000, 3)
+    adv = sp.DeviceAlignment.from_arrays(keys2, None, 12, counts=counts2, n_sites=int(counts2.sum()), taxa=names12)
+    splits2 = []
+    for _ in range(16):
+        k = int(rng.integers(2, 11))
+        left = sorted(rng.choice(12, size=k, replace=False).tolist())
+        splits2.append((tuple(names12[t] for t in left), tuple(names12[t] for t in range(12) if t not in left)))
+    want = sp.score_splits(adv, splits2)
+    monkeypatch.setenv("SPLITP_FORCE_BIG", "1")
+    got2, st2 = sp.score_splits(adv, splits2, return_status=True)
+    monkeypatch.delenv("SPLITP_FORCE_BIG")
+    assert not np.any(st2 & 3) and np.abs(got2 - want).max() <= SCORE_TOL
+    assert int((st2 >> 8).max()) > 41       # at least one split went through the wide block
