@@ -185,7 +185,9 @@ int sp_divergence_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, int64_t
  * Hand-back chain of SP_METHOD_FLATTENING on a count table (every stage bit-reproducible): in-LDS kernel -> the same
  * kernel with its entry lists in global memory -> with all arrays in global memory (tables beyond ~9 k patterns) ->
  * for a split whose 4-wide block finds no certified spectral gap in 40 half products: the dense route (smaller side
- * <= 1024 rows) or the kernel's 8-wide fallback block (larger sides, 12+ taxa). */
+ * <= 1024 rows) or the kernel's 8-wide fallback block (larger sides, 12+ taxa).
+ * Tables with more than 65535 patterns and float-weight tables: the dense route up to 11 taxa, from 12 taxa on the
+ * big-table form of the sparse route (segmented sorts + global-memory products, same block iteration and stop rule). */
 #define SP_METHOD_FLATTENING 0
 #define SP_METHOD_SUBFLATTENING 1
 #define SP_METHOD_FLATTENING_DENSE 2
