@@ -55,14 +55,14 @@ def _score_big_sparse(ri, ci, v, shape):
     """A sparse matrix whose smaller side exceeds what the dense route keeps in LDS (1024 compact rows): the flattening of
     12 and more taxa in the reference's default FlatFormat.sparse.  Re-expressed as a pattern table - key = row * 4^b + col
     with 4^a >= rows, 4^b >= cols is a table of a + b "taxa" whose flattening for the split (first a | last b) IS the
-    matrix - and scored by the batched sparse kernel (LDS form or its global-memory form).  Needs count-derived values
-    (value = count / N, as every table from an alignment has) and a + b <= 16; otherwise None (the caller's dense route
-    then reports the limit)."""
+    matrix - and scored by the batched sparse route: the list kernels for count-derived values (value = count / N, as
+    every table from an alignment has) up to 65535 cells, its big-table form for more cells or arbitrary non-negative
+    values.  Needs a + b <= 16; otherwise None (the caller's dense route then reports the limit)."""
     from .batch import score_encoded
     from .device import DeviceAlignment, infer_counts
 
     rows, cols = int(shape[0]), int(shape[1])
-    if min(rows, cols) <= 1024 or len(v) == 0 or len(v) > 65535:
+    if min(rows, cols) <= 1024 or len(v) == 0:
         return None
     a = max(1, (max(rows - 1, 1).bit_length() + 1) // 2)
     b = max(1, (max(cols - 1, 1).bit_length() + 1) // 2)
@@ -74,10 +74,14 @@ def _score_big_sparse(ri, ci, v, shape):
     if len(keys) > 1 and (np.diff(keys.astype(np.int64)) == 0).any():
         return None                                  # duplicate cells: not a flattening
     inf = infer_counts(vals)
-    if inf is None:
-        return None
-    counts, n_sites = inf
-    dev = DeviceAlignment.from_arrays(keys, None, a + b, counts=counts, n_sites=n_sites)
+    if inf is not None:
+        counts, n_sites = inf
+        dev = DeviceAlignment.from_arrays(keys, None, a + b, counts=counts, n_sites=n_sites)
+    else:                                            # arbitrary real values: the big-table form takes float weights
+        if (vals < 0).any():
+            return None                              # (its start block and trace assume non-negative weights only as a
+                                                     #  heuristic, but negative cells are not a flattening: dense route)
+        dev = DeviceAlignment.from_arrays(keys, vals, a + b, exact=False)
     taxa_arr = np.arange(a + b, dtype=np.int32)[None, :]
     try:
         scores, status = score_encoded(dev, taxa_arr, np.array([a], dtype=np.int32), _lib.SP_METHOD_FLATTENING)
