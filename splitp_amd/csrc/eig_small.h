@@ -156,9 +156,7 @@ __device__ __forceinline__ void jacobi_nb(EigShared& sh) {
         const int pa = act ? lane / NP : 0, pb = act ? lane % NP : 0;
         for (int e = lane; e < EIG_B * EIG_B; e += 64) sh.Q[(e >> 4) * EIG_VP + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
         wave_sync_lds();
-        int sweep_count = 0;
         for (int sweep = 0; sweep < 15; ++sweep) {
-            sweep_count = sweep;
             double rel = 0, dmx = 0;
             for (int k = 0; k < NB; ++k) dmx = fmax(dmx, fabs(sh.H[k * EIG_VP + k]));
             for (int e = lane; e < EIG_B * EIG_B; e += 64) {
