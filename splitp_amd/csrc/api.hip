@@ -939,11 +939,11 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
     SP_REQUIRE(al->D > 0, SP_EINVAL, "empty pattern table");
     // tables beyond the list kernels' 65535 rows at taxon counts the dense route cannot take: the big-table form
     bool handled = false;
-    if (method == SP_METHOD_FLATTENING && al->n_taxa <= 16) {
+    if (method == SP_METHOD_FLATTENING) {
         const char* fb = getenv("SPLITP_FORCE_BIG");   // "1": every table (tests)
         bool want = fb && fb[0] == '1';
         if (!want && al->n_taxa >= 12) {
-            if (!al->exact) {
+            if (!al->exact || al->n_taxa > 16) {   // (more than 16 taxa: the list kernels pack keys into 32 bits)
                 want = true;            // float weights: the list kernels carry integer counts, the dense route ends at 11 taxa
             } else {
                 int64_t srows = 0;

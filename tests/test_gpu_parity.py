@@ -1082,3 +1082,33 @@ def test_big_table_form(sp, golden, monkeypatch):
     monkeypatch.delenv("SPLITP_FORCE_BIG")
     assert not np.any(st2 & 3) and np.abs(got2 - want).max() <= SCORE_TOL
     assert int((st2 >> 8).max()) > 41       # at least one split went through the wide block
+
+
+def test_flattening_scores_20_taxa(sp):
+    """Flattening scores beyond 16 taxa (big-table form; sides up to 14 taxa): a 20-taxon 100 k-site alignment against the
+    reference's own sparse scorer (ARPACK top-4 + Frobenius norm, phylogenetics.py:303-312) on the reduced flattening."""
+    import scipy.sparse
+    from splitp_amd import synthetic as syn
+
+    n, length = 20, 100_000
+    names = syn.taxa_names(n)
+    sites = syn.simulate_sites(n, length, 0.05, seed=6)
+    keys, counts = syn.pattern_table(sites)
+    dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=length, taxa=names)
+    rng = np.random.default_rng(6)
+    splits = [(tuple(names[:10]), tuple(names[10:]))]                      # the root split of the balanced tree
+    for k in (6, 8, 10, 13):
+        left = sorted(rng.choice(n, size=k, replace=False).tolist())
+        splits.append((tuple(names[t] for t in left), tuple(names[t] for t in range(n) if t not in left)))
+    got, st = sp.score_splits(dev, splits, return_status=True)
+    assert not np.any(st & 3) and np.array_equal(got, sp.score_splits(dev, splits))
+    for i, spl in enumerate(splits):
+        rows, cols = O.flat_indices(keys, n, [names.index(t) for t in spl[0]], [names.index(t) for t in spl[1]])
+        ur, ri = np.unique(rows, return_inverse=True)
+        uc, ci = np.unique(cols, return_inverse=True)
+        m = scipy.sparse.coo_matrix((counts.astype(np.float64), (ri, ci)), shape=(len(ur), len(uc))).tocsc()
+        want = O.sparse_split_score(m)
+        assert abs(want - got[i]) <= 1e-9, (i, m.shape, want, got[i])
+    assert got[0] < got[1:].min()                                           # the true split scores lowest
+    with pytest.raises(NotImplementedError):                                # a side of more than 14 taxa: stated limit (SP_ELIMIT)
+        sp.score_splits(dev, [(tuple(names[:3]), tuple(names[3:]))])
