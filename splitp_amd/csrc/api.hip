@@ -892,10 +892,25 @@ static int run_sparse_big_route(sp_alignment* al, const int32_t* split_taxa, con
     if (ctx->cache) ctx->cache->valid = false;   // the plan pools are overwritten
     SP_CHECK(ctx->scores.ensure((size_t)S * 8));
     SP_CHECK(ctx->status.ensure((size_t)S * 4));
-    const int64_t cap_entries = std::min<int64_t>(((int64_t)1 << 32) - 1, (int64_t)6e9 / 28);
+    int max_side = 0;
+    for (int64_t s = 0; s < S; ++s) {
+        SP_REQUIRE(split_a[s] >= 1 && split_a[s] < n, SP_EINVAL, "split %lld: side sizes %d | %d", (long long)s, split_a[s],
+                   n - split_a[s]);
+        max_side = std::max(max_side, std::max(split_a[s], n - split_a[s]));
+    }
+    const bool by_keys = max_side > 14 || (getenv("SPLITP_BIG_BY_KEYS") != nullptr);   // beyond the bitmap compaction
+    const int64_t cap_entries = std::min<int64_t>(((int64_t)1 << 32) - 1, (int64_t)6e9 / (by_keys ? 56 : 28));
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(S, cap_entries / std::max<int64_t>(D, 1)));
     for (int64_t s0 = 0; s0 < S; s0 += chunk) {
         const int64_t cnt = std::min(chunk, S - s0);
+        if (by_keys) {
+            for (int64_t s = s0; s < s0 + cnt; ++s)
+                SP_CHECK(check_split(n, split_taxa + s * n, split_a[s], split_taxa + s * n + split_a[s], n - split_a[s]));
+            SP_CHECK(launch_sparse_big_keys(ctx, al->keys.as<u64>(), D, n, split_taxa + s0 * n, split_a + s0, cnt,
+                                            al->exact ? al->counts.as<u32>() : nullptr, al->weights.as<double>(), ctx->n_cu,
+                                            ctx->scores.as<double>() + s0, ctx->status.as<int>() + s0));
+            continue;
+        }
         Plan plan;
         SP_CHECK(plan_splits(n, D, split_taxa + s0 * n, split_a + s0, cnt, false, false, false, plan));
         SP_CHECK(upload_plan(ctx, plan, D));

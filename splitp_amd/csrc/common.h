@@ -202,6 +202,8 @@ int launch_divergence(sp_ctx* ctx, bool exact, int64_t D, int64_t S, const u32* 
 int launch_divergence_matrix(sp_ctx* ctx, const double* m_dev, int64_t rows, int64_t cols, double* scratch, double* out);
 size_t sparse_slab_bytes(int64_t D, int64_t bm_words, bool wide = false);
 size_t sparse_list_slab_bytes(int64_t D);
+int launch_sparse_big_keys(sp_ctx* ctx, const u64* keys, int64_t D, int n, const int32_t* split_taxa, const int32_t* split_a,
+                           int64_t S, const u32* counts, const double* weights, int dev_cus, double* scores, int* status);
 int launch_sparse_big(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, const u32* cc, const u32* counts,
                       const double* weights, const int2* dims, int dev_cus, double* scores, int* status);
 int launch_sparse_score_lists(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, const SplitDev* splits_dev,

@@ -1854,3 +1854,148 @@ int launch_sparse_big(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, const u3
     }
     return SP_OK;
 }
+
+
+// ---- big-table form without the bitmap compaction: sides of more than 14 taxa -------------------------------------------
+// The reindex kernel ranks side keys through presence bitmaps of 4^k bits, which ends at k = 14.  Here the raw side keys
+// (2 bits a taxon, up to 62 bits) are sorted directly - the same stable segmented sort that orders the products - and
+// the compact id of a key is the number of run heads before it.
+__global__ __launch_bounds__(256) void k_side_keys(const u64* __restrict__ keys, int64_t D, int n,
+                                                   const int* __restrict__ split_taxa, const int* __restrict__ split_a,
+                                                   u64* __restrict__ rk, u64* __restrict__ ck) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.y;
+    if (i >= D) return;
+    const u64 key = keys[i];
+    const int* taxa = split_taxa + (size_t)s * n;
+    const int a = split_a[s];
+    u64 r = 0, c = 0;
+    for (int t = 0; t < a; ++t) r = (r << 2) | ((key >> (2 * (n - 1 - taxa[t]))) & 3ull);
+    for (int t = a; t < n; ++t) c = (c << 2) | ((key >> (2 * (n - 1 - taxa[t]))) & 3ull);
+    rk[(size_t)s * D + i] = r;
+    ck[(size_t)s * D + i] = c;
+}
+
+// One workgroup per split: compact id of every sorted position (= run heads before it), the same id scattered back to
+// the patterns, and the number of distinct keys.
+__global__ __launch_bounds__(1024) void k_compact_sorted(const u64* __restrict__ sorted_keys, const u32* __restrict__ perm,
+                                                         int64_t D64, u32* __restrict__ id_sorted,
+                                                         u32* __restrict__ id_by_pattern, int* __restrict__ dim_out,
+                                                         int dim_stride) {
+    __shared__ u32 part[1024];
+    const int D = (int)D64;
+    const size_t base = (size_t)blockIdx.x * D;
+    const u64* k = sorted_keys + base;
+    const int t = threadIdx.x;
+    const int chunk = (D + 1023) / 1024;
+    const int lo = min(D, t * chunk), hi = min(D, lo + chunk);
+    u32 heads = 0;
+    for (int j = lo; j < hi; ++j) heads += (j == 0 || k[j] != k[j - 1]) ? 1u : 0u;
+    part[t] = heads;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan (Hillis-Steele)
+        const u32 v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u32 run = part[t] - heads;   // heads before this chunk
+    for (int j = lo; j < hi; ++j) {
+        run += (j == 0 || k[j] != k[j - 1]) ? 1u : 0u;
+        id_sorted[base + j] = run - 1;
+        id_by_pattern[base + perm[base + j]] = run - 1;
+    }
+    if (t == 1023) dim_out[(size_t)blockIdx.x * dim_stride] = (int)part[1023];
+}
+
+// split_taxa / split_a: host arrays of this chunk of splits.  keys: the table's pattern keys (device).
+int launch_sparse_big_keys(sp_ctx* ctx, const u64* keys, int64_t D, int n, const int32_t* split_taxa, const int32_t* split_a,
+                           int64_t S, const u32* counts, const double* weights, int dev_cus, double* scores, int* status) {
+    if (S == 0) return SP_OK;
+    SP_REQUIRE(D >= 1 && D < ((int64_t)1 << 31) && S * D < ((int64_t)1 << 32), SP_ELIMIT,
+               "big-table form: %lld splits x %lld patterns per call is beyond the 2^32 entries one segmented sort takes",
+               (long long)S, (long long)D);
+    int max_side = 1;
+    for (int64_t s = 0; s < S; ++s) max_side = std::max(max_side, std::max(split_a[s], n - split_a[s]));
+    SP_REQUIRE(max_side <= 31, SP_ELIMIT, "a split side of %d taxa does not fit a 64-bit side key", max_side);
+    PhaseScope ps(ctx, SP_PHASE_SPARSE);
+    const size_t total = (size_t)S * (size_t)D;
+    DevBuf d_taxa, d_a, rk, ck, sk, iota, permc, permr, idc_s, idr_s, cc, rr, dims, off, tmp, slabs;
+    auto cleanup = [&]() {
+        d_taxa.release(); d_a.release(); rk.release(); ck.release(); sk.release(); iota.release(); permc.release();
+        permr.release(); idc_s.release(); idr_s.release(); cc.release(); rr.release(); dims.release(); off.release();
+        tmp.release(); slabs.release();
+    };
+    auto fail = [&](int code) { cleanup(); return code; };
+    int rc;
+    if ((rc = d_taxa.ensure((size_t)S * n * 4)) || (rc = d_a.ensure((size_t)S * 4)) || (rc = rk.ensure(total * 8)) ||
+        (rc = ck.ensure(total * 8)) || (rc = sk.ensure(total * 8)) || (rc = iota.ensure(total * 4)) ||
+        (rc = permc.ensure(total * 4)) || (rc = permr.ensure(total * 4)) || (rc = idc_s.ensure(total * 4)) ||
+        (rc = idr_s.ensure(total * 4)) || (rc = cc.ensure(total * 4)) || (rc = rr.ensure(total * 4)) ||
+        (rc = dims.ensure((size_t)S * sizeof(int2))) || (rc = off.ensure((size_t)(S + 1) * 4)))
+        return fail(rc);
+    hipError_t e = hipMemcpyAsync(d_taxa.p, split_taxa, (size_t)S * n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_a.p, split_a, (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // (pageable host arrays of the caller)
+    if (e != hipSuccess) {
+        sp_set_error("big-table form: %s", hipGetErrorString(e));
+        return fail(SP_EHIP);
+    }
+    hipLaunchKernelGGL(k_side_keys, dim3((unsigned)((D + 255) / 256), (unsigned)S), dim3(256), 0, ctx->stream, keys, D, n,
+                       d_taxa.as<int>(), d_a.as<int>(), rk.as<u64>(), ck.as<u64>());
+    hipLaunchKernelGGL(k_iota_segments, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, iota.as<u32>(), D,
+                       (int64_t)total);
+    hipLaunchKernelGGL(k_segment_offsets, dim3((unsigned)((S + 256) / 256)), dim3(256), 0, ctx->stream, off.as<u32>(), D, (int)S);
+    const unsigned bits = (unsigned)(2 * max_side);
+    size_t t1 = 0;
+    e = rocprim::segmented_radix_sort_pairs(nullptr, t1, ck.as<u64>(), sk.as<u64>(), iota.as<u32>(), permc.as<u32>(),
+                                            (unsigned)total, (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits, ctx->stream);
+    if (e != hipSuccess) {
+        sp_set_error("big-table form: rocPRIM size query failed: %s", hipGetErrorString(e));
+        return fail(SP_EHIP);
+    }
+    if ((rc = tmp.ensure(std::max<size_t>(t1, 16)))) return fail(rc);
+    int* dimp = reinterpret_cast<int*>(dims.p);
+    e = rocprim::segmented_radix_sort_pairs(tmp.p, t1, ck.as<u64>(), sk.as<u64>(), iota.as<u32>(), permc.as<u32>(),
+                                            (unsigned)total, (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_compact_sorted, dim3((unsigned)S), dim3(1024), 0, ctx->stream, sk.as<u64>(), permc.as<u32>(), D,
+                           idc_s.as<u32>(), cc.as<u32>(), dimp + 1, 2);   // .y = columns
+        e = rocprim::segmented_radix_sort_pairs(tmp.p, t1, rk.as<u64>(), sk.as<u64>(), iota.as<u32>(), permr.as<u32>(),
+                                                (unsigned)total, (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits,
+                                                ctx->stream);
+    }
+    if (e != hipSuccess) {
+        sp_set_error("big-table form: segmented sort failed: %s", hipGetErrorString(e));
+        return fail(SP_EHIP);
+    }
+    hipLaunchKernelGGL(k_compact_sorted, dim3((unsigned)S), dim3(1024), 0, ctx->stream, sk.as<u64>(), permr.as<u32>(), D,
+                       idr_s.as<u32>(), rr.as<u32>(), dimp, 2);            // .x = rows
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(S, dev_cus));
+    const size_t slab_doubles = (size_t)2 * SPK_WB * ((size_t)D + 16);
+    if ((rc = slabs.ensure((size_t)grid * slab_doubles * 8))) return fail(rc);
+    const size_t lds = ((sizeof(SpkShared) + 15) & ~(size_t)15) + ((sizeof(SpkbPart) + 15) & ~(size_t)15) + sizeof(EigShared) + 16;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_big<u32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_big<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+        sp_set_error("big-table form: cannot reserve %zu bytes of LDS", lds);
+        return fail(SP_EHIP);
+    }
+    if (counts)
+        hipLaunchKernelGGL(k_sparse_big<u32>, dim3(grid), dim3(SPK_THREADS), lds, ctx->stream, D, (int)S, rr.as<u32>(),
+                           cc.as<u32>(), idc_s.as<u32>(), permc.as<u32>(), idr_s.as<u32>(), permr.as<u32>(), counts,
+                           reinterpret_cast<const int2*>(dims.p), slabs.as<double>(), slab_doubles, scores, status);
+    else
+        hipLaunchKernelGGL(k_sparse_big<double>, dim3(grid), dim3(SPK_THREADS), lds, ctx->stream, D, (int)S, rr.as<u32>(),
+                           cc.as<u32>(), idc_s.as<u32>(), permc.as<u32>(), idr_s.as<u32>(), permr.as<u32>(), weights,
+                           reinterpret_cast<const int2*>(dims.p), slabs.as<double>(), slab_doubles, scores, status);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess) {
+        sp_set_error("big-table form: %s", hipGetErrorString(e));
+        return SP_EHIP;
+    }
+    return SP_OK;
+}

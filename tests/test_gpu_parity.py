@@ -1043,6 +1043,9 @@ def test_big_table_form(sp, golden, monkeypatch):
     for d in (dev, dev_w):
         got, st = sp.score_splits(d, splits, return_status=True)
         assert not np.any(st & 3) and np.abs(got - g["scores"]).max() <= SCORE_TOL
+        monkeypatch.setenv("SPLITP_BIG_BY_KEYS", "1")          # compaction by sorting the raw side keys (sides > 14 taxa)
+        assert np.array_equal(sp.score_splits(d, splits), got)
+        monkeypatch.delenv("SPLITP_BIG_BY_KEYS")
     monkeypatch.delenv("SPLITP_FORCE_BIG")
 
     n, length = 12, 1_000_000
@@ -1110,5 +1113,15 @@ def test_flattening_scores_20_taxa(sp):
         want = O.sparse_split_score(m)
         assert abs(want - got[i]) <= 1e-9, (i, m.shape, want, got[i])
     assert got[0] < got[1:].min()                                           # the true split scores lowest
-    with pytest.raises(NotImplementedError):                                # a side of more than 14 taxa: stated limit (SP_ELIMIT)
-        sp.score_splits(dev, [(tuple(names[:3]), tuple(names[3:]))])
+    # sides of more than 14 taxa are beyond the bitmap compaction: the raw side keys are sorted instead
+    long_side = [(tuple(names[:2]), tuple(names[2:])), ((names[0], names[7], names[19]), tuple(t for t in names if t not in (names[0], names[7], names[19])))]
+    got_l, st_l = sp.score_splits(dev, long_side + splits[:2], return_status=True)
+    assert not np.any(st_l & 3)
+    assert np.abs(got_l[2:] - got[:2]).max() <= SCORE_TOL                   # same answers as the bitmap path for the short sides
+    for i, spl in enumerate(long_side):
+        rows, cols = O.flat_indices(keys, n, [names.index(t) for t in spl[0]], [names.index(t) for t in spl[1]])
+        ur, ri = np.unique(rows, return_inverse=True)
+        uc, ci = np.unique(cols, return_inverse=True)
+        m = np.zeros((len(ur), len(uc)))
+        np.add.at(m, (ri, ci), counts.astype(np.float64))
+        assert abs(O.dense_split_score(m) - got_l[i]) <= SCORE_TOL, (i, m.shape)
