@@ -136,6 +136,7 @@ extern "C" int sp_ctx_destroy(sp_ctx* c) {
                       &c->scores, &c->status,  &c->misc,   &c->misc2, &c->gram_items, &c->aldescs, &c->slabs};
     delete c->cache;
     for (auto* b : bufs) b->release();
+    for (auto& b : c->big) b.release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SP_OK;
@@ -899,7 +900,7 @@ static int run_sparse_big_route(sp_alignment* al, const int32_t* split_taxa, con
         max_side = std::max(max_side, std::max(split_a[s], n - split_a[s]));
     }
     const bool by_keys = max_side > 14 || (getenv("SPLITP_BIG_BY_KEYS") != nullptr);   // beyond the bitmap compaction
-    const int64_t cap_entries = std::min<int64_t>(((int64_t)1 << 32) - 1, (int64_t)6e9 / (by_keys ? 56 : 28));
+    const int64_t cap_entries = std::min<int64_t>(((int64_t)1 << 32) - 1, (int64_t)6e9 / (by_keys ? 96 : 64));
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(S, cap_entries / std::max<int64_t>(D, 1)));
     for (int64_t s0 = 0; s0 < S; s0 += chunk) {
         const int64_t cnt = std::min(chunk, S - s0);

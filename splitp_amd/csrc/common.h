@@ -93,6 +93,7 @@ struct sp_ctx {
     DevBuf gram_items; // GramItem[]: Gram tiles, then the row-block items
     DevBuf aldescs;    // AlDesc[] of the current multi-alignment call
     DevBuf slabs;      // per-workgroup global-memory slabs of the sparse kernel's HBM form (grow-only)
+    DevBuf big[24];    // work buffers of the big-table form (grow-only: a multi-GB hipMalloc / hipFree per call costs more than the kernels)
     std::vector<AlDesc> aldescs_host;
     hipEvent_t upload_ev = nullptr;  // last plan / descriptor upload of the sparse route (other streams wait on it)
     PlanCache* cache = nullptr;
