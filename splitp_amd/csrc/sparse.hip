@@ -1524,13 +1524,18 @@ struct SpkbPart {
 
 // out[key][0..3] = sum over the entries j of the run `key` of count * in[minor][0..3]; keys sorted (stable), perm = pattern
 // index of every sorted position, minor_of / counts indexed by pattern.  out has `nmajor` rows.  Ends with a barrier.
-template <typename CT>
+// RM: `in` / `out` are row-major blocks ([row][4]: the four values of a row are ONE 32-byte access - a column-major block
+// costs four L2 sectors per entry, and the products of a 124 k-pattern table are L2-bandwidth bound); else column-major
+// with column strides ics / ocs (the 8-wide fallback block, two 4-column passes).
+template <typename CT, bool RM>
 __device__ __forceinline__ void spkb_product(const u32* __restrict__ keys, const u32* __restrict__ minor,
                                              const CT* __restrict__ cnt, int D, const double* __restrict__ in, int ics,
                                              double* __restrict__ out, int ocs, int nmajor, SpkbPart& pt) {
+    auto iat = [&](u32 row, int k) { return RM ? (size_t)row * 4 + k : (size_t)k * ics + row; };
+    auto oat = [&](u32 row, int k) { return RM ? (size_t)row * 4 + k : (size_t)k * ocs + row; };
     for (int i = threadIdx.x; i < nmajor; i += SPK_THREADS) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) out[(size_t)k * ocs + i] = 0.0;
+        for (int k = 0; k < 4; ++k) out[oat((u32)i, k)] = 0.0;
     }
     __syncthreads();
     const int t = threadIdx.x;
@@ -1553,7 +1558,7 @@ __device__ __forceinline__ void spkb_product(const u32* __restrict__ keys, const
             const double c = (double)cnt[at(t, jj)];
             double x[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = in[(size_t)k * ics + m];
+            for (int k = 0; k < 4; ++k) x[k] = in[iat(m, k)];
             if (key != cur) {   // the run `cur` ended inside the chunk
                 if (first_run) {
 #pragma unroll
@@ -1561,7 +1566,7 @@ __device__ __forceinline__ void spkb_product(const u32* __restrict__ keys, const
                     first_run = false;
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) out[(size_t)k * ocs + cur] = acc[k];
+                    for (int k = 0; k < 4; ++k) out[oat(cur, k)] = acc[k];
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc[k] = 0.0;
@@ -1581,7 +1586,7 @@ __device__ __forceinline__ void spkb_product(const u32* __restrict__ keys, const
             fl |= 4;
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) out[(size_t)k * ocs + cur] = acc[k];
+            for (int k = 0; k < 4; ++k) out[oat(cur, k)] = acc[k];
         }
     }
     pt.flags[t] = fl;
@@ -1597,7 +1602,7 @@ __device__ __forceinline__ void spkb_product(const u32* __restrict__ keys, const
             if (!(fu & 2)) break;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) out[(size_t)k * ocs + key] = acc[k];
+        for (int k = 0; k < 4; ++k) out[oat(key, k)] = acc[k];
     }
     __syncthreads();
 }
@@ -1717,8 +1722,13 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
         const u32* minr = minr_all + (size_t)sid * dpad;
         const CT* cntr = cntr_all + (size_t)sid * dpad;
         const int Vp = ((R + 3) & ~3) + 4, Wp = ((C + 3) & ~3) + 4;
-        double* V = slab;                       // (8 columns each: the wide fallback block uses all of them)
-        double* W = slab + (size_t)SPK_WB * Vp;
+        // slab: row-major 4-wide V and W ([row][4]) for the normal iteration, then the column-major 8-column blocks of
+        // the wide fallback
+        const size_t dpad16 = (size_t)D + 16;
+        double* V = slab;
+        double* W = slab + 4 * dpad16;
+        double* V8 = slab + 8 * dpad16;
+        double* W8 = V8 + (size_t)SPK_WB * Vp;
         // start block: unit vectors on the rows of the 4 most frequent patterns + hash noise, orthonormalised
         int top_row[4];
 #pragma unroll
@@ -1734,53 +1744,56 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
                     for (int q = 0; q < 4; ++q) hit = hit && !(q < k && top_row[q] == top_row[k]);   // a row only once
                     if (hit) x += 1.0;
                 }
-                V[(size_t)k * Vp + i] = x;
+                if (i < R) V[(size_t)i * 4 + k] = x;
             }
         }
         __syncthreads();
-        spk_gram(V, R, 1, Vp, sh);
+        spk_gram(V, R, 4, 1, sh);
         spk_chol_factor(sh, false);
-        spk_orth(V, R, 1, Vp, sh);
+        spk_orth(V, R, 4, 1, sh);
         double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0;
         int it = 0, conv = 0;
         for (it = 1; it <= SPKB_MAXHALF; ++it) {
             const bool odd = it & 1;   // odd: W = C^T V (column order)   even: V = C W (row order)
             double* X = odd ? W : V;
-            const int rows = odd ? C : R, xcs = odd ? Wp : Vp;
+            const int rows = odd ? C : R;
             if (odd)
-                spkb_product(keyc, minc, cntc, D, V, Vp, W, Wp, C, pt);
+                spkb_product<CT, true>(keyc, minc, cntc, D, V, 0, W, 0, C, pt);
             else
-                spkb_product(keyr, minr, cntr, D, W, Wp, V, Vp, R, pt);
-            spk_gram(X, rows, 1, xcs, sh);
+                spkb_product<CT, true>(keyr, minr, cntr, D, W, 0, V, 0, R, pt);
+            spk_gram(X, rows, 4, 1, sh);
             top4 = (sh.S[0] + sh.S[5]) + (sh.S[10] + sh.S[15]);
             spk_chol_factor(sh, it >= 4, trace - top4);
             if (spk_converged(top4, sh.L[11], trace, it, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
                 break;
             }
-            spk_orth(X, rows, 1, xcs, sh);
+            spk_orth(X, rows, 4, 1, sh);
         }
         if (!conv) {
             // no certified gap behind the 4th value after SPKB_MAXHALF half products (clustered / slowly decaying
             // spectrum): the 8-wide fallback block of the list kernels, on the same sorted orders (two 4-column passes)
-            for (int i = threadIdx.x; i < Vp; i += SPK_THREADS) {
+            for (int i = threadIdx.x; i < Vp; i += SPK_THREADS) {   // columns 0..3: the block so far, 4..7: noise
 #pragma unroll
-                for (int k = 0; k < 4; ++k) V[(size_t)(4 + k) * Vp + i] = i < R ? spk_hash((unsigned)i, (unsigned)(8 + k)) : 0.0;
+                for (int k = 0; k < 4; ++k) {
+                    V8[(size_t)k * Vp + i] = i < R ? V[(size_t)i * 4 + k] : 0.0;
+                    V8[(size_t)(4 + k) * Vp + i] = i < R ? spk_hash((unsigned)i, (unsigned)(8 + k)) : 0.0;
+                }
             }
             __syncthreads();
             double th4 = 0, sum8 = 0;
-            spk_wide_ritz_orth(V, R, Vp, esh, top4, th4, sum8);   // here only as an orthonormaliser
+            spk_wide_ritz_orth(V8, R, Vp, esh, top4, th4, sum8);   // here only as an orthonormaliser
             prev_sum = 0; prev_delta = 0; prev_ratio = 1.0;
             int wit = 1;
             for (; wit <= SPK_MAXHALF_WIDE; ++wit) {
                 const bool odd = wit & 1;
-                double* X = odd ? W : V;
+                double* X = odd ? W8 : V8;
                 const int rows = odd ? C : R, xcs = odd ? Wp : Vp;
                 for (int cb = 0; cb < SPK_WB; cb += 4) {
                     if (odd)
-                        spkb_product(keyc, minc, cntc, D, V + (size_t)cb * Vp, Vp, W + (size_t)cb * Wp, Wp, C, pt);
+                        spkb_product<CT, false>(keyc, minc, cntc, D, V8 + (size_t)cb * Vp, Vp, W8 + (size_t)cb * Wp, Wp, C, pt);
                     else
-                        spkb_product(keyr, minr, cntr, D, W + (size_t)cb * Wp, Wp, V + (size_t)cb * Vp, Vp, R, pt);
+                        spkb_product<CT, false>(keyr, minr, cntr, D, W8 + (size_t)cb * Wp, Wp, V8 + (size_t)cb * Vp, Vp, R, pt);
                 }
                 spk_wide_ritz_orth(X, rows, xcs, esh, top4, th4, sum8);
                 if (spk_wide_converged(top4, th4, sum8, trace, wit, prev_sum, prev_delta, prev_ratio)) {
@@ -1822,7 +1835,8 @@ static int big_run_kernel(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, cons
     auto fail = [&](int code) { cleanup(); return code; };
     int rc;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(S, dev_cus));
-    const size_t slab_doubles = (size_t)2 * SPK_WB * ((size_t)D + 16);   // V and W: 8 columns of at most D + 8 rows each
+    // row-major 4-wide V and W (4 (D + 16) doubles each), then the column-major 8-column blocks of the wide fallback
+    const size_t slab_doubles = (size_t)(8 + 2 * SPK_WB) * ((size_t)D + 16);
     if ((rc = minc.ensure(padded * 4)) || (rc = minr.ensure(padded * 4)) || (rc = cntc.ensure(padded * sizeof(CT))) ||
         (rc = cntr.ensure(padded * sizeof(CT))) || (rc = kci.ensure(padded * 4)) || (rc = kri.ensure(padded * 4)) ||
         (rc = slabs.ensure((size_t)grid * slab_doubles * 8)))
