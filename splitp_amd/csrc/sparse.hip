@@ -1613,11 +1613,16 @@ template <typename CT>
 __global__ void k_gather_sorted(const u32* __restrict__ key_sorted, const u32* __restrict__ perm,
                                 const u32* __restrict__ other_by_pattern, const CT* __restrict__ counts, int64_t D,
                                 int64_t total, u32* __restrict__ key_i, u32* __restrict__ minor_i, CT* __restrict__ cnt_i) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    const int64_t seg = g / D, j = g % D;
+    // (one thread per DESTINATION word: the three stores of a wave are consecutive; scattered 4-byte stores - one thread
+    // per source position - made this kernel as expensive as the iteration itself)
     const int64_t chunk = (D + SPK_THREADS - 1) / SPK_THREADS;
-    const int64_t dst = seg * chunk * SPK_THREADS + (j % chunk) * SPK_THREADS + j / chunk;
+    const int64_t dpad = chunk * SPK_THREADS;
+    const int64_t dst = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dst >= total) return;   // total = segments * dpad here
+    const int64_t seg = dst / dpad, r = dst % dpad;
+    const int64_t j = (r % SPK_THREADS) * chunk + r / SPK_THREADS;
+    if (j >= D) return;         // padding: never read
+    const int64_t g = seg * D + j;
     const u32 p = perm[g];
     key_i[dst] = key_sorted[g];
     minor_i[dst] = other_by_pattern[seg * D + p];
@@ -1827,7 +1832,6 @@ template <typename CT>
 static int big_run_kernel(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, const u32* cc, const u32* keyc, const u32* permc,
                           const u32* keyr, const u32* permr, const CT* counts, const int2* dims, int dev_cus,
                           double* scores, int* status) {
-    const size_t total = (size_t)S * (size_t)D;
     DevBuf &minc = ctx->big[0], &minr = ctx->big[1], &cntc = ctx->big[2], &cntr = ctx->big[3], &slabs = ctx->big[4],
            &kci = ctx->big[20], &kri = ctx->big[21];
     const size_t padded = (size_t)S * (size_t)((D + SPK_THREADS - 1) / SPK_THREADS) * SPK_THREADS;
@@ -1841,10 +1845,10 @@ static int big_run_kernel(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, cons
         (rc = cntr.ensure(padded * sizeof(CT))) || (rc = kci.ensure(padded * 4)) || (rc = kri.ensure(padded * 4)) ||
         (rc = slabs.ensure((size_t)grid * slab_doubles * 8)))
         return fail(rc);
-    const dim3 gg((unsigned)((total + 255) / 256));
-    hipLaunchKernelGGL(k_gather_sorted<CT>, gg, dim3(256), 0, ctx->stream, keyc, permc, rr, counts, D, (int64_t)total,
+    const dim3 gg((unsigned)((padded + 255) / 256));
+    hipLaunchKernelGGL(k_gather_sorted<CT>, gg, dim3(256), 0, ctx->stream, keyc, permc, rr, counts, D, (int64_t)padded,
                        kci.as<u32>(), minc.as<u32>(), cntc.as<CT>());   // column order: the minor index is the row
-    hipLaunchKernelGGL(k_gather_sorted<CT>, gg, dim3(256), 0, ctx->stream, keyr, permr, cc, counts, D, (int64_t)total,
+    hipLaunchKernelGGL(k_gather_sorted<CT>, gg, dim3(256), 0, ctx->stream, keyr, permr, cc, counts, D, (int64_t)padded,
                        kri.as<u32>(), minr.as<u32>(), cntr.as<CT>());   // row order: the minor index is the column
     const size_t lds = ((sizeof(SpkShared) + 15) & ~(size_t)15) + ((sizeof(SpkbPart) + 15) & ~(size_t)15) + sizeof(EigShared) + 16;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_big<CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
