@@ -707,11 +707,10 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
             if ((st[i] >> 8) == 0) fit.push_back(i);
         if (!fit.empty() && al->spk_D <= 65535) {
             const size_t slab = sparse_list_slab_bytes(al->spk_D);
-            DevBuf fidx;
+            DevBuf& fidx = ctx->big[22];   // (pooled: a hipMalloc / hipFree pair per call costs more than the index upload)
             DevBuf& slabs = ctx->slabs;
             int rc2 = SP_OK;
             if ((rc2 = slabs.ensure(fit.size() * slab)) || (rc2 = fidx.ensure(fit.size() * 4))) {
-                fidx.release();
                 return rc2;
             }
             hipError_t e = hipMemcpyAsync(fidx.p, fit.data(), fit.size() * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -722,7 +721,6 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
             if (e == hipSuccess && rc2 == SP_OK)
                 e = hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            fidx.release();
             if (rc2 != SP_OK) return rc2;
             if (e != hipSuccess) {
                 sp_set_error("sparse route (lists in global memory): %s", hipGetErrorString(e));
@@ -745,11 +743,10 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
         if (!fit.empty() && al->spk_D <= 65535) {
             const size_t slab = (sparse_slab_bytes(al->spk_D, bmw) + 255) & ~(size_t)255;
             const size_t chunk = std::max<size_t>(1, std::min<size_t>(fit.size(), ((size_t)2 << 30) / slab));
-            DevBuf fidx;
+            DevBuf& fidx = ctx->big[22];   // (pooled: a hipMalloc / hipFree pair per call costs more than the index upload)
             DevBuf& slabs = ctx->slabs;   // kept for the next call (a 2 GB hipMalloc costs more than the kernel)
             int rc2 = SP_OK;
             if ((rc2 = slabs.ensure(chunk * slab)) || (rc2 = fidx.ensure(fit.size() * 4))) {
-                fidx.release();
                 return rc2;
             }
             hipError_t e = hipMemcpyAsync(fidx.p, fit.data(), fit.size() * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -762,7 +759,6 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
             if (e == hipSuccess && rc2 == SP_OK)
                 e = hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            fidx.release();
             if (rc2 != SP_OK) return rc2;
             if (e != hipSuccess) {
                 sp_set_error("sparse route (HBM form): %s", hipGetErrorString(e));
@@ -791,11 +787,10 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
         if (!widev.empty() && al->spk_D <= 65535) {
             const size_t slab = (sparse_slab_bytes(al->spk_D, bmw, true) + 255) & ~(size_t)255;
             const size_t chunk = std::max<size_t>(1, std::min<size_t>(widev.size(), ((size_t)2 << 30) / slab));
-            DevBuf widx;
+            DevBuf& widx = ctx->big[22];
             DevBuf& slabs = ctx->slabs;
             int rc2 = SP_OK;
             if ((rc2 = slabs.ensure(chunk * slab)) || (rc2 = widx.ensure(widev.size() * 4))) {
-                widx.release();
                 return rc2;
             }
             hipError_t e = hipMemcpyAsync(widx.p, widev.data(), widev.size() * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -808,7 +803,6 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
             if (e == hipSuccess && rc2 == SP_OK)
                 e = hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            widx.release();
             if (rc2 != SP_OK) return rc2;
             if (e != hipSuccess) {
                 sp_set_error("sparse route (wide block): %s", hipGetErrorString(e));

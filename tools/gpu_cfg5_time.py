@@ -10,12 +10,14 @@ splits = list(sp.all_splits(names))
 for L in (20_000, 100_000):
     dev = sim.generate_device_alignment(syn.balanced_tree(n), sim.JukesCantor(), L, seed=5, branch_length=0.05)
     dev.taxa = tuple(names)
-    sp.score_splits(dev, splits)
+    from splitp_amd import batch, _lib
+    taxa_arr, a_arr = batch.encode_all_splits(n)          # (the Python split objects cost more than the scoring)
+    batch.score_encoded(dev, taxa_arr, a_arr, _lib.SP_METHOD_FLATTENING)
     dev.ctx.enable_timing(True)
     for rep in range(2):
         dev.ctx.reset_timing()
         t0 = time.perf_counter()
-        s, st = sp.score_splits(dev, splits, return_status=True)
+        s, st = batch.score_encoded(dev, taxa_arr, a_arr, _lib.SP_METHOD_FLATTENING)
         dt = time.perf_counter() - t0
         ph = {k: (round(v[0], 3), v[1]) for k, v in dev.ctx.phase_times().items() if v[1]}
         print("L", L, "D", dev.info()["D"], "wall %.2f ms" % (dt * 1e3), ph, "splits/s %.0f" % (len(splits) / dt))
