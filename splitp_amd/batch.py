@@ -204,8 +204,20 @@ def score_all_splits(pattern_probabilities, method=Method.flattening, route="aut
     """Scores of every split of the table's taxa, in `all_splits` order, without building the Python split objects
     (single process; `score_splits(table, all_splits(taxa))` is the distributed form)."""
     al = as_device_alignment(pattern_probabilities)
+    code = _method_code(method, route)
+    if code == _lib.SP_METHOD_SUBFLATTENING and al.n_taxa <= 31:
+        # the splits are enumerated on the device (sp_score_all_splits): no split list is built or uploaded at all
+        lib = al.ctx._lib
+        n = C.c_int64()
+        _lib.check(lib.sp_score_all_splits(al.handle, code, int(bool(trivial)), int(size or 0), C.byref(n), None, None, None))
+        scores = np.empty(n.value, dtype=np.float64)
+        status = np.zeros(n.value, dtype=np.int32)
+        if n.value:
+            _lib.check(lib.sp_score_all_splits(al.handle, code, int(bool(trivial)), int(size or 0), C.byref(n),
+                                               _lib._ptr(scores, C.c_double), None, _lib._ptr(status, C.c_int32)))
+        return (scores, status) if return_status else scores
     taxa_arr, a_arr = encode_all_splits(al.n_taxa, trivial=trivial, size=size)
-    scores, status = score_encoded(al, taxa_arr, a_arr, _method_code(method, route))
+    scores, status = score_encoded(al, taxa_arr, a_arr, code)
     return (scores, status) if return_status else scores
 
 

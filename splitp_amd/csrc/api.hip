@@ -1021,6 +1021,30 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
     return SP_OK;
 }
 
+int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int64_t* n_out, bool score);  // subflat.hip
+
+// Every split of the table's taxa in the reference's all_splits order (splits.py:39-59), enumerated on the device.
+extern "C" int sp_score_all_splits(sp_alignment* al, int method, int trivial, int size, int64_t* n_splits,
+                                   double* scores_host, void* scores_dev, int32_t* status_host) {
+    SP_REQUIRE(al, SP_EINVAL, "alignment is NULL");
+    sp_ctx* ctx = al->ctx;
+    SP_HIP(hipSetDevice(ctx->device));
+    SP_REQUIRE(method == SP_METHOD_SUBFLATTENING, SP_EINVAL,
+               "sp_score_all_splits enumerates on the device for SP_METHOD_SUBFLATTENING only (method %d: pass the "
+               "split list to sp_score_splits)", method);
+    const bool score = scores_host || scores_dev || status_host;
+    SP_REQUIRE(!score || al->D > 0, SP_EINVAL, "empty pattern table");
+    int64_t n = 0;
+    SP_CHECK(run_subflat_all_splits(al, trivial, size, &n, score));
+    if (n_splits) *n_splits = n;
+    if (!score || n == 0) return SP_OK;
+    if (scores_dev) SP_HIP(hipMemcpyAsync(scores_dev, ctx->scores.p, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (scores_host) SP_HIP(hipMemcpyAsync(scores_host, ctx->scores.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (status_host) SP_HIP(hipMemcpyAsync(status_host, ctx->status.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (scores_host || status_host) SP_HIP(hipStreamSynchronize(ctx->stream));
+    return SP_OK;
+}
+
 // Generic matrix: upload (transposed if needed so the smaller side indexes rows), Gram, eigen.
 extern "C" int sp_score_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, int64_t cols, int64_t ld,
                                    double* score) {

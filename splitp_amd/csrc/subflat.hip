@@ -557,6 +557,9 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
     }
 }
 
+// Scores of S splits whose taxon lists (int8, split-major) and first-side sizes already sit on the device.
+static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da, int64_t S, int kmax);
+
 int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S) {
     sp_ctx* ctx = al->ctx;
     const int n = al->n_taxa;
@@ -575,16 +578,110 @@ int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t
         }
         kmax = std::max(kmax, std::min(a, n - a));
     }
-    SP_CHECK(ensure_moments(al));
-    const int rmax = (3 * kmax + 1 + 1) & ~1;
     SP_CHECK(ctx->coords.ensure(taxa8.size() + (size_t)S * 4 + 64));
-    SP_CHECK(ctx->scores.ensure((size_t)S * 8));
-    SP_CHECK(ctx->status.ensure((size_t)S * 4));
     int8_t* dtaxa = ctx->coords.as<int8_t>();
     int* da = reinterpret_cast<int*>(dtaxa + ((taxa8.size() + 15) & ~(size_t)15));
     SP_HIP(hipMemcpyAsync(dtaxa, taxa8.data(), taxa8.size(), hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(hipMemcpyAsync(da, split_a, (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));  // taxa8 is a host temporary
+    return launch_subscore(al, dtaxa, da, S, kmax);
+}
+
+// ---- every split of the taxa, enumerated on the device ----------------------------------------------------------------
+// all_splits (reference splits.py:39-59): size classes ascending; inside a class itertools.combinations order (for the
+// balanced class n/2|n/2: taxon 0 plus every (n/2 - 1)-subset of the others); the side holding taxon 0 first, both sides in
+// taxon order.  Building those 524 267 Python tuples for 20 taxa costs seconds, encoding them 1.2 s, scoring them 21 ms:
+// here thread i un-ranks combination i of its class (combinatorial number system) and writes the taxon list itself.
+__global__ __launch_bounds__(256) void k_enumerate_splits(int n, int bal, int even, unsigned long long count,
+                                                          const unsigned long long* __restrict__ binom,   // [33][33]
+                                                          int8_t* __restrict__ taxa_out, int* __restrict__ a_out) {
+    const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= count) return;
+    const int m = even ? n - 1 : n, r = even ? bal - 1 : bal, base = even ? 1 : 0;
+    unsigned int member = even ? 1u : 0u;
+    unsigned long long x = idx;
+    int e = 0;
+    for (int slot = 0; slot < r; ++slot) {
+        // combinations starting with element e at this slot: C(m - e - 1, r - slot - 1)
+        while (true) {
+            const unsigned long long c = binom[(m - e - 1) * 33 + (r - slot - 1)];
+            if (x < c) break;
+            x -= c;
+            ++e;
+        }
+        member |= 1u << (e + base);
+        ++e;
+    }
+    const unsigned int all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    const unsigned int first = (member & 1u) ? member : (~member & all);   // the side that holds taxon 0
+    int8_t* out = taxa_out + idx * (unsigned long long)n;
+    int pos = 0;
+    for (int t = 0; t < n; ++t)
+        if (first & (1u << t)) out[pos++] = (int8_t)t;
+    const int a = pos;
+    for (int t = 0; t < n; ++t)
+        if (!(first & (1u << t))) out[pos++] = (int8_t)t;
+    a_out[idx] = a;
+}
+
+static unsigned long long binom_host(int nn, int kk) {
+    if (kk < 0 || kk > nn) return 0;
+    unsigned long long c = 1;
+    for (int i = 1; i <= kk; ++i) c = c * (unsigned long long)(nn - kk + i) / (unsigned long long)i;   // exact: c stays an integer
+    return c;
+}
+
+// Number of splits all_splits yields, and - when scores are asked for - their subflattening scores in that order.
+int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int64_t* n_out, bool score) {
+    sp_ctx* ctx = al->ctx;
+    const int n = al->n_taxa;
+    SP_REQUIRE(n >= 2 && n <= 31, SP_ELIMIT, "split enumeration supports 2..31 taxa (got %d)", n);
+    SP_REQUIRE(size >= 0 && size <= n / 2, SP_EINVAL, "size %d out of range [0, %d]", size, n / 2);
+    std::vector<int> sizes;
+    if (size > 0) sizes.push_back(size);
+    else for (int b = trivial ? 1 : 2; b <= n / 2; ++b) sizes.push_back(b);
+    int64_t total = 0;
+    std::vector<unsigned long long> counts;
+    for (int b : sizes) {
+        const bool even = 2 * b == n;
+        const unsigned long long c = even ? binom_host(n - 1, b - 1) : binom_host(n, b);
+        counts.push_back(c);
+        total += (int64_t)c;
+    }
+    if (n_out) *n_out = total;
+    if (!score || total == 0) return SP_OK;
+    SP_REQUIRE(total < ((int64_t)1 << 31), SP_ELIMIT, "%lld splits: more than one call takes", (long long)total);
+    std::vector<unsigned long long> bt(33 * 33, 0);
+    for (int i = 0; i < 33; ++i)
+        for (int j = 0; j <= i; ++j) bt[i * 33 + j] = binom_host(i, j);
+    const size_t taxa_bytes = ((size_t)total * n + 15) & ~(size_t)15;
+    SP_CHECK(ctx->coords.ensure(taxa_bytes + (size_t)total * 4 + 64));
+    SP_CHECK(ctx->misc2.ensure(bt.size() * 8));
+    int8_t* dtaxa = ctx->coords.as<int8_t>();
+    int* da = reinterpret_cast<int*>(dtaxa + taxa_bytes);
+    SP_HIP(hipMemcpyAsync(ctx->misc2.p, bt.data(), bt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));   // bt is a host temporary
+    int64_t off = 0;
+    int kmax = 0;
+    for (size_t q = 0; q < sizes.size(); ++q) {
+        const int b = sizes[q];
+        if (counts[q] == 0) continue;
+        hipLaunchKernelGGL(k_enumerate_splits, dim3((unsigned)((counts[q] + 255) / 256)), dim3(256), 0, ctx->stream, n, b,
+                           2 * b == n ? 1 : 0, counts[q], ctx->misc2.as<unsigned long long>(), dtaxa + (size_t)off * n, da + off);
+        off += (int64_t)counts[q];
+        kmax = std::max(kmax, b);
+    }
+    SP_HIP(hipGetLastError());
+    return launch_subscore(al, dtaxa, da, total, kmax);
+}
+
+static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da, int64_t S, int kmax) {
+    sp_ctx* ctx = al->ctx;
+    const int n = al->n_taxa;
+    SP_CHECK(ensure_moments(al));
+    const int rmax = (3 * kmax + 1 + 1) & ~1;
+    SP_CHECK(ctx->scores.ensure((size_t)S * 8));
+    SP_CHECK(ctx->status.ensure((size_t)S * 4));
     PhaseScope ps(ctx, SP_PHASE_SUBSCORE);
     const int mdim = 3 * n + 1;
     if (mdim <= SUBT_MMAX && rmax <= 32 && !getenv("SPLITP_SUBSCORE_JACOBI")) {   // fast form (the env switch keeps the Jacobi kernel testable)

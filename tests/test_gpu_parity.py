@@ -955,6 +955,15 @@ def test_config4_size_subflattening(sp):
     from itertools import islice
     head = list(islice(sp.all_splits(names), 64))
     assert np.array_equal(sp.score_splits(dev, head, method=sp.Method.subflattening), every[:64])
+    # ... which enumerates the splits on the device: same scores as the host enumeration, every size class and option
+    from splitp_amd import batch, _lib
+    ta, aa = batch.encode_all_splits(n)
+    host_way, _ = batch.score_encoded(dev, ta, aa, _lib.SP_METHOD_SUBFLATTENING)
+    assert np.array_equal(host_way, every)
+    for kw in ({"trivial": True}, {"size": 10}, {"size": 1}, {"size": 7}):
+        ta, aa = batch.encode_all_splits(n, **kw)
+        want, _ = batch.score_encoded(dev, ta, aa, _lib.SP_METHOD_SUBFLATTENING)
+        assert np.array_equal(sp.score_all_splits(dev, method=sp.Method.subflattening, **kw), want), kw
     M = O.moment_matrix(keys, counts, n)
     for i in range(0, len(splits), 17):
         oa = [names.index(t) for t in splits[i][0]]
