@@ -1134,3 +1134,28 @@ def test_flattening_scores_20_taxa(sp):
         m = np.zeros((len(ur), len(uc)))
         np.add.at(m, (ri, ci), counts.astype(np.float64))
         assert abs(O.dense_split_score(m) - got_l[i]) <= SCORE_TOL, (i, m.shape)
+
+
+def test_score_all_splits_matches_host_enumeration(sp):
+    """sp_score_all_splits (splits un-ranked on the device) against the host enumeration of all_splits, every taxon count
+    from 2 to 13 and every option; count-only call; methods other than subflattening are refused."""
+    from splitp_amd import batch, _lib
+    import ctypes as C
+
+    rng = np.random.default_rng(21)
+    for n in range(2, 14):
+        keys, counts = _copy_mutate_table(rng, n, 3000, 4)
+        names = taxa_names(n)
+        dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=int(counts.sum()), taxa=names)
+        for kw in ({}, {"trivial": True}, {"size": max(1, n // 2)}, {"size": 1}):
+            ta, aa = batch.encode_all_splits(n, **kw)
+            got, st = sp.score_all_splits(dev, method=sp.Method.subflattening, return_status=True, **kw)
+            assert len(got) == len(aa) == len(list(sp.all_splits(names, **kw))), (n, kw)
+            if len(aa):
+                want, _ = batch.score_encoded(dev, ta, aa, _lib.SP_METHOD_SUBFLATTENING)
+                assert np.array_equal(got, want, equal_nan=True) and not np.any(st & 3), (n, kw)
+        cnt = C.c_int64()
+        _lib.check(dev.ctx._lib.sp_score_all_splits(dev.handle, _lib.SP_METHOD_SUBFLATTENING, 0, 0, C.byref(cnt), None, None, None))
+        assert cnt.value == len(list(sp.all_splits(names)))
+    with pytest.raises(ValueError):
+        _lib.check(dev.ctx._lib.sp_score_all_splits(dev.handle, _lib.SP_METHOD_FLATTENING, 0, 0, C.byref(cnt), None, None, None))
