@@ -57,7 +57,7 @@ def _score_big_sparse(ri, ci, v, shape):
     with 4^a >= rows, 4^b >= cols is a table of a + b "taxa" whose flattening for the split (first a | last b) IS the
     matrix - and scored by the batched sparse route: the list kernels for count-derived values (value = count / N, as
     every table from an alignment has) up to 65535 cells, its big-table form for more cells or arbitrary non-negative
-    values.  Needs a + b <= 16; otherwise None (the caller's dense route then reports the limit)."""
+    values.  Needs a + b <= 31 (more than 16: big-table form only); otherwise None (the caller's dense route then reports the limit)."""
     from .batch import score_encoded
     from .device import DeviceAlignment, infer_counts
 
@@ -66,7 +66,7 @@ def _score_big_sparse(ri, ci, v, shape):
         return None
     a = max(1, (max(rows - 1, 1).bit_length() + 1) // 2)
     b = max(1, (max(cols - 1, 1).bit_length() + 1) // 2)
-    if a + b > 16:
+    if a + b > 31:                                   # (the packed key row * 4^b + col has to fit 62 bits)
         return None
     keys = ri.astype(np.uint64) * np.uint64(4 ** b) + ci.astype(np.uint64)
     order = np.argsort(keys, kind="stable")
