@@ -716,7 +716,7 @@ __device__ __forceinline__ void spk_wide_apply(double* X, int rows, int cs, cons
 // Ritz values of the operator's Gram form on span(X_in).  Out: sum of the 4 largest (top4), the 4th largest (th4), the
 // sum of all 8 (sum8).  X becomes orthonormal (dead directions - eigenvalue <= 1e-24 of the largest - become zero columns).
 __device__ __forceinline__ void spk_wide_ritz_orth(double* X, int rows, int cs, EigShared& esh, double& top4, double& th4,
-                                                   double& sum8) {
+                                                   double& sum8, double* th5_out = nullptr) {
     spk_wide_gram(X, rows, cs, esh);
     jacobi_nb<SPK_WB>(esh);
     double th[SPK_WB];
@@ -729,6 +729,7 @@ __device__ __forceinline__ void spk_wide_ritz_orth(double* X, int rows, int cs, 
     sum8 = 0;
     top4 = 0;
     th4 = 0;
+    double th5 = 0;
 #pragma unroll
     for (int k = 0; k < SPK_WB; ++k) {
         int rank = 0;
@@ -737,7 +738,9 @@ __device__ __forceinline__ void spk_wide_ritz_orth(double* X, int rows, int cs, 
         sum8 += th[k];
         if (rank < 4) top4 += th[k];
         if (rank == 3) th4 = th[k];
+        if (rank == 4) th5 = th[k];
     }
+    if (th5_out) *th5_out = th5;
     if (threadIdx.x < SPK_WB * SPK_WB) {
         const int i = threadIdx.x / SPK_WB, j = threadIdx.x % SPK_WB;
         const double rj = (esh.theta[j] > 1e-24 * tmax && esh.theta[j] > 0) ? 1.0 / sqrt(esh.theta[j]) : 0.0;
@@ -769,9 +772,16 @@ __device__ __forceinline__ void spk_wide_ritz_orth(double* X, int rows, int cs, 
 // Stop rule of the wide block.  The slowest error component decays by lambda_9 / lambda_4 <= (trace - sum8) / th4 per half
 // product; where that bound is useful (< 0.9) it certifies the score to 5e-11 as in spk_converged, otherwise (heavy
 // tails: thousands of small eigenvalues outweigh lambda_4) the two-ratio estimate has to meet a ten times tighter tolerance.
+// The sum of the four largest Ritz values is not smooth: when the block's 4th vector is (almost exactly) the 5th
+// eigenvector of a close pair lambda_4 ~ lambda_5 - which is what the 4-wide phase hands over after a stall - the sum
+// sits on a plateau while the direction of lambda_4 is still growing out of the guard columns as the 5th Ritz value, and
+// jumps only when that value overtakes the 4th (found by the randomised tests: 1.9e-8 in a score).  So the 5th Ritz value
+// must be out of reach: either it has settled, or even four more steps of its current growth leave it below the 4th.
 __device__ __forceinline__ bool spk_wide_converged(double s4, double th4, double sum8, double trace, int k, double& prev_sum,
-                                                   double& prev_delta, double& prev_ratio) {
+                                                   double& prev_delta, double& prev_ratio, double th5, double& prev_th5) {
     bool conv = false;
+    const double d5 = fabs(th5 - prev_th5);
+    prev_th5 = th5;
     const double delta = fabs(s4 - prev_sum);
     double ratio = 1.0;
     if (k >= 3) {
@@ -790,6 +800,8 @@ __device__ __forceinline__ bool spk_wide_converged(double s4, double th4, double
             } else {
                 conv = k >= 6 && (delta <= 0.1 * tol || tail <= 0.1 * tol);
             }
+            const bool fifth_out_of_reach = d5 <= tol || th5 + 4.0 * d5 < th4;
+            conv = conv && fifth_out_of_reach;
         }
     }
     prev_ratio = ratio;
@@ -1230,7 +1242,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     // been formed (no eigen-decomposition, no polar factor).  Small row side: dense G instead of the two sparse halves.
     // Start: unit vectors on the 4 rows picked above.  General path: C^T of unit vectors is just those 4 rows of C, so
     // the first half product is a scatter of 4 CSR rows into W (plus 1 % hash noise for the directions they miss).
-    double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0;
+    double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0, prev_th5 = 0;
     int it = 0, conv = 0;
     if (small) {
         for (int i = threadIdx.x; i < R; i += SPK_THREADS) {
@@ -1332,8 +1344,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
                          ics, X + (size_t)cb * xcs, xrs, xcs, it == 3 ? 20 : -1);
             if (wide_on) {
                 double th4, sum8;
-                spk_wide_ritz_orth(X, rows, xcs, esh, top4, th4, sum8);
-                if (spk_wide_converged(top4, th4, sum8, trace, it - 1, prev_sum, prev_delta, prev_ratio)) {
+                double th5;
+                spk_wide_ritz_orth(X, rows, xcs, esh, top4, th4, sum8, &th5);
+                if (spk_wide_converged(top4, th4, sum8, trace, it - 1, prev_sum, prev_delta, prev_ratio, th5, prev_th5)) {
                     conv = 1;
                     break;
                 }
@@ -1756,7 +1769,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
         spk_gram(V, R, 4, 1, sh);
         spk_chol_factor(sh, false);
         spk_orth(V, R, 4, 1, sh);
-        double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0;
+        double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0, prev_th5 = 0;
         int it = 0, conv = 0;
         for (it = 1; it <= SPKB_MAXHALF; ++it) {
             const bool odd = it & 1;   // odd: W = C^T V (column order)   even: V = C W (row order)
@@ -1800,8 +1813,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
                     else
                         spkb_product<CT, false>(keyr, minr, cntr, D, W8 + (size_t)cb * Wp, Wp, V8 + (size_t)cb * Vp, Vp, R, pt);
                 }
-                spk_wide_ritz_orth(X, rows, xcs, esh, top4, th4, sum8);
-                if (spk_wide_converged(top4, th4, sum8, trace, wit, prev_sum, prev_delta, prev_ratio)) {
+                double th5;
+                spk_wide_ritz_orth(X, rows, xcs, esh, top4, th4, sum8, &th5);
+                if (spk_wide_converged(top4, th4, sum8, trace, wit, prev_sum, prev_delta, prev_ratio, th5, prev_th5)) {
                     conv = 1;
                     break;
                 }
