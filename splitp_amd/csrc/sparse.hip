@@ -1062,10 +1062,19 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     // every wave gets its own row when that fits (shorter chunks per lane), else the first SPK_SORT_WAVES waves sort
     const size_t cw_c1 = (size_t)((Kc + (bits8 ? 3 : 1)) / (bits8 ? 4 : 2)) * 4, cw_r1 = (size_t)((R + 1) / 2) * 4;
     const size_t grp_r_probe = small ? 0 : (((size_t)R + 1) * 2 + 15) & ~(size_t)15;
-    const int ns_c = build_end + SPK_WAVES * cw_c1 <= top ? SPK_WAVES : SPK_SORT_WAVES;
-    const int ns_r = build_end + SPK_WAVES * cw_r1 + grp_r_probe + 16 <= top ? SPK_WAVES : SPK_SORT_WAVES;
-    const size_t cw_c = (size_t)ns_c * cw_c1;
-    const size_t cw_r = small ? 0 : (size_t)ns_r * cw_r1;
+    // All-global form: the sort counters - the only words of the build that take an atomic per entry - go to the
+    // otherwise idle LDS when at least 4 wave rows fit (global atomics made the two list builds 78 % of a 4|8 split of
+    // the 12-taxon table).
+    const size_t lds_used = ((sizeof(SpkShared) + 15) & ~(size_t)15) + sizeof(EigShared) + 32;
+    const size_t lds_free = HBM ? (size_t)SPK_LDS_BYTES - lds_used : 0;
+    const int ns_c_lds = HBM ? (int)min((size_t)SPK_WAVES, lds_free / max(cw_c1, (size_t)4)) : 0;
+    const int ns_r_lds = (HBM && !small) ? (int)min((size_t)SPK_WAVES, lds_free / max(cw_r1, (size_t)4)) : 0;
+    const bool cwc_lds = ns_c_lds >= 4, cwr_lds = ns_r_lds >= 4;
+    const int ns_c = cwc_lds ? ns_c_lds : (build_end + SPK_WAVES * cw_c1 <= top ? SPK_WAVES : SPK_SORT_WAVES);
+    const int ns_r = cwr_lds ? ns_r_lds
+                             : (build_end + SPK_WAVES * cw_r1 + grp_r_probe + 16 <= top ? SPK_WAVES : SPK_SORT_WAVES);
+    const size_t cw_c = cwc_lds ? 0 : (size_t)ns_c * cw_c1;                  // bytes taken behind the staging arrays
+    const size_t cw_r = (small || cwr_lds) ? 0 : (size_t)ns_r * cw_r1;
     // build-time start of every group (general path): columns - in the not yet written CSR list; rows - right behind
     // the row counters
     const size_t grp_r_bytes = small ? 0 : (((size_t)R + 1) * 2 + 15) & ~(size_t)15;
@@ -1080,7 +1089,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         }
         return;
     }
-    u32* cwbuf = reinterpret_cast<u32*>(base + build_end);
+    u32* const cw_lds = reinterpret_cast<u32*>(smem + lds_used);
+    u32* cwbuf = cwc_lds ? cw_lds : reinterpret_cast<u32*>(base + build_end);
+    u32* cwbuf_r = cwr_lds ? cw_lds : reinterpret_cast<u32*>(base + build_end);
     unsigned short* grp_c = grp_c_in_csr ? reinterpret_cast<unsigned short*>(csr_ent)
                                          : reinterpret_cast<unsigned short*>(base + ((build_end + cw_c + 15) & ~(size_t)15));
     unsigned short* grp_r = reinterpret_cast<unsigned short*>(base + ((build_end + cw_r + 15) & ~(size_t)15));
@@ -1093,7 +1104,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
     SSTAMP(2);
     if (!small)
         spk_build_list<false, 16, true>(pc, cnt, Di, R, grp_r, desc_r, csr_ent, perm_r, &sh.nw_r, &sh.nr_r, &sh.nq_r, &sh.used_r,
-                                        cwbuf, ns_r, sh);
+                                        cwbuf_r, ns_r, sh);
     SSTAMP(3);
     // ids in use on raw sides (small path: the used rows are the non-zero diagonal entries of G, checked below)
     if (degenerate(small ? 5 : sh.used_r, sh.used_c)) return;
@@ -1505,7 +1516,15 @@ int launch_sparse_score_hbm(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, cons
     if (S_sub == 0) return SP_OK;
     if (ctx->upload_ev) SP_HIP(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
     PhaseScope ps(ctx, SP_PHASE_SPARSE);
-    const size_t lds = ((sizeof(SpkShared) + 31) & ~(size_t)15) + sizeof(EigShared) + 16;
+    const size_t lds = SPK_LDS_BYTES;   // SpkShared + the Jacobi workspace of the wide block + the sort counters
+    static bool attr_h = false;
+    if (!attr_h) {
+        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_score<true, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_BYTES));
+        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_score<true, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_BYTES));
+        attr_h = true;
+    }
     if (wide)
         hipLaunchKernelGGL((k_sparse_score<true, true>), dim3((unsigned)S_sub), dim3(SPK_THREADS), lds, ctx->stream, als_dev,
                            1, n_taxa, splits_dev, order_dev, (int)S, scores, status, slabs, slab_bytes);
