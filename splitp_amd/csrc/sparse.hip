@@ -1676,6 +1676,8 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
     SpkbPart& pt = *reinterpret_cast<SpkbPart*>(smem_b + ((sizeof(SpkShared) + 15) & ~(size_t)15));
     EigShared& esh = *reinterpret_cast<EigShared*>(smem_b + ((sizeof(SpkShared) + 15) & ~(size_t)15) +
                                                    ((sizeof(SpkbPart) + 15) & ~(size_t)15));
+    const size_t lds_used_b = ((sizeof(SpkShared) + 15) & ~(size_t)15) + ((sizeof(SpkbPart) + 15) & ~(size_t)15) +
+                              ((sizeof(EigShared) + 15) & ~(size_t)15) + 16;
     const int D = (int)D64;
     double* slab = slabs + (size_t)blockIdx.x * slab_doubles;
     // trace = sum count^2 (exact in u64 for counts) and the 4 heaviest patterns, once per workgroup
@@ -1762,8 +1764,15 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
         // slab: row-major 4-wide V and W ([row][4]) for the normal iteration, then the column-major 8-column blocks of
         // the wide fallback
         const size_t dpad16 = (size_t)D + 16;
-        double* V = slab;
-        double* W = slab + 4 * dpad16;
+        // a block of up to ~2100 rows lives in the free LDS instead (V first, W if it still fits): the product that
+        // gathers from it then stays off the L2, which is what bounds this kernel (most splits have one short side)
+        double* const lds_blk = reinterpret_cast<double*>(smem_b + lds_used_b);
+        const size_t lds_free_d = ((size_t)SPK_LDS_BYTES - lds_used_b) / 8;
+        const size_t v_need = (size_t)4 * ((size_t)R + 4), w_need = (size_t)4 * ((size_t)C + 4);
+        const bool v_lds = v_need <= lds_free_d;
+        const bool w_lds = w_need <= lds_free_d - (v_lds ? v_need : 0);
+        double* V = v_lds ? lds_blk : slab;
+        double* W = w_lds ? lds_blk + (v_lds ? v_need : 0) : slab + 4 * dpad16;
         double* V8 = slab + 8 * dpad16;
         double* W8 = V8 + (size_t)SPK_WB * Vp;
         // start block: unit vectors on the rows of the 4 most frequent patterns + hash noise, orthonormalised
@@ -1883,7 +1892,7 @@ static int big_run_kernel(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, cons
                        kci.as<u32>(), minc.as<u32>(), cntc.as<CT>());   // column order: the minor index is the row
     hipLaunchKernelGGL(k_gather_sorted<CT>, gg, dim3(256), 0, ctx->stream, keyr, permr, cc, counts, D, (int64_t)padded,
                        kri.as<u32>(), minr.as<u32>(), cntr.as<CT>());   // row order: the minor index is the column
-    const size_t lds = ((sizeof(SpkShared) + 15) & ~(size_t)15) + ((sizeof(SpkbPart) + 15) & ~(size_t)15) + sizeof(EigShared) + 16;
+    const size_t lds = SPK_LDS_BYTES;   // shared structs + one or both 4-wide blocks of short sides
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_big<CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
         sp_set_error("big-table form: cannot reserve %zu bytes of LDS", lds);
