@@ -148,7 +148,7 @@ def main():
 
     # (more lanes with RCCL: the all-gather adds latency to every step, not work.  5, not 4: with 4 lane streams next to
     # RCCL's the step time is 10 % worse than with 3 or 5 - 0.119 vs 0.108 ms under torch.distributed.run on one GPU - two
-    # of the streams apparently end up sharing a hardware queue)
+    # of the streams apparently end up sharing a hardware queue; without RCCL the bad count is 5: 0.122 vs 0.104 ms)
     lanes = [Lane() for _ in range(args.lanes if args.lanes > 0 else (5 if world > 1 else 3))]
 
     # argument objects of the library calls are built once (the step loop is host-work sensitive: ~50 us of Python per
