@@ -48,10 +48,11 @@ extern "C" {
 #define SP_ELIMIT 4   /* size outside what this build supports (see message) */
 #define SP_ENOCONV 5  /* eigen iteration did not converge (score still written, flagged) */
 
-#define SP_ABI_VERSION 1
+#define SP_ABI_VERSION 2
 
 typedef struct sp_ctx sp_ctx;             /* device + stream + workspace arena */
 typedef struct sp_alignment sp_alignment; /* device-resident pattern table */
+typedef struct sp_plan sp_plan;           /* immutable, reference-counted candidate-split list on the device */
 
 /* ---------------------------------------------------------------- context ---------- */
 int sp_abi_version(void);
@@ -64,11 +65,13 @@ int sp_device_count(void);
 int sp_ctx_create(int device, void* stream, sp_ctx** out);
 int sp_ctx_destroy(sp_ctx* ctx);
 int sp_ctx_set_stream(sp_ctx* ctx, void* stream);
-/* Retarget the context to another stream WITHOUT draining or ordering against the previous one ("lanes": several
- * scoring steps in flight on different streams).  Safe only between sp_score_splits_async / _multi_async calls whose
- * split list is unchanged: those read the cached plan and write only the caller's buffers. */
-int sp_ctx_set_stream_unordered(sp_ctx* ctx, void* hip_stream);
 int sp_ctx_synchronize(sp_ctx* ctx);
+/* Test / tuning switches (they select between kernels that must agree - never a CPU path).  Defaults are read from the
+ * environment once, at sp_ctx_create (SPLITP_<NAME IN CAPITALS>, SPLITP_DEBUG_LDS_CAP for "lds_cap").  Names:
+ *   "force_big" 0/1, "big_by_keys" 0/1, "subscore_jacobi" 0/1, "divergence_global" 0/1, "hist_sort" -1 auto / 0 / 1,
+ *   "lds_cap" bytes (0 = off), "wide_cap" half products of the sparse route's last resort (0 = built-in 600). */
+int sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value);
+int sp_ctx_get_option(sp_ctx* ctx, const char* name, int64_t* value);
 /* Gram-kernel selection of the dense flattening route: 0 = auto (exact integer Gram on the int8 matrix
  * cores, count limbs of 7 bits, when the alignment holds counts < 128^3; fp64 MFMA otherwise),
  * 1 = always the fp64 MFMA kernel.  Both give bit-identical Gram matrices for integer counts. */
@@ -88,7 +91,8 @@ int sp_ctx_set_gram_mode(sp_ctx* ctx, int mode);
 #define SP_PHASE_DENSE 7    /* full 4^a x 4^b dense scatter (sp_flatten_dense)             */
 #define SP_PHASE_SPARSE 8   /* sparse route: one workgroup per split, everything in LDS     */
 #define SP_PHASE_DIVERGENCE 9 /* mutual-information score (marginals + sum over the patterns)  */
-#define SP_N_PHASES 10
+#define SP_PHASE_CHAIN 10   /* sparse route: the hand-back kernel queued behind the in-LDS kernel (k_sparse_slow) */
+#define SP_N_PHASES 11
 int sp_ctx_enable_timing(sp_ctx* ctx, int on);
 int sp_ctx_reset_timing(sp_ctx* ctx);
 int sp_ctx_phase_times(sp_ctx* ctx, double* ms /*[SP_N_PHASES]*/, int64_t* launches /*[SP_N_PHASES]*/);
@@ -209,18 +213,41 @@ int sp_score_all_splits(sp_alignment* al, int method, int trivial, int size, int
 /* Asynchronous form for pipelines that keep everything on the device (benchmark loop, multi-GPU all-gather):
  * enqueues the scoring of the splits on the context's stream and returns without any host synchronisation.
  *   scores_dev[n_splits] (double) and status_dev[n_splits] (int32) are device buffers written by the kernels.
- * No hand-back is performed: with SP_METHOD_FLATTENING / _SPARSE a split the in-LDS kernel cannot take has
- * status bit 1 set (score: undefined if the status is exactly 2, an uncertified upper estimate otherwise) - the
- * caller re-scores those with the synchronous sp_score_splits(SP_METHOD_FLATTENING) after its own synchronisation
- * (splitp_amd/batch.py finish_async does). */
+ * With SP_METHOD_FLATTENING / _SPARSE on a table the sparse route takes, this is sp_score_plan_async on an internally
+ * cached plan: the hand-back chain runs on the device and every score is final (status as described there).  Other
+ * methods and tables run their synchronous route with device outputs. */
 int sp_score_splits_async(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
                           int method, void* scores_dev, void* status_dev);
 
 /* Several alignments (same taxa, same candidate-split list - e.g. the replicates of a simulation study, BASELINE
- * config 5) in ONE launch of the in-LDS kernel; asynchronous like sp_score_splits_async.  scores_dev / status_dev
- * hold n_al * n_splits entries, alignment-major. */
+ * config 5) in ONE device pass; asynchronous like sp_score_splits_async.  scores_dev / status_dev hold
+ * n_al * n_splits entries, alignment-major. */
 int sp_score_splits_multi_async(sp_alignment* const* als, int n_al, const int32_t* split_taxa, const int32_t* split_a,
                                 int64_t n_splits, void* scores_dev, void* status_dev);
+
+/* ---------------------------------------------------------------- plans and lanes --- */
+/* A candidate-split list as a device object: validated, laid out and uploaded ONCE (synchronously), immutable
+ * afterwards and reference-counted - the loop of README.md:36-41 over many alignments, or the same alignment scored
+ * from several streams, re-uses it without re-planning.  split_taxa / split_a as for sp_score_splits; sides of at
+ * most 14 taxa.  The creator holds one reference; sp_plan_release drops one and frees the plan with the last. */
+int sp_plan_create(sp_ctx* ctx, int n_taxa, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
+                   sp_plan** out);
+int sp_plan_retain(sp_plan* plan);
+int sp_plan_release(sp_plan* plan);
+int sp_plan_info(const sp_plan* plan, int* n_taxa, int64_t* n_splits);
+
+/* Flattening + split score of every split of `plan` for each of the n_al alignments (count tables of the plan's taxa,
+ * at most 65535 table rows, at most 16 taxa: the sparse route), enqueued on the stream of `lane` with NO host
+ * synchronisation.  `lane` is any context of the alignments' device - it supplies the stream and the work memory, so
+ * several lanes (one context per HIP stream) keep several calls in flight; plan and alignments are only read.
+ * The whole hand-back chain runs on the device: behind the in-LDS kernel a second kernel of persistent workgroups
+ * picks - from the status words the first one left - the splits that did not fit (re-run in the lists-in-global form,
+ * then the all-global form) and those whose 4-wide block found no certified spectral gap (8-wide block).  On completion
+ * of the stream work every score is final: status bit 0 = the last resort hit its iteration cap (score = upper
+ * estimate), bits 8.. = operator applications, bit 1 never set.  scores_dev / status_dev: n_al * n_splits entries,
+ * alignment-major.  The first call for an alignment prepares its split-independent metadata (synchronously, once). */
+int sp_score_plan_async(sp_ctx* lane, sp_alignment* const* als, int n_al, sp_plan* plan, void* scores_dev,
+                        void* status_dev);
 
 #ifdef __cplusplus
 }

@@ -17,13 +17,16 @@ SP_METHOD_SUBFLATTENING = 1
 SP_METHOD_FLATTENING_DENSE = 2
 SP_METHOD_FLATTENING_SPARSE = 3
 SP_METHOD_MUTUAL_INFORMATION = 4
-SP_N_PHASES = 10
-PHASE_NAMES = ("reindex", "scatter", "gram", "eigen", "moment", "subscore", "hist", "dense", "sparse", "divergence")
+SP_N_PHASES = 11
+PHASE_NAMES = ("reindex", "scatter", "gram", "eigen", "moment", "subscore", "hist", "dense", "sparse", "divergence", "chain")
+SP_OK, SP_EINVAL, SP_EHIP, SP_ENOMEM, SP_ELIMIT, SP_ENOCONV = 0, 1, 2, 3, 4, 5
+SP_ABI_VERSION = 2
 
 # every symbol include/splitp_hip.h declares
 SYMBOLS = (
     "sp_abi_version", "sp_last_error", "sp_device_count",
-    "sp_ctx_create", "sp_ctx_destroy", "sp_ctx_set_stream", "sp_ctx_set_stream_unordered", "sp_ctx_synchronize", "sp_ctx_set_gram_mode",
+    "sp_ctx_create", "sp_ctx_destroy", "sp_ctx_set_stream", "sp_ctx_synchronize", "sp_ctx_set_gram_mode",
+    "sp_ctx_set_option", "sp_ctx_get_option",
     "sp_ctx_enable_timing", "sp_ctx_reset_timing", "sp_ctx_phase_times",
     "sp_alignment_create", "sp_alignment_from_sequences", "sp_alignment_from_site_keys", "sp_simulate_alignment",
     "sp_alignment_destroy", "sp_alignment_info", "sp_alignment_fetch",
@@ -31,6 +34,7 @@ SYMBOLS = (
     "sp_subflatten", "sp_moment_matrix",
     "sp_score_matrix_f64", "sp_score_coo_f64", "sp_divergence_matrix_f64", "sp_score_splits", "sp_score_splits_async",
     "sp_score_splits_multi_async", "sp_score_all_splits",
+    "sp_plan_create", "sp_plan_retain", "sp_plan_release", "sp_plan_info", "sp_score_plan_async",
 )
 
 
@@ -71,7 +75,8 @@ def load():
         "sp_ctx_create": [i32, vp, P(vp)],
         "sp_ctx_destroy": [vp],
         "sp_ctx_set_stream": [vp, vp],
-        "sp_ctx_set_stream_unordered": [vp, vp],
+        "sp_ctx_set_option": [vp, C.c_char_p, i64],
+        "sp_ctx_get_option": [vp, C.c_char_p, P(i64)],
         "sp_ctx_synchronize": [vp],
         "sp_ctx_set_gram_mode": [vp, i32],
         "sp_ctx_enable_timing": [vp, i32],
@@ -97,6 +102,11 @@ def load():
         "sp_score_splits_async": [vp, P(C.c_int32), P(C.c_int32), i64, i32, vp, vp],
         "sp_score_splits_multi_async": [P(vp), i32, P(C.c_int32), P(C.c_int32), i64, vp, vp],
         "sp_score_all_splits": [vp, i32, i32, i32, P(i64), P(dbl), vp, P(C.c_int32)],
+        "sp_plan_create": [vp, i32, P(C.c_int32), P(C.c_int32), i64, P(vp)],
+        "sp_plan_retain": [vp],
+        "sp_plan_release": [vp],
+        "sp_plan_info": [vp, P(i32), P(i64)],
+        "sp_score_plan_async": [vp, P(vp), i32, vp, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -106,11 +116,16 @@ def load():
     return lib
 
 
-def check(status):
+def check(status, allow_noconv=False):
+    """Raise for a non-zero status.  allow_noconv: SP_ENOCONV (scores written, some flagged as upper estimates) is
+    returned to the caller instead, who warns with the per-split status words in hand."""
+    if status == SP_ENOCONV and allow_noconv:
+        return status
     if status != 0:
         msg = load().sp_last_error().decode(errors="replace")
         codes = {1: ValueError, 4: NotImplementedError}
         raise codes.get(status, SplitPDeviceError)(f"libsplitp_hip: {msg} (status {status})")
+    return 0
 
 
 def device_count():

@@ -117,9 +117,22 @@ def _method_code(method, route="auto"):
     raise ValueError(f"unsupported method {method!r} (flattening, subflattening or mutual_information)")
 
 
+def warn_unconverged(status, stacklevel=3):
+    """RuntimeWarning when any status word carries bit 0 (the C ABI's SP_ENOCONV: score written, upper estimate)."""
+    status = np.asarray(status)
+    bad = int(np.count_nonzero(status & 1))
+    if bad:
+        import warnings
+
+        warnings.warn(f"{bad} of {status.size} splits hit the iteration cap of their eigen-solver: "
+                      "their scores are upper estimates (status bit 0)", RuntimeWarning, stacklevel=stacklevel)
+    return bad
+
+
 def score_encoded(al, split_taxa, split_a, method_code, scores_dev_ptr=None, want_host=True):
     """Score already-encoded splits on this process's GPU.  Returns (scores, status) host arrays
-    when want_host, else enqueues only (scores land in scores_dev_ptr)."""
+    when want_host, else enqueues only (scores land in scores_dev_ptr).  The library reports unconverged splits
+    with SP_ENOCONV (scores still written): that becomes a RuntimeWarning here, the status words say which."""
     n = len(split_a)
     split_taxa = np.ascontiguousarray(split_taxa, dtype=np.int32)
     split_a = np.ascontiguousarray(split_a, dtype=np.int32)
@@ -128,19 +141,47 @@ def score_encoded(al, split_taxa, split_a, method_code, scores_dev_ptr=None, wan
     _lib.check(al.ctx._lib.sp_score_splits(
         al.handle, _lib._ptr(split_taxa, C.c_int32), _lib._ptr(split_a, C.c_int32), n, method_code,
         _lib._ptr(scores, C.c_double), C.c_void_p(scores_dev_ptr) if scores_dev_ptr else None,
-        _lib._ptr(status, C.c_int32)))
-    if want_host and np.any(status & 1):
-        import warnings
-
-        warnings.warn(f"{int(np.sum((status & 1) != 0))} of {n} splits hit the iteration cap of their eigen-solver: "
-                      "their scores are upper estimates (status bit 0)", RuntimeWarning, stacklevel=2)
+        _lib._ptr(status, C.c_int32)), allow_noconv=True)
+    if want_host:
+        warn_unconverged(status)
     return scores, status
 
 
+class SplitPlan:
+    """A candidate-split list as an immutable device object (sp_plan): planned and uploaded once, shared read-only by
+    any number of contexts (lanes) and alignments of the device."""
+
+    def __init__(self, ctx, split_taxa, split_a, n_taxa):
+        import weakref
+
+        self.split_taxa = np.ascontiguousarray(split_taxa, dtype=np.int32)
+        self.split_a = np.ascontiguousarray(split_a, dtype=np.int32)
+        self.n_taxa = int(n_taxa)
+        self.n_splits = len(self.split_a)
+        self.handle = C.c_void_p()
+        lib = ctx._lib
+        _lib.check(lib.sp_plan_create(ctx.handle, self.n_taxa, _lib._ptr(self.split_taxa, C.c_int32),
+                                      _lib._ptr(self.split_a, C.c_int32), self.n_splits, C.byref(self.handle)))
+        self._fin = weakref.finalize(self, lib.sp_plan_release, self.handle)
+
+    @classmethod
+    def from_splits(cls, splits, table):
+        al = as_device_alignment(table)
+        taxa_arr, a_arr = encode_splits(list(splits), table, al.n_taxa)
+        return cls(al.ctx, taxa_arr, a_arr, al.n_taxa)
+
+
+def score_plan_async(lane_ctx, als, plan, scores_dev_ptr, status_dev_ptr, _handles=None):
+    """sp_score_plan_async: every split of `plan` for each alignment in `als`, enqueued on the lane's stream, complete on
+    the device (hand-back chain included); results alignment-major in the given device buffers."""
+    arr = _handles if _handles is not None else (C.c_void_p * len(als))(*[a.handle.value for a in als])
+    _lib.check(lane_ctx._lib.sp_score_plan_async(lane_ctx.handle, arr, len(als), plan.handle,
+                                                 C.c_void_p(scores_dev_ptr), C.c_void_p(status_dev_ptr)))
+
+
 def score_encoded_async(al, split_taxa, split_a, method_code, scores_dev_ptr, status_dev_ptr):
-    """Enqueue only (no host synchronisation, no hand-back): scores and status land in the given device buffers.
-    Callers check `status & 2` after their own sync and re-score those splits with the dense route
-    (`finish_async`)."""
+    """Enqueue only (no host synchronisation): scores and status land in the given device buffers.  On the sparse
+    route the hand-back chain runs on the device, so the results are final once the stream has run."""
     split_taxa = np.ascontiguousarray(split_taxa, dtype=np.int32)
     split_a = np.ascontiguousarray(split_a, dtype=np.int32)
     _lib.check(al.ctx._lib.sp_score_splits_async(
@@ -149,7 +190,7 @@ def score_encoded_async(al, split_taxa, split_a, method_code, scores_dev_ptr, st
 
 
 def score_encoded_multi_async(als, split_taxa, split_a, scores_dev_ptr, status_dev_ptr):
-    """Several alignments (same taxa / split list) in one launch of the in-LDS kernel; results alignment-major."""
+    """Several alignments (same taxa / split list) in one device pass of the sparse route; results alignment-major."""
     split_taxa = np.ascontiguousarray(split_taxa, dtype=np.int32)
     split_a = np.ascontiguousarray(split_a, dtype=np.int32)
     arr = (C.c_void_p * len(als))(*[a.handle.value for a in als])
@@ -159,10 +200,11 @@ def score_encoded_multi_async(als, split_taxa, split_a, scores_dev_ptr, status_d
 
 
 def finish_async(al, split_taxa, split_a, scores_host, status_host):
-    """Hand-back for the asynchronous form: re-score with the synchronous entry point whatever the in-LDS kernel
-    flagged (status bit 1) - it walks the chain LDS form -> global-memory form of the same kernel -> dense route.
-    scores_host / status_host are NumPy views of the fetched results, patched in place."""
-    redo = np.nonzero(np.asarray(status_host) & 2)[0]
+    """Second opinion for the asynchronous form: the device chain leaves no status bit 1 behind, but its last resort (the
+    8-wide block) can hit its cap on gapless spectra (status bit 0: upper estimate).  Such splits are re-scored with the
+    synchronous entry point, whose hand-back also has the dense route's 16-wide block for sides of up to 1024 rows.
+    scores_host / status_host are NumPy views of the fetched results, patched in place; returns how many were redone."""
+    redo = np.nonzero(np.asarray(status_host) & 3)[0]
     if len(redo):
         sc, st = score_encoded(al, split_taxa[redo], split_a[redo], _lib.SP_METHOD_FLATTENING)
         scores_host[redo] = sc
@@ -170,33 +212,48 @@ def finish_async(al, split_taxa, split_a, scores_host, status_host):
     return len(redo)
 
 
-def gather_scores(local_scores, shards, n_total, group=None, device_tensor=None):
+def packed_width(per):
+    """doubles per rank in the exchange buffer: `per` scores, then `per` int32 status words (padded to a double)."""
+    return per + (per + 1) // 2
+
+
+def gather_scores(local_scores, shards, n_total, group=None, device_tensor=None, local_status=None,
+                  return_status=False):
     """All-gather the per-rank score shards and un-permute them into split order.
 
-    local_scores: 1-D array / tensor of this rank's shard (len(shards[rank])).  With the "nccl"
-    backend (RCCL over xGMI) the exchange is one all_gather_into_tensor of ceil(S/P) doubles per
-    rank on the GPU; with "gloo" (CPU tests) the same call on host tensors."""
+    local_scores / local_status: this rank's shard (len(shards[rank])).  ONE collective moves both: each rank sends
+    packed_width(per) doubles - its scores, then its int32 status words - so the un-converged flag (status bit 0)
+    reaches every rank with the scores.  With the "nccl" backend (RCCL over xGMI) that is one all_gather_into_tensor
+    on the GPU (device_tensor = the already packed device buffer); with "gloo" (CPU tests) the same call on host
+    tensors.  Returns scores, or (scores, status) with return_status."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     per = max(len(s) for s in shards)
+    width = packed_width(per)
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     if device_tensor is not None:
         send = device_tensor
     else:
-        send = torch.zeros(per, dtype=torch.float64, device=dev)
-        loc = torch.as_tensor(np.asarray(local_scores, dtype=np.float64))
-        send[: len(shards[rank])] = loc.to(dev)
-    recv = torch.empty(world * per, dtype=torch.float64, device=dev)
+        host = np.zeros(width, dtype=np.float64)
+        mine = len(shards[rank])
+        host[:mine] = np.asarray(local_scores, dtype=np.float64)
+        if local_status is not None:
+            host[per:].view(np.int32)[:mine] = np.asarray(local_status, dtype=np.int32)
+        send = torch.from_numpy(host).to(dev)
+    recv = torch.empty(world * width, dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(recv, send, group=group)
-    allv = recv.cpu().numpy().reshape(world, per)
+    allv = recv.cpu().numpy().reshape(world, width)
     out = np.empty(n_total, dtype=np.float64)
+    status = np.zeros(n_total, dtype=np.int32)
     for r in range(world):
-        out[shards[r]] = allv[r, : len(shards[r])]
-    return out
+        k = len(shards[r])
+        out[shards[r]] = allv[r, :k]
+        status[shards[r]] = allv[r, per:].view(np.int32)[:k]
+    return (out, status) if return_status else out
 
 
 def score_all_splits(pattern_probabilities, method=Method.flattening, route="auto", trivial=False, size=None,
@@ -254,11 +311,17 @@ def score_splits(pattern_probabilities, splits, method=Method.flattening, distri
     mine = shards[rank]
     per = max(len(s) for s in shards)
     if dist.get_backend(group) == "nccl":
-        send = torch.zeros(per, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+        # scores and status of this rank's shard are written by the kernels straight into the packed exchange buffer
+        send = torch.zeros(packed_width(per), dtype=torch.float64,
+                           device=torch.device("cuda", torch.cuda.current_device()))
         if len(mine):
-            score_encoded(al, taxa_arr[mine], a_arr[mine], code, scores_dev_ptr=send.data_ptr(), want_host=False)
-        out = gather_scores(None, shards, len(splits), group=group, device_tensor=send)
+            score_encoded_async(al, taxa_arr[mine], a_arr[mine], code, send.data_ptr(), send.data_ptr() + per * 8)
+        out, status = gather_scores(None, shards, len(splits), group=group, device_tensor=send, return_status=True)
     else:
-        loc, _ = score_encoded(al, taxa_arr[mine], a_arr[mine], code) if len(mine) else (np.zeros(0), None)
-        out = gather_scores(loc, shards, len(splits), group=group)
-    return out
+        if len(mine):
+            loc, loc_st = score_encoded(al, taxa_arr[mine], a_arr[mine], code)
+        else:
+            loc, loc_st = np.zeros(0), np.zeros(0, dtype=np.int32)
+        out, status = gather_scores(loc, shards, len(splits), group=group, local_status=loc_st, return_status=True)
+    warn_unconverged(status)
+    return (out, status) if return_status else out

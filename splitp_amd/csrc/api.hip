@@ -94,6 +94,7 @@ static int drain_timers(sp_ctx* ctx) {
 
 // ------------------------------------------------------------------ context --------------------
 extern "C" int sp_ctx_create(int device, void* stream, sp_ctx** out) {
+    return sp_guard("sp_ctx_create", [&]() -> int {
     SP_REQUIRE(out, SP_EINVAL, "sp_ctx_create: out is NULL");
     int n = sp_device_count();
     SP_REQUIRE(n > 0, SP_EHIP, "sp_ctx_create: no HIP device visible (this library has no CPU fallback)");
@@ -115,13 +116,63 @@ extern "C" int sp_ctx_create(int device, void* stream, sp_ctx** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    // test / tuning switches: the environment is read here, once (later changes: sp_ctx_set_option)
     const char* gm = getenv("SPLITP_GRAM");
     if (gm && strcmp(gm, "f64") == 0) c->gram_mode = 1;
+    auto env_flag = [](const char* name) {
+        const char* v = getenv(name);
+        return v && v[0] && v[0] != '0';
+    };
+    c->opt.force_big = env_flag("SPLITP_FORCE_BIG");
+    c->opt.big_by_keys = env_flag("SPLITP_BIG_BY_KEYS");
+    c->opt.subscore_jacobi = env_flag("SPLITP_SUBSCORE_JACOBI");
+    c->opt.divergence_global = env_flag("SPLITP_DIVERGENCE_GLOBAL");
+    if (const char* hs = getenv("SPLITP_HIST_SORT")) c->opt.hist_sort = hs[0] == '1' ? 1 : (hs[0] == '0' ? 0 : -1);
+    if (const char* lc = getenv("SPLITP_DEBUG_LDS_CAP")) c->opt.lds_cap = atoll(lc);
     *out = c;
     return SP_OK;
+    });
+}
+
+static long long* option_slot(sp_ctx* c, const char* name, int** as_int) {
+    *as_int = nullptr;
+    if (!strcmp(name, "force_big")) *as_int = &c->opt.force_big;
+    else if (!strcmp(name, "big_by_keys")) *as_int = &c->opt.big_by_keys;
+    else if (!strcmp(name, "subscore_jacobi")) *as_int = &c->opt.subscore_jacobi;
+    else if (!strcmp(name, "divergence_global")) *as_int = &c->opt.divergence_global;
+    else if (!strcmp(name, "hist_sort")) *as_int = &c->opt.hist_sort;
+    else if (!strcmp(name, "wide_cap")) *as_int = &c->opt.wide_cap;
+    else if (!strcmp(name, "lds_cap")) return &c->opt.lds_cap;
+    return nullptr;
+}
+
+extern "C" int sp_ctx_set_option(sp_ctx* c, const char* name, int64_t value) {
+    return sp_guard("sp_ctx_set_option", [&]() -> int {
+    SP_REQUIRE(c && name, SP_EINVAL, "sp_ctx_set_option: NULL argument");
+    int* pi = nullptr;
+    long long* pl = option_slot(c, name, &pi);
+    SP_REQUIRE(pi || pl, SP_EINVAL, "sp_ctx_set_option: unknown option '%s'", name);
+    SP_REQUIRE(value >= -1 && value <= ((int64_t)1 << 30), SP_EINVAL, "sp_ctx_set_option: value %lld out of range",
+               (long long)value);
+    if (pi) *pi = (int)value; else *pl = (long long)value;
+    if (c->cache) c->cache->valid = false;
+    return SP_OK;
+    });
+}
+
+extern "C" int sp_ctx_get_option(sp_ctx* c, const char* name, int64_t* value) {
+    return sp_guard("sp_ctx_get_option", [&]() -> int {
+    SP_REQUIRE(c && name && value, SP_EINVAL, "sp_ctx_get_option: NULL argument");
+    int* pi = nullptr;
+    long long* pl = option_slot(c, name, &pi);
+    SP_REQUIRE(pi || pl, SP_EINVAL, "sp_ctx_get_option: unknown option '%s'", name);
+    *value = pi ? (int64_t)*pi : (int64_t)*pl;
+    return SP_OK;
+    });
 }
 
 extern "C" int sp_ctx_destroy(sp_ctx* c) {
+    return sp_guard("sp_ctx_destroy", [&]() -> int {
     if (!c) return SP_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -131,18 +182,20 @@ extern "C" int sp_ctx_destroy(sp_ctx* c) {
             (void)hipEventDestroy(pr.second);
         }
     for (auto e : c->timer.pool) (void)hipEventDestroy(e);
-    if (c->upload_ev) (void)hipEventDestroy(c->upload_ev);
     DevBuf* bufs[] = {&c->splits, &c->bitmaps, &c->coords, &c->dims, &c->mats,  &c->grams,  &c->eigws,
-                      &c->scores, &c->status,  &c->misc,   &c->misc2, &c->gram_items, &c->aldescs, &c->slabs};
+                      &c->scores, &c->status,  &c->misc,   &c->misc2, &c->gram_items, &c->aldescs, &c->slabs, &c->chain};
+    if (c->cache && c->cache->sparse) (void)sp_plan_release(c->cache->sparse);
     delete c->cache;
     for (auto* b : bufs) b->release();
     for (auto& b : c->big) b.release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SP_OK;
+    });
 }
 
 extern "C" int sp_ctx_set_stream(sp_ctx* c, void* stream) {
+    return sp_guard("sp_ctx_set_stream", [&]() -> int {
     SP_REQUIRE(c, SP_EINVAL, "sp_ctx_set_stream: ctx is NULL");
     SP_HIP(hipStreamSynchronize(c->stream));
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -154,42 +207,36 @@ extern "C" int sp_ctx_set_stream(sp_ctx* c, void* stream) {
         c->own_stream = true;
     }
     return SP_OK;
-}
-
-// Lanes: retarget the context WITHOUT draining or ordering against the previous stream.  Only the asynchronous
-// scoring entry points with an unchanged split list are safe to interleave this way - they read the cached plan and
-// write nothing but the caller's buffers (uploads are fenced by ctx->upload_ev).
-extern "C" int sp_ctx_set_stream_unordered(sp_ctx* c, void* stream) {
-    SP_REQUIRE(c && stream, SP_EINVAL, "sp_ctx_set_stream_unordered: NULL argument");
-    if (c->own_stream) {
-        SP_HIP(hipStreamSynchronize(c->stream));
-        (void)hipStreamDestroy(c->stream);
-    }
-    c->stream = reinterpret_cast<hipStream_t>(stream);
-    c->own_stream = false;
-    return SP_OK;
+    });
 }
 
 extern "C" int sp_ctx_set_gram_mode(sp_ctx* c, int mode) {
+    return sp_guard("sp_ctx_set_gram_mode", [&]() -> int {
     SP_REQUIRE(c, SP_EINVAL, "ctx is NULL");
     SP_REQUIRE(mode == 0 || mode == 1, SP_EINVAL, "gram mode must be 0 (auto) or 1 (fp64)");
     c->gram_mode = mode;
     if (c->cache) c->cache->valid = false;
     return SP_OK;
+    });
 }
 
 extern "C" int sp_ctx_synchronize(sp_ctx* c) {
+    return sp_guard("sp_ctx_synchronize", [&]() -> int {
     SP_REQUIRE(c, SP_EINVAL, "sp_ctx_synchronize: ctx is NULL");
     SP_HIP(hipStreamSynchronize(c->stream));
     return SP_OK;
+    });
 }
 
 extern "C" int sp_ctx_enable_timing(sp_ctx* c, int on) {
+    return sp_guard("sp_ctx_enable_timing", [&]() -> int {
     SP_REQUIRE(c, SP_EINVAL, "ctx is NULL");
     c->timing = on != 0;
     return SP_OK;
+    });
 }
 extern "C" int sp_ctx_reset_timing(sp_ctx* c) {
+    return sp_guard("sp_ctx_reset_timing", [&]() -> int {
     SP_REQUIRE(c, SP_EINVAL, "ctx is NULL");
     SP_CHECK(drain_timers(c));
     for (int i = 0; i < SP_N_PHASES; ++i) {
@@ -197,8 +244,10 @@ extern "C" int sp_ctx_reset_timing(sp_ctx* c) {
         c->timer.launches[i] = 0;
     }
     return SP_OK;
+    });
 }
 extern "C" int sp_ctx_phase_times(sp_ctx* c, double* ms, int64_t* launches) {
+    return sp_guard("sp_ctx_phase_times", [&]() -> int {
     SP_REQUIRE(c, SP_EINVAL, "ctx is NULL");
     SP_CHECK(drain_timers(c));
     for (int i = 0; i < SP_N_PHASES; ++i) {
@@ -206,11 +255,13 @@ extern "C" int sp_ctx_phase_times(sp_ctx* c, double* ms, int64_t* launches) {
         if (launches) launches[i] = c->timer.launches[i];
     }
     return SP_OK;
+    });
 }
 
 // ------------------------------------------------------------------ alignment ------------------
 extern "C" int sp_alignment_create(sp_ctx* ctx, const uint64_t* keys, const double* weights, const int64_t* counts,
                                    int64_t D, int n_taxa, int64_t N, sp_alignment** out) {
+    return sp_guard("sp_alignment_create", [&]() -> int {
     SP_REQUIRE(ctx && out, SP_EINVAL, "sp_alignment_create: NULL ctx/out");
     SP_REQUIRE(n_taxa >= 2 && n_taxa <= 32, SP_EINVAL, "n_taxa must be in [2, 32], got %d", n_taxa);
     SP_REQUIRE(D >= 0, SP_EINVAL, "D < 0");
@@ -260,9 +311,11 @@ extern "C" int sp_alignment_create(sp_ctx* ctx, const uint64_t* keys, const doub
     }
     *out = al;
     return SP_OK;
+    });
 }
 
 extern "C" int sp_alignment_destroy(sp_alignment* al) {
+    return sp_guard("sp_alignment_destroy", [&]() -> int {
     if (!al) return SP_OK;
     (void)hipSetDevice(al->ctx->device);
     (void)hipStreamSynchronize(al->ctx->stream);
@@ -271,23 +324,28 @@ extern "C" int sp_alignment_destroy(sp_alignment* al) {
     al->counts.release();
     al->keys32.release();
     al->spk_meta.release();
+    al->aldesc.release();
     al->spk_keys.release();
     al->spk_counts.release();
     al->moments.release();
     delete al;
     return SP_OK;
+    });
 }
 
 extern "C" int sp_alignment_info(const sp_alignment* al, int64_t* D, int* n_taxa, int64_t* N, int* exact) {
+    return sp_guard("sp_alignment_info", [&]() -> int {
     SP_REQUIRE(al, SP_EINVAL, "alignment is NULL");
     if (D) *D = al->D;
     if (n_taxa) *n_taxa = al->n_taxa;
     if (N) *N = al->N;
     if (exact) *exact = al->exact ? 1 : 0;
     return SP_OK;
+    });
 }
 
 extern "C" int sp_alignment_fetch(sp_alignment* al, uint64_t* keys, double* weights, int64_t* counts) {
+    return sp_guard("sp_alignment_fetch", [&]() -> int {
     SP_REQUIRE(al, SP_EINVAL, "alignment is NULL");
     SP_HIP(hipSetDevice(al->ctx->device));
     SP_HIP(hipStreamSynchronize(al->ctx->stream));
@@ -301,6 +359,7 @@ extern "C" int sp_alignment_fetch(sp_alignment* al, uint64_t* keys, double* weig
         for (int64_t i = 0; i < al->D; ++i) counts[i] = c[i];
     }
     return SP_OK;
+    });
 }
 
 // ------------------------------------------------------------------ split validation / planning
@@ -408,6 +467,7 @@ static u32* cc_ptr(sp_ctx* ctx, size_t S, int64_t D) { return ctx->coords.as<u32
 // ------------------------------------------------------------------ flattening API ------------
 extern "C" int sp_flatten_indices(sp_alignment* al, const int32_t* oa, int a, const int32_t* ob, int b, int64_t* rows,
                                   int64_t* cols) {
+    return sp_guard("sp_flatten_indices", [&]() -> int {
     SP_REQUIRE(al && rows && cols, SP_EINVAL, "NULL argument");
     sp_ctx* ctx = al->ctx;
     SP_HIP(hipSetDevice(ctx->device));
@@ -430,10 +490,12 @@ extern "C" int sp_flatten_indices(sp_alignment* al, const int32_t* oa, int a, co
     SP_HIP(hipMemcpyAsync(cols, dcols, al->D * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;
+    });
 }
 
 extern "C" int sp_flatten_reduced_prepare(sp_alignment* al, const int32_t* oa, int a, const int32_t* ob, int b,
                                           int64_t* R, int64_t* C) {
+    return sp_guard("sp_flatten_reduced_prepare", [&]() -> int {
     SP_REQUIRE(al && R && C, SP_EINVAL, "NULL argument");
     sp_ctx* ctx = al->ctx;
     SP_HIP(hipSetDevice(ctx->device));
@@ -461,6 +523,7 @@ extern "C" int sp_flatten_reduced_prepare(sp_alignment* al, const int32_t* oa, i
     *C = al->red_C = d.y;
     al->red_ready = true;
     return SP_OK;
+    });
 }
 
 __global__ void k_scatter_exact_shape(int64_t D, const u32* __restrict__ rr, const u32* __restrict__ cc,
@@ -470,6 +533,7 @@ __global__ void k_scatter_exact_shape(int64_t D, const u32* __restrict__ rr, con
 }
 
 extern "C" int sp_flatten_reduced_fetch(sp_alignment* al, double* matrix, int64_t* row_keys, int64_t* col_keys) {
+    return sp_guard("sp_flatten_reduced_fetch", [&]() -> int {
     SP_REQUIRE(al && al->red_ready, SP_EINVAL, "sp_flatten_reduced_fetch without a preceding _prepare");
     sp_ctx* ctx = al->ctx;
     SP_HIP(hipSetDevice(ctx->device));
@@ -496,10 +560,12 @@ extern "C" int sp_flatten_reduced_fetch(sp_alignment* al, double* matrix, int64_
     }
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;
+    });
 }
 
 extern "C" int sp_flatten_dense_counts(sp_alignment* al, const int32_t* oa, int a, const int32_t* ob, int b,
                                        uint32_t* out_host) {
+    return sp_guard("sp_flatten_dense_counts", [&]() -> int {
     SP_REQUIRE(al && out_host, SP_EINVAL, "NULL argument");
     SP_REQUIRE(al->exact, SP_EINVAL, "sp_flatten_dense_counts needs an alignment with integer counts");
     sp_ctx* ctx = al->ctx;
@@ -522,6 +588,7 @@ extern "C" int sp_flatten_dense_counts(sp_alignment* al, const int32_t* oa, int 
     SP_HIP(hipMemcpyAsync(out_host, ctx->mats.p, (size_t)cells * 4, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;
+    });
 }
 
 // ------------------------------------------------------------------ scoring --------------------
@@ -578,15 +645,6 @@ __global__ void k_patch_scores(const int* __restrict__ idx, int n, const double*
     }
 }
 
-// The sparse route may be driven from several streams (sp_ctx_set_stream between calls) as long as the split list
-// does not change: uploads are recorded in ctx->upload_ev and every launch waits on it, so a launch on stream B
-// never reads a plan that stream A is still uploading.
-static int mark_upload(sp_ctx* ctx) {
-    if (!ctx->upload_ev) SP_HIP(hipEventCreateWithFlags(&ctx->upload_ev, hipEventDisableTiming));
-    SP_HIP(hipEventRecord(ctx->upload_ev, ctx->stream));
-    return SP_OK;
-}
-
 // Rows of the table the sparse kernel sees: D, plus one row per further 65535 of every count >= 2^16 (common.h).  The
 // first call for an alignment with such counts copies the counts to the host once.
 static int sparse_rows(sp_alignment* al, int64_t* rows) {
@@ -595,6 +653,7 @@ static int sparse_rows(sp_alignment* al, int64_t* rows) {
             al->spk_D = al->D;
         } else {
             std::vector<u32> hc((size_t)al->D);
+            SP_HIP(hipStreamSynchronize(al->ctx->stream));
             SP_HIP(hipMemcpy(hc.data(), al->counts.p, (size_t)al->D * 4, hipMemcpyDeviceToHost));
             int64_t extra = 0;
             for (u32 c : hc) extra += c >= 65536u ? (int64_t)((c + 65534u) / 65535u) - 1 : 0;
@@ -605,10 +664,13 @@ static int sparse_rows(sp_alignment* al, int64_t* rows) {
     return SP_OK;
 }
 
+// One-time, per alignment: 32-bit keys, trace, largest counts, and the AlDesc the kernels read - built on `ctx`'s stream
+// and SYNCHRONISED, so that afterwards the alignment is immutable and any context (lane) of the device may score it.
 static int prepare_sparse_table(sp_ctx* ctx, sp_alignment* al) {
     SP_REQUIRE(al->n_taxa <= 16, SP_ELIMIT, "sparse route: at most 16 taxa");
     int64_t rows = 0;
     SP_CHECK(sparse_rows(al, &rows));
+    SP_HIP(hipStreamSynchronize(al->ctx->stream));   // the table itself may still be in flight on its creator's stream
     unsigned long long trace = 0;
     const u64* keys = al->keys.as<u64>();
     const u32* counts = al->counts.as<u32>();
@@ -640,55 +702,181 @@ static int prepare_sparse_table(sp_ctx* ctx, sp_alignment* al) {
     }
     SP_CHECK(al->keys32.ensure((size_t)std::max<int64_t>(rows, 1) * 4));
     SP_CHECK(al->spk_meta.ensure(sizeof(SpkMeta)));
+    SP_CHECK(al->aldesc.ensure(sizeof(AlDesc)));
     SP_CHECK(launch_sparse_meta(ctx, keys, counts, rows, al->keys32.as<u32>(), al->spk_meta.as<SpkMeta>(), trace, al->D));
-    SP_CHECK(mark_upload(ctx));
+    const AlDesc d{al->keys32.as<u32>(), counts, al->spk_meta.as<SpkMeta>(), rows};
+    SP_HIP(hipMemcpyAsync(al->aldesc.p, &d, sizeof(d), hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
     al->spk_ready = true;
     return SP_OK;
 }
 
-static int upload_aldescs(sp_ctx* ctx, sp_alignment* const* als, int n_al) {
-    std::vector<AlDesc> d((size_t)n_al);
-    for (int i = 0; i < n_al; ++i) {
-        sp_alignment* al = als[i];
-        if (!al->spk_ready) SP_CHECK(prepare_sparse_table(ctx, al));   // one-time: 32-bit keys, trace, largest counts
-        d[i] = AlDesc{al->keys32.as<u32>(), al->spk_D != al->D ? al->spk_counts.as<u32>() : al->counts.as<u32>(),
-                      al->spk_meta.as<SpkMeta>(), al->spk_D};
-    }
-    if (ctx->aldescs_host.size() == d.size() && ctx->aldescs.p &&
-        memcmp(ctx->aldescs_host.data(), d.data(), d.size() * sizeof(AlDesc)) == 0)
-        return SP_OK;  // same alignments as last call: the device copy is current
-    SP_CHECK(ctx->aldescs.ensure(d.size() * sizeof(AlDesc)));
-    ctx->aldescs_host = d;
-    SP_HIP(hipMemcpyAsync(ctx->aldescs.p, ctx->aldescs_host.data(), d.size() * sizeof(AlDesc), hipMemcpyHostToDevice,
-                          ctx->stream));
-    return mark_upload(ctx);
+static AlDesc host_aldesc(const sp_alignment* al) {
+    return AlDesc{al->keys32.as<u32>(), al->spk_D != al->D ? al->spk_counts.as<u32>() : al->counts.as<u32>(),
+                  al->spk_meta.as<SpkMeta>(), al->spk_D};
 }
 
-// Sparse route + hand-back: splits the in-LDS kernel flags (status bit 1: lists do not fit, or no
-// convergence with the 4-wide block) are re-scored on the dense route and patched in.
-static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device, const int32_t* split_taxa,
-                            const int32_t* split_a, int64_t S, bool strict, double* out_scores = nullptr,
-                            int* out_status = nullptr) {
-    sp_ctx* ctx = al->ctx;
-    const Plan& plan = pc.plan;
-    if (!plan_on_device) {
-        SP_CHECK(ctx->splits.ensure((size_t)S * sizeof(SplitDev)));
-        SP_HIP(hipMemcpyAsync(ctx->splits.p, plan.splits.data(), (size_t)S * sizeof(SplitDev), hipMemcpyHostToDevice,
-                              ctx->stream));
-        SP_CHECK(ctx->gram_items.ensure((size_t)S * sizeof(int)));
-        SP_HIP(hipMemcpyAsync(ctx->gram_items.p, plan.order.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice,
-                              ctx->stream));
-        SP_CHECK(mark_upload(ctx));
+// Descriptor array of a multi-alignment call.  One alignment: the alignment's own immutable device copy.  Several: the
+// context's buffer, rewritten on the context's stream only when the set differs from the last call's - in stream order
+// behind every kernel that read the previous contents (a context's buffer is only ever used on its own stream).
+static int aldescs_for(sp_ctx* ctx, sp_alignment* const* als, int n_al, const AlDesc** out) {
+    for (int i = 0; i < n_al; ++i)
+        if (!als[i]->spk_ready) SP_CHECK(prepare_sparse_table(ctx, als[i]));
+    if (n_al == 1) {
+        *out = als[0]->aldesc.as<AlDesc>();
+        return SP_OK;
     }
+    std::vector<AlDesc> d((size_t)n_al);
+    for (int i = 0; i < n_al; ++i) d[i] = host_aldesc(als[i]);
+    if (!(ctx->aldescs_host.size() == d.size() && ctx->aldescs.p &&
+          memcmp(ctx->aldescs_host.data(), d.data(), d.size() * sizeof(AlDesc)) == 0)) {
+        SP_CHECK(ctx->aldescs.ensure(d.size() * sizeof(AlDesc)));
+        // (pageable source: the runtime stages it before returning, so the vector may be replaced right away)
+        SP_HIP(hipMemcpyAsync(ctx->aldescs.p, d.data(), d.size() * sizeof(AlDesc), hipMemcpyHostToDevice, ctx->stream));
+        SP_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->aldescs_host = d;
+    }
+    *out = ctx->aldescs.as<AlDesc>();
+    return SP_OK;
+}
+
+// ------------------------------------------------------------------ plans ----------------------
+extern "C" int sp_plan_create(sp_ctx* ctx, int n_taxa, const int32_t* split_taxa, const int32_t* split_a,
+                              int64_t n_splits, sp_plan** out) {
+    return sp_guard("sp_plan_create", [&]() -> int {
+    SP_REQUIRE(ctx && out && (n_splits == 0 || (split_taxa && split_a)), SP_EINVAL, "sp_plan_create: NULL argument");
+    SP_REQUIRE(n_taxa >= 2 && n_taxa <= 32 && n_splits >= 0, SP_EINVAL, "sp_plan_create: bad sizes");
+    SP_HIP(hipSetDevice(ctx->device));
+    Plan hp;
+    SP_CHECK(plan_splits(n_taxa, 1, split_taxa, split_a, n_splits, true, false, false, hp, 0));
+    sp_plan* pl = new sp_plan();
+    pl->device = ctx->device;
+    pl->n = n_taxa;
+    pl->S = n_splits;
+    pl->splits = hp.splits;
+    pl->taxa.assign(split_taxa, split_taxa + (size_t)n_splits * n_taxa);
+    pl->a.assign(split_a, split_a + n_splits);
+    // heaviest first: the larger the smaller side, the longer the workgroup runs (stable: ties keep the list order)
+    std::vector<int> order((size_t)n_splits);
+    for (int64_t i = 0; i < n_splits; ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return pl->splits[x].nr > pl->splits[y].nr; });
+    for (const SplitDev& sd : pl->splits) pl->bm_words_max = std::max<int64_t>(pl->bm_words_max, (int64_t)sd.rw + sd.cw);
+    int rc = SP_OK;
+    const size_t s1 = (size_t)std::max<int64_t>(n_splits, 1);
+    if ((rc = pl->splits_dev.ensure(s1 * sizeof(SplitDev))) || (rc = pl->order_dev.ensure(s1 * sizeof(int)))) {
+        sp_plan_release(pl);
+        return rc;
+    }
+    if (n_splits > 0) {
+        hipError_t e = hipMemcpy(pl->splits_dev.p, pl->splits.data(), (size_t)n_splits * sizeof(SplitDev), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(pl->order_dev.p, order.data(), (size_t)n_splits * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            sp_plan_release(pl);
+            sp_set_error("sp_plan_create: upload failed: %s", hipGetErrorString(e));
+            return SP_EHIP;
+        }
+    }
+    *out = pl;
+    return SP_OK;
+    });
+}
+
+extern "C" int sp_plan_retain(sp_plan* plan) {
+    return sp_guard("sp_plan_retain", [&]() -> int {
+    SP_REQUIRE(plan, SP_EINVAL, "plan is NULL");
+    ++plan->refs;
+    return SP_OK;
+    });
+}
+
+extern "C" int sp_plan_release(sp_plan* plan) {
+    return sp_guard("sp_plan_release", [&]() -> int {
+    if (!plan) return SP_OK;
+    if (--plan->refs > 0) return SP_OK;
+    (void)hipSetDevice(plan->device);
+    (void)hipDeviceSynchronize();   // kernels of any lane may still be reading it
+    plan->splits_dev.release();
+    plan->order_dev.release();
+    delete plan;
+    return SP_OK;
+    });
+}
+
+extern "C" int sp_plan_info(const sp_plan* plan, int* n_taxa, int64_t* n_splits) {
+    return sp_guard("sp_plan_info", [&]() -> int {
+    SP_REQUIRE(plan, SP_EINVAL, "plan is NULL");
+    if (n_taxa) *n_taxa = plan->n;
+    if (n_splits) *n_splits = plan->S;
+    return SP_OK;
+    });
+}
+
+// The device-side sparse route for n_al alignments x the plan's splits on `ctx`'s stream (no host synchronisation once
+// the alignments are prepared).
+static int enqueue_sparse_plan(sp_ctx* ctx, sp_alignment* const* als, int n_al, const sp_plan* plan, double* scores,
+                               int* status, bool wide_all) {
+    int64_t dmax = 0;
+    for (int i = 0; i < n_al; ++i) {
+        sp_alignment* al = als[i];
+        SP_REQUIRE(al && al->ctx->device == ctx->device && al->n_taxa == plan->n, SP_EINVAL,
+                   "alignment %d: NULL, on another device, or not of the plan's %d taxa", i, plan->n);
+        int64_t srows = 0;
+        SP_CHECK(sparse_rows(al, &srows));
+        SP_REQUIRE(al->exact && srows <= 65535 && al->D > 0 && al->n_taxa <= 16, SP_ELIMIT,
+                   "sparse route needs integer counts, 1..65535 table rows (counts >= 65536 take several) and at most 16 "
+                   "taxa (alignment %d: %lld rows, %d taxa, %s)", i, (long long)srows, al->n_taxa,
+                   al->exact ? "counts" : "float weights");
+        dmax = std::max(dmax, srows);
+    }
+    const AlDesc* descs = nullptr;
+    SP_CHECK(aldescs_for(ctx, als, n_al, &descs));
+    return launch_sparse_chain(ctx, descs, n_al, plan->n, plan->splits_dev.as<SplitDev>(), plan->order_dev.as<int>(),
+                               plan->S, scores, status, dmax, plan->bm_words_max, wide_all);
+}
+
+extern "C" int sp_score_plan_async(sp_ctx* lane, sp_alignment* const* als, int n_al, sp_plan* plan, void* scores_dev,
+                                   void* status_dev) {
+    return sp_guard("sp_score_plan_async", [&]() -> int {
+    SP_REQUIRE(lane && als && n_al >= 1 && plan && scores_dev && status_dev, SP_EINVAL, "sp_score_plan_async: NULL argument");
+    SP_REQUIRE(plan->device == lane->device, SP_EINVAL, "plan and lane are on different devices");
+    SP_HIP(hipSetDevice(lane->device));
+    if (plan->S == 0) return SP_OK;
+    return enqueue_sparse_plan(lane, als, n_al, plan, (double*)scores_dev, (int*)status_dev, true);
+    });
+}
+
+// The context's cached plan for a split list (content-keyed): the asynchronous convenience entry points and the
+// synchronous sparse route re-plan only when the list changes.
+static int cached_sparse_plan(sp_ctx* ctx, int n, const int32_t* split_taxa, const int32_t* split_a, int64_t S,
+                              sp_plan** out) {
+    if (!ctx->cache) ctx->cache = new PlanCache();
+    sp_plan*& pl = ctx->cache->sparse;
+    const size_t nt = (size_t)S * n;
+    if (pl && pl->n == n && pl->S == S && memcmp(pl->a.data(), split_a, (size_t)S * 4) == 0 &&
+        memcmp(pl->taxa.data(), split_taxa, nt * 4) == 0) {
+        *out = pl;
+        return SP_OK;
+    }
+    if (pl) {
+        (void)sp_plan_release(pl);
+        pl = nullptr;
+    }
+    SP_CHECK(sp_plan_create(ctx, n, split_taxa, split_a, S, &pl));
+    *out = pl;
+    return SP_OK;
+}
+
+// Synchronous sparse route: the device chain (in-LDS kernel -> lists in global memory -> all arrays in global memory ->
+// 8-wide fallback block for sides beyond the dense route), then - the only host step - splits whose 4-wide block found no
+// certified gap and whose smaller side fits the dense route's 1024 rows are re-scored there and patched in.
+static int run_sparse_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S, bool strict) {
+    sp_ctx* ctx = al->ctx;
+    const int n = al->n_taxa;
+    sp_plan* plan = nullptr;
+    SP_CHECK(cached_sparse_plan(ctx, n, split_taxa, split_a, S, &plan));
     SP_CHECK(ctx->scores.ensure((size_t)S * 8));
     SP_CHECK(ctx->status.ensure((size_t)S * 4));
-    SP_CHECK(upload_aldescs(ctx, &al, 1));
-    SP_CHECK(launch_sparse_score(ctx, ctx->aldescs.as<AlDesc>(), 1, al->n_taxa,
-                                 ctx->splits.as<SplitDev>(), ctx->gram_items.as<int>(), S,
-                                 out_scores ? out_scores : ctx->scores.as<double>(),
-                                 out_status ? out_status : ctx->status.as<int>()));
-    pc.valid = true;
-    if (out_scores) return SP_OK;  // asynchronous form: the caller inspects the status array itself
+    SP_CHECK(enqueue_sparse_plan(ctx, &al, 1, plan, ctx->scores.as<double>(), ctx->status.as<int>(), false));
     std::vector<int> st((size_t)S);
     SP_HIP(hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
@@ -697,124 +885,10 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
         if (st[i] & 2) redo.push_back((int)i);
     if (redo.empty()) return SP_OK;
     SP_REQUIRE(!strict, SP_ELIMIT,
-               "sparse route: %zu of %lld splits were handed back by the in-LDS kernel (first: split %d, status 0x%x: "
-               "%s)", redo.size(), (long long)S, redo[0], st[redo[0]],
-               (st[redo[0]] >> 8) ? "no convergence with the 4-wide block" : "lists / blocks do not fit LDS");
-    {   // splits that only lacked LDS space, first resort: the LDS form with its two entry lists in global memory
-        // (everything the products gather from stays in LDS; 13.5 k patterns with ~1800 ids a side fit)
-        std::vector<int> fit;
-        for (int i : redo)
-            if ((st[i] >> 8) == 0) fit.push_back(i);
-        if (!fit.empty() && al->spk_D <= 65535) {
-            const size_t slab = sparse_list_slab_bytes(al->spk_D);
-            DevBuf& fidx = ctx->big[22];   // (pooled: a hipMalloc / hipFree pair per call costs more than the index upload)
-            DevBuf& slabs = ctx->slabs;
-            int rc2 = SP_OK;
-            if ((rc2 = slabs.ensure(fit.size() * slab)) || (rc2 = fidx.ensure(fit.size() * 4))) {
-                return rc2;
-            }
-            hipError_t e = hipMemcpyAsync(fidx.p, fit.data(), fit.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess)
-                rc2 = launch_sparse_score_lists(ctx, ctx->aldescs.as<AlDesc>(), al->n_taxa, ctx->splits.as<SplitDev>(),
-                                                fidx.as<int>(), (int64_t)fit.size(), S, ctx->scores.as<double>(),
-                                                ctx->status.as<int>(), slabs.as<unsigned char>(), slab);
-            if (e == hipSuccess && rc2 == SP_OK)
-                e = hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (rc2 != SP_OK) return rc2;
-            if (e != hipSuccess) {
-                sp_set_error("sparse route (lists in global memory): %s", hipGetErrorString(e));
-                return SP_EHIP;
-            }
-            redo.clear();
-            for (int64_t i = 0; i < S; ++i)
-                if (st[i] & 2) redo.push_back((int)i);
-            if (redo.empty()) return SP_OK;
-        }
-    }
-    {   // still no room: the same kernel with ALL its arrays in a global-memory slab per workgroup
-        std::vector<int> fit;
-        int64_t bmw = 0;
-        for (int i : redo)
-            if ((st[i] >> 8) == 0) {
-                fit.push_back(i);
-                bmw = std::max<int64_t>(bmw, (int64_t)plan.splits[i].rw + plan.splits[i].cw);
-            }
-        if (!fit.empty() && al->spk_D <= 65535) {
-            const size_t slab = (sparse_slab_bytes(al->spk_D, bmw) + 255) & ~(size_t)255;
-            const size_t chunk = std::max<size_t>(1, std::min<size_t>(fit.size(), ((size_t)2 << 30) / slab));
-            DevBuf& fidx = ctx->big[22];   // (pooled: a hipMalloc / hipFree pair per call costs more than the index upload)
-            DevBuf& slabs = ctx->slabs;   // kept for the next call (a 2 GB hipMalloc costs more than the kernel)
-            int rc2 = SP_OK;
-            if ((rc2 = slabs.ensure(chunk * slab)) || (rc2 = fidx.ensure(fit.size() * 4))) {
-                return rc2;
-            }
-            hipError_t e = hipMemcpyAsync(fidx.p, fit.data(), fit.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-            for (size_t k0 = 0; k0 < fit.size() && e == hipSuccess && rc2 == SP_OK; k0 += chunk) {
-                const size_t cnt = std::min(chunk, fit.size() - k0);
-                rc2 = launch_sparse_score_hbm(ctx, ctx->aldescs.as<AlDesc>(), al->n_taxa, ctx->splits.as<SplitDev>(),
-                                              fidx.as<int>() + k0, (int64_t)cnt, S, ctx->scores.as<double>(),
-                                              ctx->status.as<int>(), slabs.as<unsigned char>(), slab);
-            }
-            if (e == hipSuccess && rc2 == SP_OK)
-                e = hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (rc2 != SP_OK) return rc2;
-            if (e != hipSuccess) {
-                sp_set_error("sparse route (HBM form): %s", hipGetErrorString(e));
-                return SP_EHIP;
-            }
-            redo.clear();
-            for (int64_t i = 0; i < S; ++i)
-                if (st[i] & 2) redo.push_back((int)i);
-            if (redo.empty()) return SP_OK;
-        }
-    }
-    const int n = al->n_taxa;
-    {   // Splits the 4-wide block could not finish (status 2 with half products on the clock) whose smaller side is beyond
-        // the dense route's 1024-row eigen kernels: the same kernel with the 8-wide fallback block, arrays in global memory.
-        // Its answer is final (status bit 0 if even that ran into its cap).
-        std::vector<int> widev;
-        int64_t bmw = 0;
-        for (int i : redo) {
-            const SplitDev& sd = plan.splits[i];
-            const int64_t rmax = std::min<int64_t>(pow4(std::min(sd.nr, sd.nc)), std::max<int64_t>(al->D, 1));
-            if ((st[i] >> 8) != 0 && round_up(rmax, 64) > EIG_MAXR) {
-                widev.push_back(i);
-                bmw = std::max<int64_t>(bmw, (int64_t)sd.rw + sd.cw);
-            }
-        }
-        if (!widev.empty() && al->spk_D <= 65535) {
-            const size_t slab = (sparse_slab_bytes(al->spk_D, bmw, true) + 255) & ~(size_t)255;
-            const size_t chunk = std::max<size_t>(1, std::min<size_t>(widev.size(), ((size_t)2 << 30) / slab));
-            DevBuf& widx = ctx->big[22];
-            DevBuf& slabs = ctx->slabs;
-            int rc2 = SP_OK;
-            if ((rc2 = slabs.ensure(chunk * slab)) || (rc2 = widx.ensure(widev.size() * 4))) {
-                return rc2;
-            }
-            hipError_t e = hipMemcpyAsync(widx.p, widev.data(), widev.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-            for (size_t k0 = 0; k0 < widev.size() && e == hipSuccess && rc2 == SP_OK; k0 += chunk) {
-                const size_t cnt = std::min(chunk, widev.size() - k0);
-                rc2 = launch_sparse_score_hbm(ctx, ctx->aldescs.as<AlDesc>(), al->n_taxa, ctx->splits.as<SplitDev>(),
-                                              widx.as<int>() + k0, (int64_t)cnt, S, ctx->scores.as<double>(),
-                                              ctx->status.as<int>(), slabs.as<unsigned char>(), slab, true);
-            }
-            if (e == hipSuccess && rc2 == SP_OK)
-                e = hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (rc2 != SP_OK) return rc2;
-            if (e != hipSuccess) {
-                sp_set_error("sparse route (wide block): %s", hipGetErrorString(e));
-                return SP_EHIP;
-            }
-            redo.clear();
-            for (int64_t i = 0; i < S; ++i)
-                if (st[i] & 2) redo.push_back((int)i);
-            if (redo.empty()) return SP_OK;
-        }
-    }
-    // dense route on the handed-back subset (overwrites the context pools, hence the parking buffer)
+               "sparse route: %zu of %lld splits are left to the dense route (first: split %d, status 0x%x: %s)",
+               redo.size(), (long long)S, redo[0], st[redo[0]],
+               (st[redo[0]] >> 8) ? "no convergence with the 4-wide block" : "does not fit any form of the kernel");
+    // dense route on the handed-back subset (overwrites the context pools, hence the parking buffers)
     std::vector<int32_t> t2(redo.size() * (size_t)n), a2(redo.size());
     for (size_t k = 0; k < redo.size(); ++k) {
         memcpy(&t2[k * n], split_taxa + (size_t)redo[k] * n, (size_t)n * 4);
@@ -822,15 +896,13 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
     }
     DevBuf keep_scores, keep_status, idx;
     int rc = SP_OK;
-    if ((rc = keep_scores.ensure((size_t)S * 8)) || (rc = keep_status.ensure((size_t)S * 4)) ||
-        (rc = idx.ensure(redo.size() * 4))) {
-        keep_scores.release(); keep_status.release(); idx.release();
-        return rc;
-    }
     auto bail = [&](int code) {
         keep_scores.release(); keep_status.release(); idx.release();
         return code;
     };
+    if ((rc = keep_scores.ensure((size_t)S * 8)) || (rc = keep_status.ensure((size_t)S * 4)) ||
+        (rc = idx.ensure(redo.size() * 4)))
+        return bail(rc);
     if (hipMemcpyAsync(keep_scores.p, ctx->scores.p, (size_t)S * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
         hipMemcpyAsync(keep_status.p, ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
         hipMemcpyAsync(idx.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
@@ -846,11 +918,11 @@ static int run_sparse_route(sp_alignment* al, PlanCache& pc, bool plan_on_device
     rc = plan_splits(n, al->D, t2.data(), a2.data(), (int64_t)redo.size(), true, true, true, sub, nl > 0 ? nl : 0);
     if (rc == SP_OK) rc = run_dense_route(al, sub, false);
     ctx->cache = saved;
-    pc.valid = false;  // the device copy of the cached sparse plan was overwritten
+    if (ctx->cache) ctx->cache->valid = false;  // the dense route's pools were re-planned
     if (rc == SP_ELIMIT) {
-        // The dense route cannot take this shape (a side beyond its compaction / block limits, e.g. 12 taxa).  Splits
-        // the sparse kernel iterated on keep its last Ritz estimate (an upper estimate of the score), flagged with
-        // status bit 0 = "iteration cap hit, not certified"; a split that never ran has nothing to keep.
+        // The dense route cannot take this shape.  Splits the sparse kernel iterated on keep its last Ritz estimate (an
+        // upper estimate of the score), flagged with status bit 0 = "iteration cap hit, not certified"; a split that
+        // never ran has nothing to keep.
         for (int i : redo)
             if ((st[i] >> 8) == 0) return bail(rc);
         for (int i : redo) st[i] = (st[i] & ~2) | 1;
@@ -893,7 +965,7 @@ static int run_sparse_big_route(sp_alignment* al, const int32_t* split_taxa, con
                    n - split_a[s]);
         max_side = std::max(max_side, std::max(split_a[s], n - split_a[s]));
     }
-    const bool by_keys = max_side > 14 || (getenv("SPLITP_BIG_BY_KEYS") != nullptr);   // beyond the bitmap compaction
+    const bool by_keys = max_side > 14 || ctx->opt.big_by_keys;   // beyond the bitmap compaction
     const int64_t cap_entries = std::min<int64_t>(((int64_t)1 << 32) - 1, (int64_t)6e9 / (by_keys ? 96 : 64));
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(S, cap_entries / std::max<int64_t>(D, 1)));
     for (int64_t s0 = 0; s0 < S; s0 += chunk) {
@@ -941,6 +1013,7 @@ static int run_divergence_route(sp_alignment* al, const int32_t* split_taxa, con
 
 extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
                                int method, double* scores_host, void* scores_dev, int32_t* status_host) {
+    return sp_guard("sp_score_splits", [&]() -> int {
     SP_REQUIRE(al && split_taxa && split_a, SP_EINVAL, "NULL argument");
     SP_REQUIRE(n_splits >= 0, SP_EINVAL, "n_splits < 0");
     sp_ctx* ctx = al->ctx;
@@ -950,8 +1023,7 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
     // tables beyond the list kernels' 65535 rows at taxon counts the dense route cannot take: the big-table form
     bool handled = false;
     if (method == SP_METHOD_FLATTENING) {
-        const char* fb = getenv("SPLITP_FORCE_BIG");   // "1": every table (tests)
-        bool want = fb && fb[0] == '1';
+        bool want = ctx->opt.force_big != 0;   // (test switch: every table)
         if (!want && al->n_taxa >= 12) {
             if (!al->exact || al->n_taxa > 16) {   // (more than 16 taxa: the list kernels pack keys into 32 bits)
                 want = true;            // float weights: the list kernels carry integer counts, the dense route ends at 11 taxa
@@ -970,9 +1042,6 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
         // (scores and status are in the context's buffers, copied out below)
     } else if (method == SP_METHOD_FLATTENING || method == SP_METHOD_FLATTENING_DENSE ||
         method == SP_METHOD_FLATTENING_SPARSE) {
-        if (!ctx->cache) ctx->cache = new PlanCache();
-        PlanCache& pc = *ctx->cache;
-        const size_t nt = (size_t)n_splits * al->n_taxa;
         int64_t srows = 0;
         SP_CHECK(sparse_rows(al, &srows));
         const bool sparse_ok = al->exact && srows <= 65535 && al->n_taxa <= 16;
@@ -980,28 +1049,29 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
                    "sparse route needs integer counts, at most 65535 table rows (counts >= 65536 take several) and at most 16 taxa");
         const bool use_sparse = method == SP_METHOD_FLATTENING_SPARSE ||
                                 (method == SP_METHOD_FLATTENING && sparse_ok && ctx->gram_mode == 0);
-        const int nl = use_sparse ? -1 : limbs_for(al);
-        const bool hit = pc.valid && pc.nl == nl && pc.n == al->n_taxa && pc.D == al->D &&
-                         pc.a.size() == (size_t)n_splits &&
-                         memcmp(pc.a.data(), split_a, n_splits * 4) == 0 &&
-                         memcmp(pc.taxa.data(), split_taxa, nt * 4) == 0;
-        if (!hit) {
-            pc.valid = false;
-            SP_CHECK(plan_splits(al->n_taxa, al->D, split_taxa, split_a, n_splits, true, !use_sparse, !use_sparse,
-                                 pc.plan, nl > 0 ? nl : 0));
-            if (use_sparse) build_gram_items(pc.plan);  // only for the heaviest-first order
-            pc.taxa.assign(split_taxa, split_taxa + nt);
-            pc.a.assign(split_a, split_a + n_splits);
-            pc.n = al->n_taxa;
-            pc.D = al->D;
-            pc.nl = nl;
-        }
-        if (!use_sparse) {
+        if (use_sparse) {
+            SP_CHECK(run_sparse_route(al, split_taxa, split_a, n_splits, method == SP_METHOD_FLATTENING_SPARSE));
+        } else {
+            if (!ctx->cache) ctx->cache = new PlanCache();
+            PlanCache& pc = *ctx->cache;
+            const size_t nt = (size_t)n_splits * al->n_taxa;
+            const int nl = limbs_for(al);
+            const bool hit = pc.valid && pc.nl == nl && pc.n == al->n_taxa && pc.D == al->D &&
+                             pc.a.size() == (size_t)n_splits &&
+                             memcmp(pc.a.data(), split_a, n_splits * 4) == 0 &&
+                             memcmp(pc.taxa.data(), split_taxa, nt * 4) == 0;
+            if (!hit) {
+                pc.valid = false;
+                SP_CHECK(plan_splits(al->n_taxa, al->D, split_taxa, split_a, n_splits, true, true, true, pc.plan,
+                                     nl > 0 ? nl : 0));
+                pc.taxa.assign(split_taxa, split_taxa + nt);
+                pc.a.assign(split_a, split_a + n_splits);
+                pc.n = al->n_taxa;
+                pc.D = al->D;
+                pc.nl = nl;
+            }
             SP_CHECK(run_dense_route(al, pc.plan, hit));
             pc.valid = true;
-        } else {
-            SP_CHECK(run_sparse_route(al, pc, hit, split_taxa, split_a, n_splits,
-                                      method == SP_METHOD_FLATTENING_SPARSE));
         }
     } else if (method == SP_METHOD_SUBFLATTENING) {
         SP_CHECK(run_subflat_route(al, split_taxa, split_a, n_splits));
@@ -1015,10 +1085,29 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
         SP_HIP(hipMemcpyAsync(scores_dev, ctx->scores.p, n_splits * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (scores_host)
         SP_HIP(hipMemcpyAsync(scores_host, ctx->scores.p, n_splits * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (status_host)
-        SP_HIP(hipMemcpyAsync(status_host, ctx->status.p, n_splits * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (scores_host || status_host) SP_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> st_tmp;
+    int32_t* st_out = status_host;
+    if (scores_host && !status_host) {   // the return code reports unconverged splits either way
+        st_tmp.resize((size_t)n_splits);
+        st_out = st_tmp.data();
+    }
+    if (st_out) SP_HIP(hipMemcpyAsync(st_out, ctx->status.p, n_splits * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (scores_host || st_out) SP_HIP(hipStreamSynchronize(ctx->stream));
+    if (st_out) {
+        int64_t bad = 0, first = -1;
+        for (int64_t i = 0; i < n_splits; ++i)
+            if (st_out[i] & 1) {
+                if (first < 0) first = i;
+                ++bad;
+            }
+        if (bad) {
+            sp_set_error("%lld of %lld splits hit the iteration cap of their eigen-solver (first: split %lld): their scores "
+                         "are upper estimates (status bit 0)", (long long)bad, (long long)n_splits, (long long)first);
+            return SP_ENOCONV;
+        }
+    }
     return SP_OK;
+    });
 }
 
 int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int64_t* n_out, bool score);  // subflat.hip
@@ -1026,6 +1115,7 @@ int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int64_t* n_o
 // Every split of the table's taxa in the reference's all_splits order (splits.py:39-59), enumerated on the device.
 extern "C" int sp_score_all_splits(sp_alignment* al, int method, int trivial, int size, int64_t* n_splits,
                                    double* scores_host, void* scores_dev, int32_t* status_host) {
+    return sp_guard("sp_score_all_splits", [&]() -> int {
     SP_REQUIRE(al, SP_EINVAL, "alignment is NULL");
     sp_ctx* ctx = al->ctx;
     SP_HIP(hipSetDevice(ctx->device));
@@ -1043,11 +1133,13 @@ extern "C" int sp_score_all_splits(sp_alignment* al, int method, int trivial, in
     if (status_host) SP_HIP(hipMemcpyAsync(status_host, ctx->status.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (scores_host || status_host) SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;
+    });
 }
 
 // Generic matrix: upload (transposed if needed so the smaller side indexes rows), Gram, eigen.
 extern "C" int sp_score_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, int64_t cols, int64_t ld,
                                    double* score) {
+    return sp_guard("sp_score_matrix_f64", [&]() -> int {
     SP_REQUIRE(ctx && m && score, SP_EINVAL, "NULL argument");
     SP_REQUIRE(rows >= 1 && cols >= 1 && ld >= cols, SP_EINVAL, "bad matrix shape %lld x %lld (ld %lld)",
                (long long)rows, (long long)cols, (long long)ld);
@@ -1105,6 +1197,7 @@ extern "C" int sp_score_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, i
     SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;
+    });
 }
 
 // Sparse (COO) matrix: phylogenetics.py:303-312.  The reference asks ARPACK for the top-4 singular
@@ -1113,6 +1206,7 @@ extern "C" int sp_score_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, i
 // (removing all-zero rows / columns does not change singular values).
 extern "C" int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* ci, const double* v, int64_t nnz,
                                 int64_t rows, int64_t cols, double* score) {
+    return sp_guard("sp_score_coo_f64", [&]() -> int {
     SP_REQUIRE(ctx && score, SP_EINVAL, "NULL argument");
     SP_REQUIRE(rows >= 1 && cols >= 1 && nnz >= 0, SP_EINVAL, "bad shape");
     SP_REQUIRE(nnz == 0 || (ri && ci && v), SP_EINVAL, "NULL triplet arrays");
@@ -1195,10 +1289,12 @@ extern "C" int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* c
     SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;
+    });
 }
 
 extern "C" int sp_score_splits_async(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a,
                                      int64_t n_splits, int method, void* scores_dev, void* status_dev) {
+    return sp_guard("sp_score_splits_async", [&]() -> int {
     SP_REQUIRE(al && split_taxa && split_a && scores_dev && status_dev, SP_EINVAL, "NULL argument");
     SP_REQUIRE(n_splits >= 0, SP_EINVAL, "n_splits < 0");
     sp_ctx* ctx = al->ctx;
@@ -1209,88 +1305,42 @@ extern "C" int sp_score_splits_async(sp_alignment* al, const int32_t* split_taxa
     SP_CHECK(sparse_rows(al, &srows));
     const bool sparse_ok = al->exact && srows <= 65535 && al->n_taxa <= 16;
     const bool want_sparse = method == SP_METHOD_FLATTENING_SPARSE ||
-                             (method == SP_METHOD_FLATTENING && sparse_ok && ctx->gram_mode == 0);
+                             (method == SP_METHOD_FLATTENING && sparse_ok && ctx->gram_mode == 0 && !ctx->opt.force_big);
     if (want_sparse) {
-        SP_REQUIRE(sparse_ok, SP_ELIMIT, "sparse route needs integer counts, at most 65535 table rows (counts >= 65536 take several) and at most 16 taxa");
-        if (!ctx->cache) ctx->cache = new PlanCache();
-        PlanCache& pc = *ctx->cache;
-        const size_t nt = (size_t)n_splits * al->n_taxa;
-        const bool hit = pc.valid && pc.nl == -1 && pc.n == al->n_taxa && pc.D == al->D &&
-                         pc.a.size() == (size_t)n_splits && memcmp(pc.a.data(), split_a, n_splits * 4) == 0 &&
-                         memcmp(pc.taxa.data(), split_taxa, nt * 4) == 0;
-        if (!hit) {
-            pc.valid = false;
-            SP_CHECK(plan_splits(al->n_taxa, al->D, split_taxa, split_a, n_splits, true, false, false, pc.plan, 0));
-            build_gram_items(pc.plan);
-            pc.taxa.assign(split_taxa, split_taxa + nt);
-            pc.a.assign(split_a, split_a + n_splits);
-            pc.n = al->n_taxa;
-            pc.D = al->D;
-            pc.nl = -1;
-        }
-        return run_sparse_route(al, pc, hit, split_taxa, split_a, n_splits, false, (double*)scores_dev,
-                                (int*)status_dev);
+        sp_plan* plan = nullptr;
+        SP_CHECK(cached_sparse_plan(ctx, al->n_taxa, split_taxa, split_a, n_splits, &plan));
+        return enqueue_sparse_plan(ctx, &al, 1, plan, (double*)scores_dev, (int*)status_dev, true);
     }
-    // other methods: the synchronous entry point with device outputs, then the status
-    SP_CHECK(sp_score_splits(al, split_taxa, split_a, n_splits, method, nullptr, scores_dev, nullptr));
+    // other methods: the synchronous entry point with device outputs, then the status (same stream: ordered)
+    int rc = sp_score_splits(al, split_taxa, split_a, n_splits, method, nullptr, scores_dev, nullptr);
+    if (rc != SP_OK && rc != SP_ENOCONV) return rc;
     SP_HIP(hipMemcpyAsync(status_dev, ctx->status.p, (size_t)n_splits * 4, hipMemcpyDeviceToDevice, ctx->stream));
     return SP_OK;
+    });
 }
 
-// Several alignments (same taxa, same split list) in ONE launch of the in-LDS kernel: n_al * n_splits workgroups,
-// heaviest splits first across all alignments.  scores_dev / status_dev hold n_al * n_splits entries, alignment-major.
+// Several alignments (same taxa, same split list) in ONE device pass: n_al * n_splits items through the sparse route's
+// chain.  scores_dev / status_dev hold n_al * n_splits entries, alignment-major.
 extern "C" int sp_score_splits_multi_async(sp_alignment* const* als, int n_al, const int32_t* split_taxa,
                                            const int32_t* split_a, int64_t n_splits, void* scores_dev,
                                            void* status_dev) {
+    return sp_guard("sp_score_splits_multi_async", [&]() -> int {
     SP_REQUIRE(als && n_al >= 1 && split_taxa && split_a && scores_dev && status_dev, SP_EINVAL, "NULL argument");
     sp_alignment* al0 = als[0];
     SP_REQUIRE(al0, SP_EINVAL, "NULL alignment");
     sp_ctx* ctx = al0->ctx;
     SP_HIP(hipSetDevice(ctx->device));
     if (n_splits == 0) return SP_OK;
-    int64_t dmax = 0;
-    for (int i = 0; i < n_al; ++i) {
-        SP_REQUIRE(als[i] && als[i]->ctx == ctx && als[i]->n_taxa == al0->n_taxa, SP_EINVAL,
-                   "alignments of one multi call must share the context and the number of taxa");
-        int64_t srows = 0;
-        if (als[i]) SP_CHECK(sparse_rows(als[i], &srows));
-        SP_REQUIRE(als[i]->exact && srows <= 65535 && als[i]->D > 0 && als[i]->n_taxa <= 16, SP_ELIMIT,
-                   "multi-alignment scoring uses the sparse route: integer counts, 1..65535 table rows, at most 16 taxa");
-        dmax = std::max(dmax, als[i]->D);
-    }
-    if (!ctx->cache) ctx->cache = new PlanCache();
-    PlanCache& pc = *ctx->cache;
-    const size_t nt = (size_t)n_splits * al0->n_taxa;
-    const bool hit = pc.valid && pc.nl == -1 && pc.n == al0->n_taxa && pc.D == dmax &&
-                     pc.a.size() == (size_t)n_splits && memcmp(pc.a.data(), split_a, n_splits * 4) == 0 &&
-                     memcmp(pc.taxa.data(), split_taxa, nt * 4) == 0;
-    if (!hit) {
-        pc.valid = false;
-        SP_CHECK(plan_splits(al0->n_taxa, dmax, split_taxa, split_a, n_splits, true, false, false, pc.plan, 0));
-        build_gram_items(pc.plan);
-        pc.taxa.assign(split_taxa, split_taxa + nt);
-        pc.a.assign(split_a, split_a + n_splits);
-        pc.n = al0->n_taxa;
-        pc.D = dmax;
-        pc.nl = -1;
-        SP_CHECK(ctx->splits.ensure((size_t)n_splits * sizeof(SplitDev)));
-        SP_HIP(hipMemcpyAsync(ctx->splits.p, pc.plan.splits.data(), (size_t)n_splits * sizeof(SplitDev),
-                              hipMemcpyHostToDevice, ctx->stream));
-        SP_CHECK(ctx->gram_items.ensure((size_t)n_splits * sizeof(int)));
-        SP_HIP(hipMemcpyAsync(ctx->gram_items.p, pc.plan.order.data(), (size_t)n_splits * sizeof(int),
-                              hipMemcpyHostToDevice, ctx->stream));
-        SP_CHECK(mark_upload(ctx));
-    }
-    SP_CHECK(upload_aldescs(ctx, als, n_al));
-    SP_CHECK(launch_sparse_score(ctx, ctx->aldescs.as<AlDesc>(), n_al, al0->n_taxa, ctx->splits.as<SplitDev>(),
-                                 ctx->gram_items.as<int>(), n_splits, (double*)scores_dev, (int*)status_dev));
-    pc.valid = true;
-    return SP_OK;
+    sp_plan* plan = nullptr;
+    SP_CHECK(cached_sparse_plan(ctx, al0->n_taxa, split_taxa, split_a, n_splits, &plan));
+    return enqueue_sparse_plan(ctx, als, n_al, plan, (double*)scores_dev, (int*)status_dev, true);
+    });
 }
 
 // phylogenetics.py:364-373 for a dense row-major matrix on the host (any non-negative matrix; cells equal to 0 are skipped).
 extern "C" int sp_divergence_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, int64_t cols, int64_t ld,
                                         double* out) {
+    return sp_guard("sp_divergence_matrix_f64", [&]() -> int {
     SP_REQUIRE(ctx && m && out, SP_EINVAL, "NULL argument");
     SP_REQUIRE(rows >= 1 && cols >= 1 && ld >= cols, SP_EINVAL, "bad matrix shape %lld x %lld (ld %lld)",
                (long long)rows, (long long)cols, (long long)ld);
@@ -1306,4 +1356,5 @@ extern "C" int sp_divergence_matrix_f64(sp_ctx* ctx, const double* m, int64_t ro
     SP_HIP(hipMemcpyAsync(out, res, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;
+    });
 }

@@ -36,6 +36,25 @@ void sp_set_error(const char* fmt, ...);
         }                           \
     } while (0)
 
+// No C++ exception crosses the C ABI: every extern "C" body runs inside sp_guard.
+#include <exception>
+#include <new>
+template <typename F>
+static inline int sp_guard(const char* fn, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        sp_set_error("%s: out of host memory", fn);
+        return SP_ENOMEM;
+    } catch (const std::exception& e) {
+        sp_set_error("%s: C++ exception: %s", fn, e.what());
+        return SP_EHIP;
+    } catch (...) {
+        sp_set_error("%s: unknown C++ exception", fn);
+        return SP_EHIP;
+    }
+}
+
 // Grow-only device buffer.  Re-allocation synchronises the device (rare: sizes settle after
 // the first call of a given shape; 288 GB of HBM means we never need to be frugal).
 struct DevBuf {
@@ -71,6 +90,19 @@ struct AlDesc {
     int64_t D;
 };
 
+// Test / tuning switches of a context.  Defaults come from the environment ONCE, at sp_ctx_create (SPLITP_FORCE_BIG,
+// SPLITP_BIG_BY_KEYS, SPLITP_SUBSCORE_JACOBI, SPLITP_DIVERGENCE_GLOBAL, SPLITP_HIST_SORT, SPLITP_DEBUG_LDS_CAP); later
+// changes go through sp_ctx_set_option.  They select between kernels that must agree, never a CPU path.
+struct CtxOptions {
+    int force_big = 0;          // every flattening score on the big-table form
+    int big_by_keys = 0;        // ... with its sort-based compaction
+    int subscore_jacobi = 0;    // Jacobi kernel for the batched subflattening score
+    int divergence_global = 0;  // global-memory form of the mutual-information score
+    int hist_sort = -1;         // -1 auto, 0 direct bins, 1 sort + run-length encode
+    int wide_cap = 0;           // half-product cap of the wide fallback block (0 = built-in 600)
+    long long lds_cap = 0;      // pretend the LDS is this small (plain LDS form of the sparse kernel)
+};
+
 struct sp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -91,11 +123,12 @@ struct sp_ctx {
     DevBuf misc;       // API scratch
     DevBuf misc2;
     DevBuf gram_items; // GramItem[]: Gram tiles, then the row-block items
-    DevBuf aldescs;    // AlDesc[] of the current multi-alignment call
+    DevBuf aldescs;    // AlDesc[] of the current multi-alignment call (this context's stream only)
+    DevBuf chain;      // work-queue head of the sparse route's device-side hand-back chain (k_sparse_slow)
+    CtxOptions opt;
     DevBuf slabs;      // per-workgroup global-memory slabs of the sparse kernel's HBM form (grow-only)
     DevBuf big[24];    // work buffers of the big-table form (grow-only: a multi-GB hipMalloc / hipFree per call costs more than the kernels)
     std::vector<AlDesc> aldescs_host;
-    hipEvent_t upload_ev = nullptr;  // last plan / descriptor upload of the sparse route (other streams wait on it)
     PlanCache* cache = nullptr;
     int n_cu = 256;
 };
@@ -111,7 +144,8 @@ struct sp_alignment {
     DevBuf counts;   // u32[D]   (exact only)
     DevBuf keys32;   // u32[D]   sparse route: keys narrowed to 32 bits (n_taxa <= 16), filled on first use
     DevBuf spk_meta; // SpkMeta  sparse route: trace + largest counts, filled on first use
-    bool spk_ready = false;
+    DevBuf aldesc;   // AlDesc   sparse route: this table as the kernels see it (device copy, written once)
+    bool spk_ready = false;   // keys32 / spk_meta / aldesc are complete AND visible to every stream (prepared synchronously)
     // counts >= 2^16 do not fit the 16-bit count field of the sparse kernel's list entries: such a pattern is entered as
     // several table rows with the same key whose counts add up (every product is linear in the entries); spk_D = number
     // of rows of that expanded table (-1: not computed yet), spk_keys / spk_counts hold it when it differs from the table
@@ -160,12 +194,27 @@ struct Plan {
 };
 
 struct PlanCache {
+    sp_plan* sparse = nullptr;   // retained plan of the last sparse-route split list (asynchronous entry points)
     bool valid = false;
     int nl = 0;  // limb count the plan was laid out for (0 = element-typed u32 / f64 matrices, -1 = sparse route)
     int n = 0;
     int64_t D = 0;
     std::vector<int32_t> taxa, a;
     Plan plan;
+};
+
+// An immutable, reference-counted candidate-split list on the device (sp_plan_create): split descriptors + the
+// heaviest-first launch order.  Uploaded synchronously at creation and never written again, so any number of contexts
+// (lanes) of the same device may score with it concurrently.
+struct sp_plan {
+    int refs = 1;
+    int device = 0;
+    int n = 0;
+    int64_t S = 0;
+    std::vector<SplitDev> splits;   // host copy
+    std::vector<int32_t> taxa, a;   // the list as given (content key of the internal plan cache)
+    int64_t bm_words_max = 0;       // largest rw + cw among the splits (slab sizing)
+    DevBuf splits_dev, order_dev;
 };
 
 struct PhaseScope {
@@ -207,16 +256,11 @@ int launch_sparse_big_keys(sp_ctx* ctx, const u64* keys, int64_t D, int n, const
                            int64_t S, const u32* counts, const double* weights, int dev_cus, double* scores, int* status);
 int launch_sparse_big(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, const u32* cc, const u32* counts,
                       const double* weights, const int2* dims, int dev_cus, double* scores, int* status);
-int launch_sparse_score_lists(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, const SplitDev* splits_dev,
-                              const int* order_dev, int64_t S_sub, int64_t S, double* scores, int* status,
-                              unsigned char* slabs, size_t slab_bytes);
-int launch_sparse_score_hbm(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, const SplitDev* splits_dev,
-                            const int* order_dev, int64_t S_sub, int64_t S, double* scores, int* status,
-                            unsigned char* slabs, size_t slab_bytes, bool wide = false);
+int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,
+                        const int* order_dev, int64_t S, double* scores, int* status, int64_t d_max, int64_t bm_words_max,
+                        bool wide_all);
 int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta,
                        unsigned long long trace_override, int64_t orig_rows);
-int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,
-                        const int* order_dev, int64_t S, double* scores, int* status);
 template <typename T>
 int launch_gram(sp_ctx* ctx, const SplitDev* splits_dev, const GramItem* items_dev, int64_t n_items, const int2* dims,
                 const T* mats, double* grams);

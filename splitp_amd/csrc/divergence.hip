@@ -101,7 +101,7 @@ int launch_divergence(sp_ctx* ctx, bool exact, int64_t D, int64_t S, const u32* 
                       const double* weights, double n_total, unsigned long long* marg, double* out) {
     if (S == 0) return SP_OK;
     PhaseScope ps(ctx, SP_PHASE_DIVERGENCE);
-    if (exact && D <= 16384 && n_total < 4294967296.0 && !getenv("SPLITP_DIVERGENCE_GLOBAL")) {
+    if (exact && D <= 16384 && n_total < 4294967296.0 && !ctx->opt.divergence_global) {
         const size_t lds = (size_t)2 * D * 4;
         static bool attr = false;
         if (!attr) {

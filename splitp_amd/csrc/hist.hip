@@ -331,9 +331,9 @@ static int build_sorted(sp_ctx* ctx, const KT* dkeys, int64_t L, int n_taxa, sp_
 static int build_from_device_keys(sp_ctx* ctx, const void* dkeys, bool keys32, int64_t L, int n_taxa,
                                   sp_alignment** out) {
     {
-        const char* force = getenv("SPLITP_HIST_SORT");   // "1" / "0": force / forbid the sort-based form (tests)
+        const int force = ctx->opt.hist_sort;   // 1 / 0: force / forbid the sort-based form (test switch), -1: auto
         const bool big_bins = n_taxa > 16 || pow4(n_taxa) > 32 * std::max<int64_t>(L, 1);
-        const bool use_sort = n_taxa > 16 || (force ? force[0] == '1' : big_bins);
+        const bool use_sort = n_taxa > 16 || (force >= 0 ? force == 1 : big_bins);
         if (use_sort)
             return keys32 ? build_sorted<u32>(ctx, (const u32*)dkeys, L, n_taxa, out)
                           : build_sorted<u64>(ctx, (const u64*)dkeys, L, n_taxa, out);
@@ -421,6 +421,7 @@ static int build_from_device_keys(sp_ctx* ctx, const void* dkeys, bool keys32, i
 
 extern "C" int sp_alignment_from_site_keys(sp_ctx* ctx, const uint64_t* site_keys, int64_t L, int n_taxa,
                                            sp_alignment** out) {
+    return sp_guard("sp_alignment_from_site_keys", [&]() -> int {
     SP_REQUIRE(ctx && out && (site_keys || L == 0), SP_EINVAL, "NULL argument");
     SP_REQUIRE(n_taxa >= 2 && n_taxa <= 32 && L >= 0, SP_EINVAL, "bad n_taxa / L");
     SP_HIP(hipSetDevice(ctx->device));
@@ -442,10 +443,12 @@ extern "C" int sp_alignment_from_site_keys(sp_ctx* ctx, const uint64_t* site_key
         }
     }
     return build_from_device_keys(ctx, ctx->misc.p, keys32, L, n_taxa, out);
+    });
 }
 
 extern "C" int sp_alignment_from_sequences(sp_ctx* ctx, const uint8_t* seqs, int n_taxa, int64_t L, int64_t stride,
                                            sp_alignment** out) {
+    return sp_guard("sp_alignment_from_sequences", [&]() -> int {
     SP_REQUIRE(ctx && out && (seqs || L == 0), SP_EINVAL, "NULL argument");
     SP_REQUIRE(n_taxa >= 2 && n_taxa <= 32 && L >= 0 && stride >= L, SP_EINVAL, "bad n_taxa / L / stride");
     SP_HIP(hipSetDevice(ctx->device));
@@ -464,6 +467,7 @@ extern "C" int sp_alignment_from_sequences(sp_ctx* ctx, const uint8_t* seqs, int
         SP_HIP(hipGetLastError());
     }
     return build_from_device_keys(ctx, ctx->misc.p, n_taxa <= 15, L, n_taxa, out);
+    });
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -534,6 +538,7 @@ __global__ __launch_bounds__(256) void k_simulate_sites(int n_nodes, const int* 
 extern "C" int sp_simulate_alignment(sp_ctx* ctx, int n_nodes, const int32_t* parent, const int32_t* leaf_taxon,
                                      const double* transition, int n_taxa, int64_t L, uint64_t seed,
                                      sp_alignment** out) {
+    return sp_guard("sp_simulate_alignment", [&]() -> int {
     SP_REQUIRE(ctx && parent && leaf_taxon && transition && out, SP_EINVAL, "NULL argument");
     SP_REQUIRE(n_taxa >= 2 && n_taxa <= 31, SP_ELIMIT, "device simulator supports 2..31 taxa (got %d)", n_taxa);
     SP_REQUIRE(n_nodes >= n_taxa && n_nodes <= SIM_MAX_NODES, SP_ELIMIT, "tree has %d nodes (supported: n_taxa..%d)",
@@ -574,4 +579,5 @@ extern "C" int sp_simulate_alignment(sp_ctx* ctx, int n_nodes, const int32_t* pa
     }
     SP_HIP(hipStreamSynchronize(ctx->stream));   // the host arrays may die at return
     return build_from_device_keys(ctx, ctx->misc.p, keys32, L, n_taxa, out);
+    });
 }

@@ -74,7 +74,7 @@ struct SpkShared {
     double L[12];        // its Cholesky factor: 1 / l_jj (4), l_10 l_20 l_30 l_21 l_31 l_32, pivot ratio, eigenvalue bound
     double top4;
     unsigned long long trace;
-    int R, Kc, nw_c, nr_c, nq_c, nw_r, nr_r, nq_r, used_c, used_r, pad0, pad1;   // nw_* / nr_*: groups handled by a whole wave / by a 16-lane row
+    int R, Kc, nw_c, nr_c, nq_c, nw_r, nr_r, nq_r, used_c, used_r, qchunk, pad1;   // nw_* / nr_*: groups handled by a whole wave / by a 16-lane row
     int shifts[32];
     // (trace above and the two below: copies of the alignment metadata, fetched while the table is being staged)
     u32 top[SPK_NTOP];
@@ -822,27 +822,27 @@ __device__ __forceinline__ bool spk_wide_converged(double s4, double th4, double
 // column sides of ~1800 ids).  Communication inside the workgroup then goes through global memory: plain stores are
 // coherent at workgroup scope after __syncthreads(); words that were updated by ATOMICS (key bitmaps, sort counters, the
 // integer Gram) are read back with agent-scope atomic loads (spk_aload), since device atomics are done in L2 past the L1.
-template <bool HBM, bool WIDE = false, bool LISTS_GLOBAL = false>
-__global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __restrict__ als, int n_al, int n,
-                                                              const SplitDev* __restrict__ splits,
-                                                              const int* __restrict__ order, int S,
-                                                              double* __restrict__ scores_all,
-                                                              int* __restrict__ status_all,
-                                                              unsigned char* __restrict__ slabs, size_t slab_bytes) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// One (alignment, split) item, start to finish, by the whole workgroup.  `slab`: this workgroup's piece of global memory
+// (HBM: every array; LISTS_GLOBAL: the two entry lists + group descriptors; else unused).  `lds_cap`: 0, or a pretended
+// LDS size for the plain LDS form (test switch: exercises the hand-back chain on small tables).  Returns through any of
+// its early exits with scores / status of the item written by thread 0 and returns the status word (the same value in
+// every thread: all exit conditions are uniform); the caller barriers before LDS is reused.
+template <bool HBM, bool WIDE, bool LISTS_GLOBAL>
+__device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, const AlDesc* __restrict__ als, int ai,
+                                              int sid, int n, const SplitDev* __restrict__ splits, int S,
+                                              double* __restrict__ scores_all, int* __restrict__ status_all,
+                                              unsigned char* __restrict__ slab, size_t slab_bytes, size_t lds_cap,
+                                              int wide_cap) {
     SpkShared& sh = *reinterpret_cast<SpkShared*>(smem);
     // wide fallback block (HBM form only: its LDS holds nothing but SpkShared, so the Jacobi workspace sits behind it)
     constexpr bool wide_on = HBM && WIDE;   // (its own instantiation: the extra live state must not cost the others registers)
     EigShared& esh = *reinterpret_cast<EigShared*>(smem + ((sizeof(SpkShared) + 15) & ~(size_t)15));
     constexpr int NBC = wide_on ? SPK_WB : SPK_NB;
-    unsigned char* const base = HBM ? slabs + (size_t)blockIdx.x * slab_bytes : smem;
-    // (LDS form: slab_bytes = debug cap;  LISTS_GLOBAL: the LDS form with its two entry lists - written once, read
-    // sequentially - in a small slab of global memory, which is what lets a 13 k-pattern table keep its staging arrays,
-    // counters and the V / W blocks in LDS)
+    unsigned char* const base = HBM ? slab : smem;
+    // (LISTS_GLOBAL: the LDS form with its two entry lists - written once, read sequentially - in a small slab of
+    // global memory, which is what lets a 13 k-pattern table keep its staging arrays, counters and the V / W blocks in LDS)
     static_assert(!(HBM && LISTS_GLOBAL), "LISTS_GLOBAL is a variant of the LDS form");
-    const size_t cap = HBM ? slab_bytes : ((slab_bytes && !LISTS_GLOBAL) ? slab_bytes : (size_t)SPK_LDS_BYTES);
-    const int ai = blockIdx.x % n_al;
-    const int sid = order[blockIdx.x / n_al];
+    const size_t cap = HBM ? slab_bytes : ((lds_cap && !LISTS_GLOBAL) ? lds_cap : (size_t)SPK_LDS_BYTES);
     const u32* __restrict__ keys = als[ai].keys32;
     const u32* __restrict__ counts = als[ai].counts;
     const SpkMeta* __restrict__ meta = als[ai].meta;
@@ -892,14 +892,14 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             scores[sid] = 0.0;
             status[sid] = 2;
         }
-        return;
+        return 2;
     }
     (void)kc_cap;
     SSTAMP(0);
     // region A (persistent): CSC list, CSR list.  Region B: staging + bitmaps while building, then V and W (or G).
     // Sizes that depend on R / Kc are carved after the ranks are known.
     const size_t list_bytes = ((size_t)(D + 8) * 4 + 15) & ~(size_t)15;   // + 8: the unpredicated tail reads of the products
-    unsigned char* const lslab = LISTS_GLOBAL ? slabs + (size_t)blockIdx.x * slab_bytes : nullptr;
+    unsigned char* const lslab = LISTS_GLOBAL ? slab : nullptr;
     // (LISTS_GLOBAL: the group descriptors / permutations of both lists - read in sequence by the products - go there too)
     const size_t gdesc_bytes = (((size_t)max((long long)D, 1024ll) + 2) * 2 + 15) & ~(size_t)15;
     if (LISTS_GLOBAL && 2 * list_bytes + 4 * gdesc_bytes > slab_bytes) {
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             scores[sid] = 0.0;
             status[sid] = 2;
         }
-        return;
+        return 2;
     }
     u32* csc_ent = LISTS_GLOBAL ? reinterpret_cast<u32*>(lslab) : reinterpret_cast<u32*>(carve((size_t)(D + 8) * 4));
     u32* csr_ent = small_sure ? nullptr
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         }
         return true;
     };
-    if (degenerate(raw_r ? 5 : R, raw_c ? 5 : Kc)) return;
+    if (degenerate(raw_r ? 5 : R, raw_c ? 5 : Kc)) return 0;
     if (!both_raw) {   // compact coordinates in place: pc[i] = rr << 16 | cc (8 look-ups in flight per thread)
         for (int base = 0; base < Di; base += SPK_THREADS * 8) {
             u32 cell[8], rr[8], cc[8];
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             scores[sid] = 0.0;
             status[sid] = 2;
         }
-        return;
+        return 2;
     }
     u32* const cw_lds = reinterpret_cast<u32*>(smem + lds_used);
     u32* cwbuf = cwc_lds ? cw_lds : reinterpret_cast<u32*>(base + build_end);
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
                                         cwbuf_r, ns_r, sh);
     SSTAMP(3);
     // ids in use on raw sides (small path: the used rows are the non-zero diagonal entries of G, checked below)
-    if (degenerate(small ? 5 : sh.used_r, sh.used_c)) return;
+    if (degenerate(small ? 5 : sh.used_r, sh.used_c)) return 0;
     // ---- start block: unit vectors on the rows of the 4 largest counts (distinct rows) ----------------------------
     // (the dominant singular vectors of a count flattening sit on the few very frequent patterns); chosen by four
     // rounds of a block arg-max over (count, index), deterministic tie-break.
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
             if (threadIdx.x == 0) sh.used_r = (int)__popcll(nzd);
         }
         __syncthreads();
-        if (degenerate(sh.used_r, 5)) return;
+        if (degenerate(sh.used_r, 5)) return 0;
     }
     // ---- iteration: alternate half products, one Ritz sum per half product -------------------------------------
     //   h odd :  W = C^T V  (V orthonormal)  ->  trace(W^T W) = trace(V^T C C^T V) = Ritz sum of C C^T on span(V)
@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         }
     } else {
         SSTAMP(7);
-        const int maxhalf = wide_on ? SPK_MAXHALF_WIDE : SPK_MAXHALF;
+        const int maxhalf = wide_on ? (wide_cap > 0 ? wide_cap : SPK_MAXHALF_WIDE) : SPK_MAXHALF;
         for (it = 2; it <= maxhalf; ++it) {
             // (one call site: the product code is inlined once, the kernel has to stay inside the 64 KB instruction cache;
             // the wide block makes two 4-column passes)
@@ -1379,18 +1379,125 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __re
         }
     }
     SSTAMP(11);
+    // no spectral gap behind the 4th value (conv == 0): the Ritz sum so far is a lower bound of the top-4 sum, so the
+    // score written is an upper estimate; status bit 1 hands the split on (wide block / dense route), the wide block
+    // - the last resort - flags it with bit 0 instead.
+    const int code = conv ? (it << 8) : ((wide_on ? 1 : 2) | (it << 8));
     if (threadIdx.x == 0) {
-        if (conv) {
-            const double op = 1.0 - top4 / trace;
-            scores[sid] = sqrt(op > 0 ? op : 0.0);
-            status[sid] = it << 8;
-        } else {
-            // no spectral gap behind the 4th value: let the 16-wide dense route do it.  The Ritz sum so far is a lower
-            // bound of the top-4 sum, so this is an upper estimate of the score: the host keeps it (status bit 0) for
-            // shapes the dense route cannot take.
-            const double op = 1.0 - top4 / trace;
-            scores[sid] = sqrt(op > 0 ? op : 0.0);
-            status[sid] = (wide_on ? 1 : 2) | (it << 8);   // (the wide block is the last resort: flagged, not handed on)
+        const double op = 1.0 - top4 / trace;
+        scores[sid] = sqrt(op > 0 ? op : 0.0);
+        status[sid] = code;
+    }
+    return code;
+}
+
+// ---- the kernels around spk_score_one ---------------------------------------------------------------------------------
+// k_sparse_score: grid = n_al * S workgroups, block b scores split order[b / n_al] of alignment b % n_al (heaviest
+// splits of every alignment first) in the in-LDS form; score / status index = alignment * S + split.  Block 0 also
+// zeroes the work-queue head of the slow kernel queued behind it on the same stream.
+__global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __restrict__ als, int n_al, int n,
+                                                              const SplitDev* __restrict__ splits,
+                                                              const int* __restrict__ order, int S,
+                                                              double* __restrict__ scores_all,
+                                                              int* __restrict__ status_all, int* __restrict__ queue_head,
+                                                              size_t lds_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (queue_head && blockIdx.x == 0 && threadIdx.x == 0) *queue_head = 0;
+    (void)spk_score_one<false, false, false>(smem, als, (int)(blockIdx.x % n_al), order[blockIdx.x / n_al], n, splits, S,
+                                             scores_all, status_all, nullptr, 0, lds_cap, 0);
+}
+
+// k_sparse_slow: the hand-back chain ON THE DEVICE, queued behind k_sparse_score - no host round trip.  A fixed grid of
+// persistent workgroups, each with its own slab of global memory for its whole life (a slab never changes CU, so plain
+// loads / stores stay coherent through that CU's L1 and its XCD's L2), draws chunks of consecutive items from an atomic
+// head and takes the items whose status word asks for it:
+//   status == 2 ("does not fit the LDS form", no half product run): the lists-in-global form, then the all-global form;
+//   status 2 + half products (the 4-wide block found no certified gap): the 8-wide block - always when `wide_all`, else
+//   only when the smaller side is beyond the dense route's EIG_MAXR rows (the synchronous entry point hands the others
+//   to the dense route).
+// The three forms are real (non-inlined) functions.  Every workgroup ends on its one failed draw; a pass with nothing to
+// do costs each of its (few) workgroups one atomic and one status load.
+struct SpkSlow {
+    int* head;
+    unsigned char* slabs;
+    size_t slab_stride;              // bytes per workgroup
+    size_t slab_l, slab_h, slab_w;   // what the lists-in-global / all-global / wide forms may use of it
+    int chunk;                       // items per draw
+    int wide_all;
+    int wide_cap;                    // half-product cap of the wide block (0 = SPK_MAXHALF_WIDE; tests of SP_ENOCONV lower it)
+};
+
+template <bool HBM, bool WIDE, bool LISTS_GLOBAL>
+__device__ __noinline__ int spk_score_slow(const AlDesc* __restrict__ als, int ai, int sid, int n,
+                                           const SplitDev* __restrict__ splits, int S, double* __restrict__ scores_all,
+                                           int* __restrict__ status_all, unsigned char* __restrict__ slab,
+                                           size_t slab_bytes, int wide_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    return spk_score_one<HBM, WIDE, LISTS_GLOBAL>(smem, als, ai, sid, n, splits, S, scores_all, status_all, slab, slab_bytes,
+                                                  0, wide_cap);
+}
+
+__global__ __launch_bounds__(SPK_THREADS) void k_sparse_slow(const AlDesc* __restrict__ als, int n_al, int n,
+                                                             const SplitDev* __restrict__ splits, int S,
+                                                             double* __restrict__ scores_all,
+                                                             int* __restrict__ status_all, SpkSlow q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    SpkShared& sh = *reinterpret_cast<SpkShared*>(smem);
+    unsigned char* const slab = q.slabs + (size_t)blockIdx.x * q.slab_stride;
+    const int total = n_al * S;
+    const int nchunks = (total + q.chunk - 1) / q.chunk;
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        __syncthreads();   // the previous item is finished with the LDS
+        if (threadIdx.x == 0) sh.qchunk = atomicAdd(q.head, 1);
+        __syncthreads();
+        const int chunk = sh.qchunk;
+        if (chunk >= nchunks) break;   // (uniform: every workgroup ends on its one failed draw)
+        const int item = chunk * q.chunk + lane;   // (q.chunk <= 64: one status word per lane, the same in every wave)
+        bool want = false;
+        int st_mine = 0;
+        if (lane < q.chunk && item < total) {
+            const int st = st_mine = status_all[item];
+            want = st == 2;
+            if (!want && (st & 2) && (st >> 8) != 0) {
+                want = q.wide_all != 0;
+                if (!want) {
+                    const SplitDev& sp = splits[item % S];
+                    const long long side = 1ll << (2 * min(sp.nr, sp.nc));
+                    const long long rmax = min(side, (long long)als[item / S].D);
+                    want = ((rmax + 63) & ~63ll) > EIG_MAXR;
+                }
+            }
+        }
+        unsigned long long mask = __ballot(want);
+        while (mask) {
+            const int b = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int it = chunk * q.chunk + b;
+            const int ai = it / S, sid = it % S;
+            int st = __shfl(st_mine, b, 64);
+            if (st == 2) {
+                __syncthreads();
+                st = spk_score_slow<false, false, true>(als, ai, sid, n, splits, S, scores_all, status_all, slab, q.slab_l, 0);
+            }
+            if (st == 2) {
+                __syncthreads();
+                st = spk_score_slow<true, false, false>(als, ai, sid, n, splits, S, scores_all, status_all, slab, q.slab_h, 0);
+            }
+            if ((st & 2) && (st >> 8) != 0) {
+                bool wide = q.wide_all != 0;
+                if (!wide) {
+                    const SplitDev& sp = splits[sid];
+                    const long long side = 1ll << (2 * min(sp.nr, sp.nc));
+                    const long long rmax = min(side, (long long)als[ai].D);
+                    wide = ((rmax + 63) & ~63ll) > EIG_MAXR;
+                }
+                if (wide) {
+                    __syncthreads();
+                    (void)spk_score_slow<true, true, false>(als, ai, sid, n, splits, S, scores_all, status_all, slab, q.slab_w,
+                                                            q.wide_cap);
+                }
+            }
         }
     }
 }
@@ -1457,48 +1564,11 @@ int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t 
     return SP_OK;
 }
 
-int launch_sparse_score(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,
-                        const int* order_dev, int64_t S, double* scores, int* status) {
-    if (S == 0) return SP_OK;
-    if (ctx->upload_ev) SP_HIP(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
-    PhaseScope ps(ctx, SP_PHASE_SPARSE);
-    static bool attr = false;
-    if (!attr) {
-        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_score<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_BYTES));
-        attr = true;
-    }
-    hipLaunchKernelGGL(k_sparse_score<false>, dim3((unsigned)(S * n_al)), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream,
-                       als_dev, n_al, n_taxa, splits_dev, order_dev, (int)S, scores, status, (unsigned char*)nullptr,
-                       getenv("SPLITP_DEBUG_LDS_CAP") ? (size_t)atol(getenv("SPLITP_DEBUG_LDS_CAP")) : (size_t)0);
-    SP_HIP(hipGetLastError());
-    return SP_OK;
-}
-
-// The LDS form with its entry lists in global memory (k_sparse_score<false, false, true>): the splits listed in
-// order_dev[0 .. S_sub), one alignment; slab_bytes >= sparse_list_slab_bytes(D) per workgroup.
+// Bytes of global memory one workgroup of the lists-in-global form needs (two entry lists + four descriptor arrays).
 size_t sparse_list_slab_bytes(int64_t D) {
     const size_t list_bytes = ((size_t)(D + 8) * 4 + 15) & ~(size_t)15;
     const size_t gdesc_bytes = (((size_t)std::max<int64_t>(D, 1024) + 2) * 2 + 15) & ~(size_t)15;
     return (2 * list_bytes + 4 * gdesc_bytes + 255) & ~(size_t)255;
-}
-
-int launch_sparse_score_lists(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, const SplitDev* splits_dev,
-                              const int* order_dev, int64_t S_sub, int64_t S, double* scores, int* status,
-                              unsigned char* slabs, size_t slab_bytes) {
-    if (S_sub == 0) return SP_OK;
-    if (ctx->upload_ev) SP_HIP(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
-    PhaseScope ps(ctx, SP_PHASE_SPARSE);
-    static bool attr = false;
-    if (!attr) {
-        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_score<false, false, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_BYTES));
-        attr = true;
-    }
-    hipLaunchKernelGGL((k_sparse_score<false, false, true>), dim3((unsigned)S_sub), dim3(SPK_THREADS), SPK_LDS_BYTES,
-                       ctx->stream, als_dev, 1, n_taxa, splits_dev, order_dev, (int)S, scores, status, slabs, slab_bytes);
-    SP_HIP(hipGetLastError());
-    return SP_OK;
 }
 
 // Bytes of global memory one workgroup of the HBM form needs for a table of D patterns whose bitmaps take `bm_words`
@@ -1509,28 +1579,50 @@ size_t sparse_slab_bytes(int64_t D, int64_t bm_words, bool wide) {
            (size_t)D * 2 + 65536;
 }
 
-// The splits listed in order_dev[0 .. S_sub) (indices into the split / score arrays), one alignment, HBM form.
-int launch_sparse_score_hbm(sp_ctx* ctx, const AlDesc* als_dev, int n_taxa, const SplitDev* splits_dev,
-                            const int* order_dev, int64_t S_sub, int64_t S, double* scores, int* status,
-                            unsigned char* slabs, size_t slab_bytes, bool wide) {
-    if (S_sub == 0) return SP_OK;
-    if (ctx->upload_ev) SP_HIP(hipStreamWaitEvent(ctx->stream, ctx->upload_ev, 0));
-    PhaseScope ps(ctx, SP_PHASE_SPARSE);
-    const size_t lds = SPK_LDS_BYTES;   // SpkShared + the Jacobi workspace of the wide block + the sort counters
-    static bool attr_h = false;
-    if (!attr_h) {
-        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_score<true, true>),
+// The whole sparse route for n_al alignments x S splits on the context's stream, no host synchronisation: the in-LDS
+// kernel, and queued behind it the slow kernel that finishes - on the device - whatever the first one handed back.
+// d_max / bm_words_max: largest table / bitmap size among the items (slab sizing).  wide_all: see k_sparse_slow.
+// Afterwards a status word has bit 1 set only for splits left to the dense route (wide_all = false).
+int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,
+                        const int* order_dev, int64_t S, double* scores, int* status, int64_t d_max, int64_t bm_words_max,
+                        bool wide_all) {
+    if (S == 0 || n_al == 0) return SP_OK;
+    const int64_t n_items = S * n_al;
+    SP_REQUIRE(n_items < ((int64_t)1 << 31), SP_ELIMIT, "sparse route: %lld items in one call (limit 2^31)", (long long)n_items);
+    static bool attr = false;
+    if (!attr) {
+        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_score),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_BYTES));
-        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_score<true, false>),
+        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_slow),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_BYTES));
-        attr_h = true;
+        attr = true;
     }
-    if (wide)
-        hipLaunchKernelGGL((k_sparse_score<true, true>), dim3((unsigned)S_sub), dim3(SPK_THREADS), lds, ctx->stream, als_dev,
-                           1, n_taxa, splits_dev, order_dev, (int)S, scores, status, slabs, slab_bytes);
-    else
-        hipLaunchKernelGGL((k_sparse_score<true, false>), dim3((unsigned)S_sub), dim3(SPK_THREADS), lds, ctx->stream, als_dev,
-                           1, n_taxa, splits_dev, order_dev, (int)S, scores, status, slabs, slab_bytes);
+    SpkSlow q{};
+    q.slab_l = sparse_list_slab_bytes(d_max);
+    q.slab_h = (sparse_slab_bytes(d_max, bm_words_max, false) + 255) & ~(size_t)255;
+    q.slab_w = (sparse_slab_bytes(d_max, bm_words_max, true) + 255) & ~(size_t)255;
+    q.slab_stride = std::max(q.slab_l, std::max(q.slab_h, q.slab_w));
+    // few items: a handful of workgroups scan them in large chunks (an empty pass is all but free); many: one workgroup
+    // per CU drawing small chunks (balance).  Huge slabs shrink the grid (8 GB pool at most).
+    q.chunk = n_items >= 16384 ? 8 : 64;
+    const int64_t nchunks = (n_items + q.chunk - 1) / q.chunk;
+    int grid = (int)std::min<int64_t>(ctx->n_cu, nchunks);
+    grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, std::max<int64_t>(16, ((int64_t)8 << 30) / (int64_t)q.slab_stride)));
+    SP_CHECK(ctx->slabs.ensure((size_t)grid * q.slab_stride));
+    SP_CHECK(ctx->chain.ensure(64));
+    q.head = ctx->chain.as<int>();
+    q.slabs = ctx->slabs.as<unsigned char>();
+    q.wide_all = wide_all ? 1 : 0;
+    q.wide_cap = ctx->opt.wide_cap;
+    {
+        PhaseScope ps(ctx, SP_PHASE_SPARSE);
+        hipLaunchKernelGGL(k_sparse_score, dim3((unsigned)n_items), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream, als_dev,
+                           n_al, n_taxa, splits_dev, order_dev, (int)S, scores, status, q.head, (size_t)ctx->opt.lds_cap);
+        SP_HIP(hipGetLastError());
+    }
+    PhaseScope ps(ctx, SP_PHASE_CHAIN);
+    hipLaunchKernelGGL(k_sparse_slow, dim3((unsigned)grid), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream, als_dev, n_al,
+                       n_taxa, splits_dev, (int)S, scores, status, q);
     SP_HIP(hipGetLastError());
     return SP_OK;
 }

@@ -110,6 +110,7 @@ static int ensure_moments(sp_alignment* al) {
 }
 
 extern "C" int sp_moment_matrix(sp_alignment* al, int64_t* out_i64, double* out_f64) {
+    return sp_guard("sp_moment_matrix", [&]() -> int {
     SP_REQUIRE(al, SP_EINVAL, "alignment is NULL");
     sp_ctx* ctx = al->ctx;
     SP_HIP(hipSetDevice(ctx->device));
@@ -125,6 +126,7 @@ extern "C" int sp_moment_matrix(sp_alignment* al, int64_t* out_i64, double* out_
         SP_HIP(hipMemcpy(out_f64, al->moments.p, (size_t)m * m * 8, hipMemcpyDeviceToHost));
     }
     return SP_OK;
+    });
 }
 
 // idx(S) + [3n] for one split half
@@ -149,6 +151,7 @@ __global__ void k_subflatten_gather(const void* __restrict__ Mv, int n, double N
 }
 
 extern "C" int sp_subflatten(sp_alignment* al, const int32_t* oa, int a, const int32_t* ob, int b, double* out_host) {
+    return sp_guard("sp_subflatten", [&]() -> int {
     SP_REQUIRE(al && oa && ob && out_host, SP_EINVAL, "NULL argument");
     sp_ctx* ctx = al->ctx;
     SP_HIP(hipSetDevice(ctx->device));
@@ -185,6 +188,7 @@ extern "C" int sp_subflatten(sp_alignment* al, const int32_t* oa, int a, const i
     SP_HIP(hipMemcpyAsync(out_host, ctx->misc2.p, (size_t)R * C * 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;
+    });
 }
 
 // ---- batched score of subflattenings: one wave per split ------------------------------------------
@@ -684,7 +688,7 @@ static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da,
     SP_CHECK(ctx->status.ensure((size_t)S * 4));
     PhaseScope ps(ctx, SP_PHASE_SUBSCORE);
     const int mdim = 3 * n + 1;
-    if (mdim <= SUBT_MMAX && rmax <= 32 && !getenv("SPLITP_SUBSCORE_JACOBI")) {   // fast form (the env switch keeps the Jacobi kernel testable)
+    if (mdim <= SUBT_MMAX && rmax <= 32 && !ctx->opt.subscore_jacobi) {   // fast form (the option keeps the Jacobi kernel testable)
         const bool m32 = al->exact && al->N < ((int64_t)1 << 31);
         const size_t lds_t = (((size_t)mdim * mdim * (m32 ? 4 : 8) + 15) & ~(size_t)15) + (size_t)SUBT_WAVES * sizeof(SubtWave);
         int dev_cus = 256;

@@ -20,14 +20,19 @@ class Context:
     """One sp_ctx per (device); kernels run on torch's current stream for that device when
     torch sees the GPU, else on a private stream."""
 
-    def __init__(self, device: int):
+    def __init__(self, device: int, stream=None):
+        """stream: a raw hipStream_t value (int) this context stays bound to - a *lane*: several contexts, one per
+        stream, keep several sp_score_plan_async calls in flight (each has its own work memory; plans and alignments
+        are shared read-only).  Default: follow torch's current stream."""
         lib = _lib.load()
         _lib.require_gpu()
         self.device = device
         self._lib = lib
         self.handle = C.c_void_p()
-        _lib.check(lib.sp_ctx_create(device, self._torch_stream(device), C.byref(self.handle)))
-        self._stream = self._torch_stream(device)
+        self.pinned = stream is not None
+        s = C.c_void_p(stream) if self.pinned else self._torch_stream(device)
+        _lib.check(lib.sp_ctx_create(device, s, C.byref(self.handle)))
+        self._stream = s
         self._fin = weakref.finalize(self, lib.sp_ctx_destroy, self.handle)
 
     @staticmethod
@@ -41,18 +46,26 @@ class Context:
             pass
         return None
 
-    def sync_stream_with_torch(self, ordered=True):
-        """Adopt torch's current stream.  ordered=False skips the drain of the previous stream (lanes: several
-        asynchronous scoring steps in flight, see sp_ctx_set_stream_unordered)."""
+    def sync_stream_with_torch(self):
+        """Adopt torch's current stream (drains the previous one first).  A lane context keeps its own stream."""
+        if self.pinned:
+            return
         s = self._torch_stream(self.device)
         cur = None if s is None else s.value
         old = None if self._stream is None else self._stream.value
         if cur != old:
-            if ordered or s is None:
-                _lib.check(self._lib.sp_ctx_set_stream(self.handle, s))
-            else:
-                _lib.check(self._lib.sp_ctx_set_stream_unordered(self.handle, s))
+            _lib.check(self._lib.sp_ctx_set_stream(self.handle, s))
             self._stream = s
+
+    def set_option(self, name, value):
+        """Test / tuning switch of the library (include/splitp_hip.h sp_ctx_set_option): 'force_big', 'big_by_keys',
+        'subscore_jacobi', 'divergence_global', 'hist_sort' (-1 auto / 0 / 1), 'lds_cap' (bytes), 'wide_cap'."""
+        _lib.check(self._lib.sp_ctx_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int64()
+        _lib.check(self._lib.sp_ctx_get_option(self.handle, name.encode(), C.byref(v)))
+        return v.value
 
     def synchronize(self):
         _lib.check(self._lib.sp_ctx_synchronize(self.handle))

@@ -67,3 +67,67 @@ def test_sharded_scores_all_gather_gloo(tmp_path):
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     res = np.load(out)
     assert res[0] == 1 and res[1] == 2 ** 5 - 6 - 1
+
+
+def _worker_score_splits(rank, world, port, out_path):
+    """The real batch.score_splits(distributed=True) code path - shard plan, per-rank scoring call, ONE all_gather of
+    the packed scores + status, un-permute, warning - with only the device scorer stubbed (no GPU here)."""
+    import warnings
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import splitp_oracle as O
+    from splitp_amd import batch
+    from splitp_amd import synthetic as syn
+
+    n = 6
+    names = syn.taxa_names(n)
+    sites = syn.simulate_sites(n, 2000, 0.05, seed=5)
+    keys, counts = syn.pattern_table(sites)
+    splits = list(O.all_splits(names))
+
+    class FakeAlignment:
+        n_taxa = n
+        taxa = tuple(names)
+
+    calls = []
+
+    def fake_score_encoded(al, split_taxa, split_a, method_code, scores_dev_ptr=None, want_host=True):
+        calls.append(len(split_a))
+        sc = np.array([O.score_from_matrix_gram(O.reduced_flattening_packed(
+            keys, counts, n, split_taxa[i, : split_a[i]], split_taxa[i, split_a[i]:])[0].astype(float))
+            for i in range(len(split_a))])
+        st = (np.arange(len(split_a), dtype=np.int32) + 7) << 8           # "operator applications" per split
+        if rank == 1 and len(st):
+            st[0] |= 1                                                     # one unconverged split on rank 1
+        return sc, st
+
+    batch.score_encoded = fake_score_encoded
+    batch.as_device_alignment = lambda table, device=None: FakeAlignment()
+    fake = FakeAlignment()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        scores, status = batch.score_splits(fake, splits, distributed=True, return_status=True)
+        only_scores = batch.score_splits(fake, splits, distributed=True)
+    warned = sum(issubclass(w.category, RuntimeWarning) for w in caught)
+    full = np.array([O.score_from_matrix_gram(O.reduced_flattening_packed(
+        keys, counts, n, list(map(names.index, s[0])), list(map(names.index, s[1])))[0].astype(float)) for s in splits])
+    ok = (np.array_equal(scores, full) and np.array_equal(only_scores, full) and status.dtype == np.int32
+          and int(np.count_nonzero(status & 1)) == 1 and np.all(status >> 8 >= 7) and warned == 2
+          and len(calls) == 2 and calls[0] < len(splits))
+    tchk = torch.tensor([float(ok)])
+    dist.all_reduce(tchk, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        np.save(out_path, np.array([int(tchk.item()), len(splits), calls[0]], dtype=np.int64))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_score_splits_distributed_path_gloo(tmp_path):
+    out = str(tmp_path / "res2.npy")
+    port = _free_port()
+    mp.spawn(_worker_score_splits, args=(2, port, out), nprocs=2, join=True)
+    res = np.load(out)
+    assert res[0] == 1 and res[1] == 2 ** 5 - 6 - 1 and 0 < res[2] < res[1]

@@ -26,6 +26,16 @@ def sp():
     return splitp_amd
 
 
+@pytest.fixture(autouse=True)
+def _reset_context_options(sp):
+    """Test switches (sp_ctx_set_option) never leak from one test into the next."""
+    yield
+    ctx = sp.get_context()
+    for name, val in (("force_big", 0), ("big_by_keys", 0), ("subscore_jacobi", 0), ("divergence_global", 0),
+                      ("hist_sort", -1), ("lds_cap", 0), ("wide_cap", 0)):
+        ctx.set_option(name, val)
+
+
 def test_native_library_is_loaded(sp):
     # the product path is the in-tree .so, nothing else
     import os
@@ -238,13 +248,13 @@ def test_histogram_from_sequences(sp):
     assert np.array_equal(gk, k2) and np.array_equal(gc, c2)
     assert np.array_equal(gw, c2 / float(valid.sum()))
     # the two histogram forms (direct 4^n bins / radix sort + run-length encode) on the same input
-    import os
-    for force in ("1", "0"):
-        os.environ["SPLITP_HIST_SORT"] = force
+    ctx = sp.get_context()
+    for force in (1, 0):
+        ctx.set_option("hist_sort", force)
         try:
             d3 = sp.DeviceAlignment.from_sequences(seqs)
         finally:
-            del os.environ["SPLITP_HIST_SORT"]
+            ctx.set_option("hist_sort", -1)
         fk, fw, fc = d3.fetch()
         assert d3.info()["N"] == int(valid.sum()) and np.array_equal(fk, k2) and np.array_equal(fc, c2)
         assert np.array_equal(fw, gw)
@@ -344,7 +354,7 @@ def test_routes_agree(sp, golden):
     # counts >= 65536 exceed the 16-bit count field of the list entries: such patterns enter as several table rows whose
     # counts add up.  (a) a table that still fits LDS (short branches: few patterns, huge counts) - all size classes,
     # including the small-side Gram where the pieces of one count meet on one row; (b) a 700 k-site table: too many
-    # rows for LDS, so "sparse" (strict) refuses and auto runs the global-memory form of the kernel
+    # rows for LDS: the workgroups fall through to the global-memory forms of the kernel
     from splitp_amd import synthetic as syn
     sites = syn.simulate_sites(10, 600_000, 0.004, seed=8)
     keys, counts = syn.pattern_table(sites)
@@ -361,8 +371,11 @@ def test_routes_agree(sp, golden):
     keys, counts = syn.pattern_table(sites)
     assert counts.max() >= 65536
     big = sp.DeviceAlignment.from_arrays(keys, None, 10, counts=counts, n_sites=700_000, taxa=names)
-    with pytest.raises(NotImplementedError):
-        sp.score_splits(big, splits[:5], route="sparse")
+    # (the hand-back chain runs inside the kernel: "sparse" takes such a table too, in the global-memory forms)
+    # (25 k table rows, 2|8 splits: the column counters of the all-global form's sort sit in global memory, where the order
+    # in which one wave's atomics on a word are served is not fixed - groups are summed in a different order run to run,
+    # hence a tolerance here and not array_equal as for the forms whose counters are in LDS)
+    assert np.abs(sp.score_splits(big, splits[:5], route="sparse") - sp.score_splits(big, splits[:5])).max() <= 1e-13
     sb, stb = sp.score_splits(big, splits[::25], return_status=True)
     assert np.all((stb & 3) == 0) and np.all((stb >> 8) <= 8)          # scored by the sparse kernel (HBM form), not the dense route
     assert np.abs(sb - sp.score_splits(big, splits[::25], route="dense")).max() <= SCORE_TOL
@@ -386,8 +399,9 @@ def test_routes_agree(sp, golden):
 
 
 def test_async_entry_and_handback(sp, golden):
-    """sp_score_splits_async writes scores + status to device buffers without a host sync; flagged splits (status
-    bit 1) are the caller's to re-score (batch.finish_async)."""
+    """sp_score_splits_async writes scores + status to device buffers without a host sync, and the hand-back chain
+    runs ON THE DEVICE: once the stream has run no status word carries bit 1 - also on a table where every split needs
+    the last resort (the 8-wide block)."""
     import torch
     from splitp_amd import batch, _lib
 
@@ -401,9 +415,9 @@ def test_async_entry_and_handback(sp, golden):
     batch.score_encoded_async(dev, taxa_arr, a_arr, _lib.SP_METHOD_FLATTENING, sc.data_ptr(), st.data_ptr())
     torch.cuda.synchronize()
     s_h, st_h = sc.cpu().numpy(), st.cpu().numpy()
-    assert batch.finish_async(dev, taxa_arr, a_arr, s_h, st_h) == 0
+    assert not np.any(st_h & 3) and batch.finish_async(dev, taxa_arr, a_arr, s_h, st_h) == 0
     assert np.abs(s_h - g["scores"]).max() <= SCORE_TOL
-    # a gapless table: every split is handed back, finish_async repairs them
+    # a gapless table: the 4-wide block certifies nothing, the chain's wide block finishes every split on the device
     rng = np.random.default_rng(3)
     rk = np.unique(rng.integers(0, 4 ** 10, size=3000).astype(np.uint64))
     rc = rng.integers(1, 40, size=len(rk)).astype(np.int64)
@@ -414,9 +428,171 @@ def test_async_entry_and_handback(sp, golden):
     batch.score_encoded_async(flat, sub_t, sub_a, _lib.SP_METHOD_FLATTENING, sc2.data_ptr(), st2.data_ptr())
     torch.cuda.synchronize()
     s2, t2 = sc2.cpu().numpy(), st2.cpu().numpy()
-    n_redo = batch.finish_async(flat, sub_t, sub_a, s2, t2)
+    assert not np.any(t2 & 2) and (t2 >> 8).max() > 40          # past the 4-wide block's 40 half products
     ref = sp.score_splits(flat, [splits[i] for i in range(0, 501, 50)], route="dense")
-    assert n_redo > 0 and np.abs(s2 - ref).max() <= 1e-9
+    done = (t2 & 1) == 0
+    assert done.sum() > 0 and np.abs(s2 - ref)[done].max() <= 1e-9
+    # (a flat random spectrum on a SMALL side is where even the 8-wide block can run into its cap: flagged with status
+    # bit 0, an upper estimate - finish_async re-scores those through the synchronous entry point, whose hand-back goes
+    # to the dense route's 16-wide block for sides of up to 1024 rows)
+    assert np.all(s2[~done] >= ref[~done] - 1e-9)
+    assert batch.finish_async(flat, sub_t, sub_a, s2, t2) == int((~done).sum())
+    assert not np.any(t2 & 3) and np.abs(s2 - ref).max() <= 1e-9
+    # the synchronous entry point on the same table: small sides go to the dense route instead - same scores
+    assert np.abs(sp.score_splits(flat, [splits[i] for i in range(0, 501, 50)]) - ref).max() <= 1e-9
+
+
+def test_config5_one_device_pass(sp):
+    """BASELINE config 5 (batch of 32 simulated 12-taxon alignments x all 2035 splits, throughput mode) as ONE call:
+    65 120 items through the sparse route's device-side chain (in-LDS kernel -> lists in global memory -> all arrays in
+    global memory; a 100 k-site 12-taxon table has ~13.5 k patterns: the 5|7 and 6|6 splits do not fit the LDS form).
+    Equals 32 single-alignment calls bit for bit; >= 4 splits per size class of every alignment against the oracle's
+    restatement of the reference (reduced flattening + scipy SVD, constructions.py:31-55 + phylogenetics.py:280-300).
+    fp64 throughout (config 5's fp32 wording is not built: fp64 is the stricter choice)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from threadpoolctl import threadpool_limits
+    from splitp_amd import batch, _lib
+    from splitp_amd import simulation as sim
+    from splitp_amd import synthetic as syn
+
+    n, n_al, length = 12, 32, 100_000
+    names = taxa_names(n)
+    tree = syn.balanced_tree(n)
+    devs = []
+    for a in range(n_al):
+        d = sim.generate_device_alignment(tree, sim.JukesCantor(), length, seed=100 + a, branch_length=0.05)
+        d.taxa = tuple(names)
+        devs.append(d)
+    taxa_arr, a_arr = sp.encode_all_splits(n)
+    S = len(a_arr)
+    assert S == 2035
+    sc = torch.zeros(n_al * S, dtype=torch.float64, device="cuda")
+    st = torch.full((n_al * S,), -1, dtype=torch.int32, device="cuda")
+    batch.score_encoded_multi_async(devs, taxa_arr, a_arr, sc.data_ptr(), st.data_ptr())
+    torch.cuda.synchronize()
+    multi, status = sc.cpu().numpy().reshape(n_al, S), st.cpu().numpy().reshape(n_al, S)
+    assert not np.any(status & 3) and np.all(status >> 8 >= 1) and np.all(np.isfinite(multi))
+    # plan + lane form of the same pass (sp_score_plan_async on a second context) gives the same bits
+    plan = batch.SplitPlan(devs[0].ctx, taxa_arr, a_arr, n)
+    stream = torch.cuda.Stream()
+    from splitp_amd.device import Context
+    lane = Context(devs[0].ctx.device, stream=stream.cuda_stream)
+    sc_l = torch.zeros(n_al * S, dtype=torch.float64, device="cuda")
+    st_l = torch.zeros(n_al * S, dtype=torch.int32, device="cuda")
+    batch.score_plan_async(lane, devs, plan, sc_l.data_ptr(), st_l.data_ptr())
+    stream.synchronize()
+    assert np.array_equal(sc_l.cpu().numpy().reshape(n_al, S), multi)
+    # 32 single calls (the synchronous entry point with its own hand-back): bit for bit
+    for a in (0, 1, 13, 31):
+        one, st1 = batch.score_encoded(devs[a], taxa_arr, a_arr, _lib.SP_METHOD_FLATTENING)
+        assert np.array_equal(one, multi[a]) and not np.any(st1 & 3), a
+    one_by_one = np.stack([batch.score_encoded(d, taxa_arr, a_arr, _lib.SP_METHOD_FLATTENING)[0] for d in devs])
+    assert np.array_equal(one_by_one, multi)
+    # oracle: 4 splits per size class (k = 2..6) of every alignment
+    k_of = np.minimum(a_arr, n - a_arr)
+    rng = np.random.default_rng(5)
+    jobs = []
+    for a, d in enumerate(devs):
+        keys, w, cnt = d.fetch()
+        for k in range(2, 7):
+            for i in rng.choice(np.nonzero(k_of == k)[0], size=4, replace=False):
+                jobs.append((a, int(i), keys, cnt))
+
+    def check(job):
+        a, i, keys, cnt = job
+        m = O.reduced_flattening_packed(keys, cnt.astype(np.float64), n, list(taxa_arr[i, :a_arr[i]]),
+                                        list(taxa_arr[i, a_arr[i]:]))[0]
+        return abs(O.dense_split_score(m) - multi[a, i])
+
+    with threadpool_limits(limits=4):
+        with ThreadPoolExecutor(4) as pool:
+            errs = list(pool.map(check, jobs))
+    assert len(errs) == n_al * 20 and max(errs) <= SCORE_TOL, max(errs)
+
+
+def test_lanes_share_plan_and_alignment(sp, golden):
+    """Three lane contexts (one HIP stream each) score the same alignment with one shared immutable plan, several calls
+    in flight: every result equals the single-stream result bit for bit (sparse route), and the dense route driven
+    through per-lane ALIGNMENTS' own contexts is unaffected by the neighbours (the old unordered-lane API
+    raced on the dense route's pools - it is gone)."""
+    import torch
+    from splitp_amd import batch, _lib
+    from splitp_amd.device import Context
+
+    g = golden("n10_L100k")
+    names = taxa_names(10)
+    splits = [mask_to_split(int(m), 10, names) for m in g["masks"]]
+    dev = sp.DeviceAlignment.from_table(O.unpack_table(g["keys"], g["probs"], 10), taxa=names)
+    taxa_arr, a_arr = batch.encode_splits(splits, dev, 10)
+    base, st0 = batch.score_encoded(dev, taxa_arr, a_arr, _lib.SP_METHOD_FLATTENING_SPARSE)
+    plan = batch.SplitPlan(dev.ctx, taxa_arr, a_arr, 10)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    lanes = [Context(dev.ctx.device, stream=s.cuda_stream) for s in streams]
+    outs = [[(torch.zeros(501, dtype=torch.float64, device="cuda"), torch.zeros(501, dtype=torch.int32, device="cuda"))
+             for _ in range(4)] for _ in lanes]
+    for rep in range(4):
+        for li, lane in enumerate(lanes):
+            sc, st = outs[li][rep]
+            batch.score_plan_async(lane, [dev], plan, sc.data_ptr(), st.data_ptr())
+    torch.cuda.synchronize()
+    for li in range(3):
+        for rep in range(4):
+            assert np.array_equal(outs[li][rep][0].cpu().numpy(), base), (li, rep)
+            assert not np.any(outs[li][rep][1].cpu().numpy() & 3)
+    assert np.abs(base - g["scores"]).max() <= SCORE_TOL
+    # dense route: asynchronous entry point on the alignment's own context, back to back - ordered on one stream
+    dsc = [torch.zeros(501, dtype=torch.float64, device="cuda") for _ in range(3)]
+    dst = [torch.zeros(501, dtype=torch.int32, device="cuda") for _ in range(3)]
+    for i in range(3):
+        batch.score_encoded_async(dev, taxa_arr, a_arr, _lib.SP_METHOD_FLATTENING_DENSE, dsc[i].data_ptr(), dst[i].data_ptr())
+    torch.cuda.synchronize()
+    d0 = dsc[0].cpu().numpy()
+    assert np.array_equal(d0, dsc[1].cpu().numpy()) and np.array_equal(d0, dsc[2].cpu().numpy())
+    assert np.abs(d0 - g["scores"]).max() <= SCORE_TOL
+
+
+def test_enoconv_is_reported(sp):
+    """A split that exhausts the whole chain keeps its estimate and is REPORTED: the C ABI returns SP_ENOCONV (5) with
+    scores and status written (status bit 0), the Python layer turns that into a RuntimeWarning.  Forced here by capping
+    the last resort's half products (option wide_cap) on a 12-taxon table whose splits need the 8-wide block
+    (test_wide_block_fallback_12_taxa's table)."""
+    import ctypes as C
+    import warnings
+    from splitp_amd import _lib, batch
+
+    rng = np.random.default_rng(1)
+    n = 12
+    keys, counts = _copy_mutate_table(rng, n, 20000, 3)
+    names = taxa_names(n)
+    dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=int(counts.sum()), taxa=names)
+    splits = []
+    for _ in range(16):
+        k = int(rng.integers(2, n - 1))
+        left = sorted(rng.choice(n, size=k, replace=False).tolist())
+        splits.append((tuple(names[t] for t in left), tuple(names[t] for t in range(n) if t not in left)))
+    taxa_arr, a_arr = batch.encode_splits(splits, dev, n)
+    good, st_good = batch.score_encoded(dev, taxa_arr, a_arr, _lib.SP_METHOD_FLATTENING)
+    wide = np.nonzero((st_good >> 8) > 41)[0]
+    assert len(wide) > 0 and not np.any(st_good & 3)
+    t2, a2 = np.ascontiguousarray(taxa_arr[wide]), np.ascontiguousarray(a_arr[wide])
+    dev.ctx.set_option("wide_cap", 6)
+    assert dev.ctx.get_option("wide_cap") == 6
+    scores = np.zeros(len(wide))
+    status = np.zeros(len(wide), dtype=np.int32)
+    rc = dev.ctx._lib.sp_score_splits(dev.handle, _lib._ptr(t2, C.c_int32), _lib._ptr(a2, C.c_int32), len(wide),
+                                      _lib.SP_METHOD_FLATTENING, _lib._ptr(scores, C.c_double), None,
+                                      _lib._ptr(status, C.c_int32))
+    assert rc == _lib.SP_ENOCONV and np.all(status & 1) and not np.any(status & 2)
+    assert b"iteration cap" in dev.ctx._lib.sp_last_error()
+    assert np.all(np.isfinite(scores)) and np.all(scores >= good[wide] - 1e-9)      # upper estimates of the scores
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        est, st = batch.score_encoded(dev, t2, a2, _lib.SP_METHOD_FLATTENING)
+    assert any(issubclass(w.category, RuntimeWarning) for w in caught) and np.all(st & 1) and np.array_equal(est, scores)
+    dev.ctx.set_option("wide_cap", 0)
+    back, st_back = batch.score_encoded(dev, t2, a2, _lib.SP_METHOD_FLATTENING)
+    assert np.array_equal(back, good[wide]) and not np.any(st_back & 3)
 
 
 def test_multi_alignment_launch_matches_single(sp, golden):
@@ -533,12 +709,11 @@ def test_mutual_information_score(sp, golden):
         ob = [names.index(t) for t in all_splits_[i][1]]
         assert abs(O.rank1_divergence_packed(g2["keys"], g2["probs"], 10, oa, ob) - got2[i]) <= SCORE_TOL
     # the fused kernel (marginals in LDS) against the global-memory form it replaced for count tables: identical sums
-    import os
-    os.environ["SPLITP_DIVERGENCE_GLOBAL"] = "1"
+    sp.get_context().set_option("divergence_global", 1)
     try:
         glob2 = sp.score_splits(dev2, all_splits_, method=sp.Method.mutual_information)
     finally:
-        del os.environ["SPLITP_DIVERGENCE_GLOBAL"]
+        sp.get_context().set_option("divergence_global", 0)
     assert np.array_equal(glob2, got2)
     # the caller: neighbour joining by mutual information
     tree = sp.erickson_SVD(table, method=sp.Method.mutual_information)
@@ -989,12 +1164,14 @@ def test_subflattening_score_kernels_agree(sp, monkeypatch):
               sp.DeviceAlignment.from_arrays(keys, counts / 200_000.0, n, taxa=names, exact=False),
               sp.DeviceAlignment.from_arrays(keys[:3], None, n, counts=counts[:3], n_sites=int(counts[:3].sum()), taxa=names)]
     for dev in tables:
-        monkeypatch.delenv("SPLITP_SUBSCORE_JACOBI", raising=False)
+        sp.get_context().set_option("subscore_jacobi", 0)
         fast, st = sp.score_splits(dev, splits, method=sp.Method.subflattening, return_status=True)
         assert not np.any(st & 3)
-        monkeypatch.setenv("SPLITP_SUBSCORE_JACOBI", "1")
-        slow = sp.score_splits(dev, splits, method=sp.Method.subflattening)
-        monkeypatch.delenv("SPLITP_SUBSCORE_JACOBI", raising=False)
+        sp.get_context().set_option("subscore_jacobi", 1)
+        try:
+            slow = sp.score_splits(dev, splits, method=sp.Method.subflattening)
+        finally:
+            sp.get_context().set_option("subscore_jacobi", 0)
         both_nan = np.isnan(fast) & np.isnan(slow)
         err = np.where(both_nan, 0.0, np.abs(fast - slow))
         err2 = np.where(both_nan, 0.0, np.abs(fast ** 2 - slow ** 2))
@@ -1048,14 +1225,14 @@ def test_big_table_form(sp, golden, monkeypatch):
     g, names, splits, table = _n10(golden, "n10_L100k")
     dev = sp.DeviceAlignment.from_table(table, taxa=names)
     dev_w = sp.DeviceAlignment.from_arrays(g["keys"], g["probs"], 10, taxa=names, exact=False)
-    monkeypatch.setenv("SPLITP_FORCE_BIG", "1")
+    sp.get_context().set_option("force_big", 1)
     for d in (dev, dev_w):
         got, st = sp.score_splits(d, splits, return_status=True)
         assert not np.any(st & 3) and np.abs(got - g["scores"]).max() <= SCORE_TOL
-        monkeypatch.setenv("SPLITP_BIG_BY_KEYS", "1")          # compaction by sorting the raw side keys (sides > 14 taxa)
+        sp.get_context().set_option("big_by_keys", 1)          # compaction by sorting the raw side keys (sides > 14 taxa)
         assert np.array_equal(sp.score_splits(d, splits), got)
-        monkeypatch.delenv("SPLITP_BIG_BY_KEYS")
-    monkeypatch.delenv("SPLITP_FORCE_BIG")
+        sp.get_context().set_option("big_by_keys", 0)
+    sp.get_context().set_option("force_big", 0)
 
     n, length = 12, 1_000_000
     names12 = syn.taxa_names(n)
@@ -1089,9 +1266,9 @@ def test_big_table_form(sp, golden, monkeypatch):
         left = sorted(rng.choice(12, size=k, replace=False).tolist())
         splits2.append((tuple(names12[t] for t in left), tuple(names12[t] for t in range(12) if t not in left)))
     want = sp.score_splits(adv, splits2)
-    monkeypatch.setenv("SPLITP_FORCE_BIG", "1")
+    sp.get_context().set_option("force_big", 1)
     got2, st2 = sp.score_splits(adv, splits2, return_status=True)
-    monkeypatch.delenv("SPLITP_FORCE_BIG")
+    sp.get_context().set_option("force_big", 0)
     assert not np.any(st2 & 3) and np.abs(got2 - want).max() <= SCORE_TOL
     assert int((st2 >> 8).max()) > 41       # at least one split went through the wide block
 
@@ -1181,7 +1358,7 @@ def test_wide_block_plateau_regression(sp, monkeypatch):
     assert abs(sp.score_splits(dev, spl)[0] - want) <= SCORE_TOL
     assert abs(sp.score_splits(dev, spl, route="dense")[0] - want) <= SCORE_TOL
     assert abs(sp.score_splits(dev_w, spl)[0] - want) <= SCORE_TOL
-    monkeypatch.setenv("SPLITP_FORCE_BIG", "1")
+    sp.get_context().set_option("force_big", 1)
     got, st = sp.score_splits(dev, spl, return_status=True)
     assert abs(got[0] - want) <= SCORE_TOL and not (st[0] & 3)
     assert abs(sp.score_splits(dev_w, spl)[0] - want) <= SCORE_TOL
