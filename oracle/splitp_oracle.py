@@ -55,10 +55,15 @@ def index_of(chars) -> int:
 
     reference: splitp/constructions.py:166-171 (reverses the string and sums 4**o * digit).
     Characters outside ACGT raise KeyError, as in the reference (:170).
+
+    The same operations as the reference on purpose (a power per digit, not Horner's rule): this layer is also the CPU
+    baseline bench.py times, and a cheaper restatement would flatter the reference (47 % of its flattening time is
+    spent here, SURVEY row a2; tests/test_oracle_golden.py::test_oracle_wall_time_tracks_the_reference).
     """
+    text = chars if isinstance(chars, str) else "".join(chars)
     value = 0
-    for ch in chars:
-        value = value * 4 + DIGIT[ch]
+    for power, ch in enumerate(reversed(text)):
+        value += (4 ** power) * DIGIT[ch]
     return value
 
 
@@ -103,8 +108,8 @@ def reduced_flattening_loops(split, table, taxa):
     cells = {}
     seen_cols = set()
     for pattern, value in table.items():
-        r = index_of(str(pattern[i]) for i in left)
-        c = index_of(str(pattern[i]) for i in right)
+        r = index_of("".join([str(pattern[i]) for i in left]))
+        c = index_of("".join([str(pattern[i]) for i in right]))
         seen_cols.add(c)
         cells.setdefault(r, {})[c] = value
     col_rank = {c: j for j, c in enumerate(sorted(seen_cols))}
@@ -247,6 +252,18 @@ def rank1_divergence(flattening):
             if flattening[x, y] != 0:
                 total += flattening[x, y] * np.log(flattening[x, y] / (r[y] * c[x]))
     return total
+
+
+def rank_k_approximation(split, table):
+    """reference: splitp/phylogenetics.py:343-361 flattening_rank_k_approximation - for each letter the column sums of
+    the flattening with that letter banned on the row side (builtin sum over the rows of the sparse matrix, :346-353) and
+    the row sums with it banned on the column side (:354-360), then the sum over the letters of the outer products
+    A^T B (:361): a (4^|B| x 4^|A|) sparse matrix.  Taxa = sorted union of the halves (:344)."""
+    split = _normalise_split(split)
+    taxa = sorted(set(split[0]) | set(split[1]))
+    col_sums = [sum(sparse_flattening_loops(split, table, taxa, ban_row_patterns=ch)) for ch in "ACGT"]
+    row_sums = [sum(sparse_flattening_loops(split, table, taxa, ban_col_patterns=ch).T) for ch in "ACGT"]
+    return sum(a.T * b for a, b in zip(col_sums, row_sums))
 
 
 def rank1_divergence_packed(keys, vals, n_taxa, order_a, order_b):

@@ -54,6 +54,32 @@ def flattening(split, pattern_probabilities, flattening_format=FlatFormat.sparse
     return _reduced(al, oa, ob)
 
 
+class Flattening(np.ndarray):
+    """The reduced flattening as the reference returns it - a float64 ndarray - that also remembers where it came from:
+    (device-resident alignment, split).  `split_score(F)` then scores the split on the device from the resident table
+    instead of uploading F again ("API impedance"): the unchanged README loop
+    `split_score(flattening(split, table, FlatFormat.reduced))` keeps its semantics and loses the second PCIe trip.
+
+    The array is handed out READ-ONLY so that the remembered origin cannot go stale (the reference's array is writable:
+    `F.copy()` / `np.array(F)` give an ordinary writable ndarray, without the origin).  Anything derived from it - slices,
+    arithmetic, copies - is a plain result with no origin."""
+
+    _sp_origin = None
+
+    def __array_finalize__(self, obj):
+        self._sp_origin = None
+
+    def __reduce__(self):      # pickling / copy.deepcopy: a plain array
+        return np.asarray(self).__reduce__()
+
+
+def flattening_origin(matrix):
+    """(DeviceAlignment, order_a, order_b) if `matrix` is an untouched result of flattening(..., FlatFormat.reduced)."""
+    if type(matrix) is Flattening and matrix._sp_origin is not None and not matrix.flags.writeable:
+        return matrix._sp_origin
+    return None
+
+
 def _reduced(al, oa, ob):
     # reference: constructions.py:31-55
     r, c = C.c_int64(), C.c_int64()
@@ -62,6 +88,9 @@ def _reduced(al, oa, ob):
                                               len(ob), C.byref(r), C.byref(c)))
     out = np.zeros((r.value, c.value), dtype=np.float64)
     _lib.check(lib.sp_flatten_reduced_fetch(al.handle, _lib._ptr(out, C.c_double), None, None))
+    out = out.view(Flattening)
+    out._sp_origin = (al, np.array(oa, dtype=np.int32), np.array(ob, dtype=np.int32))
+    out.flags.writeable = False
     return out
 
 

@@ -6,6 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from .constructions import flattening_origin
 from .device import get_context
 from .matrix import is_sparse
 
@@ -23,6 +24,16 @@ def split_score(matrix, return_singular_values=False, force_frob_norm_on_dense=F
     Returns np.float64 (dense) / float (sparse) like the reference.  Where the reference's dense
     path can return nan from a slightly negative operand (no clamp, :293-300) this returns 0.0,
     like the reference's own sparse path (:311-312)."""
+    origin = flattening_origin(matrix)
+    if origin is not None:
+        # an untouched flattening(..., FlatFormat.reduced) of a resident table: score the split where the table lives
+        from .batch import score_encoded
+
+        al, oa, ob = origin
+        al.ctx.sync_stream_with_torch()
+        taxa_arr = np.ascontiguousarray(np.concatenate([oa, ob])[None, :], dtype=np.int32)
+        scores, _ = score_encoded(al, taxa_arr, np.array([len(oa)], dtype=np.int32), _lib.SP_METHOD_FLATTENING)
+        return np.float64(scores[0])
     ctx = get_context()
     lib = ctx._lib
     out = C.c_double()
@@ -88,6 +99,50 @@ def _score_big_sparse(ri, ci, v, shape):
     except NotImplementedError:
         return None
     return float(scores[0])
+
+
+def flattening_rank_1_approximation(flattening, return_vectors=False, dont_compute_matrix=False):
+    """Product of the marginals of a flattening (reference splitp/phylogenetics.py:332-341): r = column sums, c = row
+    sums, approximation = r^T c.  Host bookkeeping on a matrix the caller already holds; same return forms."""
+    m = np.array(flattening, dtype=np.float64) if not is_sparse(flattening) else flattening
+    r = np.array([np.asarray(m.sum(axis=0)).ravel()])
+    c = np.array([np.asarray(m.sum(axis=1)).ravel()])
+    approximation = None if dont_compute_matrix else r.T @ c
+    if return_vectors:
+        return approximation, r.tolist()[0], c.tolist()[0]
+    return approximation
+
+
+def flattening_rank_k_approximation(split, alignment):
+    """reference splitp/phylogenetics.py:343-361: for each letter x the column sums of the flattening with x banned on
+    the row side and the row sums with x banned on the column side (constructions.py:94-99), summed outer products ->
+    scipy.sparse matrix of shape (4^|B|, 4^|A|).  Taxa = sorted union of the halves (:344).
+
+    The per-pattern row / column indices come from the device (sp_flatten_indices, once for all eight banned
+    flattenings); banning is a digit count on those indices, the marginals are grouped sums."""
+    from scipy.sparse import csr_matrix
+
+    from .constructions import _digit_count, _indices
+    from .device import as_device_alignment, normalise_split
+
+    split = normalise_split(split)
+    taxa = sorted(set(split[0]) | set(split[1]))
+    al = as_device_alignment(alignment)
+    where = {t: i for i, t in enumerate(taxa)}
+    oa = np.array([where[s] for s in split[0]], dtype=np.int32)
+    ob = np.array([where[s] for s in split[1]], dtype=np.int32)
+    rows, cols = _indices(al, oa, ob)
+    _, vals, _ = al.fetch()
+    n_r, n_c = 4 ** len(oa), 4 ** len(ob)
+    total = None
+    for letter in "ACGT":
+        keep_r = _digit_count(rows, len(oa), letter) <= 1          # row pattern holds the letter at most once
+        keep_c = _digit_count(cols, len(ob), letter) <= 1
+        col_sums = np.bincount(cols[keep_r], weights=vals[keep_r], minlength=n_c)     # sum(F banned on rows) over rows
+        row_sums = np.bincount(rows[keep_c], weights=vals[keep_c], minlength=n_r)     # sum(F^T banned on cols)
+        term = csr_matrix(col_sums[:, None]) @ csr_matrix(row_sums[None, :])
+        total = term if total is None else total + term
+    return total
 
 
 def flattening_rank_1_approximation_divergence(flattening):

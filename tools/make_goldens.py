@@ -248,6 +248,94 @@ def main():
             json.dump({"versions": versions, "split_ids": ids, "divergence": vals, "ref4": v4,
                        "erickson_mutual_information": [[list(map(str, side)) for side in s] for s in tree]}, f)
 
+    # ------------------------------------------------- extras (round 2): simulator distribution, banned patterns,
+    # rank-k approximation, frobenius_norm, restatement/reference wall-time ratio
+    if want("extras"):
+        import json
+        repo = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        if repo not in sys.path:
+            sys.path.append(repo)           # our own package / oracle: used to lay the reference's trees out as arrays
+        from splitp import simulation as rsim
+        from splitp.constructions import sparse_flattening_with_banned_patterns as sfb
+        from splitp.phylogenetics import flattening_rank_k_approximation
+        from splitp.matrix import frobenius_norm
+        from splitp_amd import simulation as own_sim
+        from oracle import splitp_oracle as O
+        out = dict(versions=versions)
+        model = splitp.model.GTR.JukesCantor(1 / 2)
+        # (a) exact pattern probabilities (simulation.py:58-83) of a 4-taxon balanced tree and an unbalanced 5-taxon tree
+        for tag, tree in (("sim4", splitp.trees.balanced_newick_tree(4, 0.1)),
+                          ("sim5", splitp.Phylogeny("((A:0.1,B:0.2):0.05,(C:0.3,(D:0.1,E:0.15):0.07):0.02);"))):
+            probs = rsim.get_pattern_probabilities(tree, model)
+            parent, leaf, trans, taxa = own_sim.tree_arrays(tree, model)
+            n = len(taxa)
+            dense = np.zeros(4 ** n)
+            for pat, v in probs.items():
+                k = 0
+                for ch in pat:
+                    k = k * 4 + STATE[ch]
+                dense[k] = v
+            out[f"{tag}_parent"] = parent; out[f"{tag}_leaf"] = leaf; out[f"{tag}_trans"] = trans
+            out[f"{tag}_probs"] = dense; out[f"{tag}_n"] = n
+        # (b) banned-pattern flattenings (constructions.py:94-105) and their caller flattening_rank_k_approximation
+        # (phylogenetics.py:343-361): a 7-pattern 4-taxon table, every letter on either side; one 10-taxon split
+        t7 = {"ATCG": 2 / 5, "GATC": 1 / 5, "CGAT": 1 / 5, "TCGA": 1 / 5, "AATT": 0.1, "AACC": 0.05, "ACAC": 0.05}
+        k7, p7 = pack(t7)
+        out["t7_keys"] = k7; out["t7_probs"] = p7
+        taxa4 = ["0", "1", "2", "3"]
+        split4 = (("0", "1"), ("2", "3"))
+        for ch in "ACGT":
+            for side in ("row", "col"):
+                m = sfb(split4, t7, taxa4, **{f"ban_{side}_patterns": ch}).tocoo()
+                out[f"t7_ban_{side}_{ch}_r"] = m.row; out[f"t7_ban_{side}_{ch}_c"] = m.col; out[f"t7_ban_{side}_{ch}_v"] = m.data
+        out["t7_rank_k"] = np.asarray(flattening_rank_k_approximation(split4, t7).todense())
+        g = np.load(os.path.join(OUT, "n10_L10k.npz"))
+        names10 = [str(np.base_repr(i, base=max(i + 1, 2))) for i in range(10)]
+        table10 = {}
+        for k, v in zip(g["keys"].tolist(), g["probs"].tolist()):
+            table10["".join("ACGT"[(k >> (2 * (9 - t))) & 3] for t in range(10))] = v
+        sid = 7
+        m10 = int(g["masks"][sid])
+        split10 = (tuple(names10[t] for t in range(10) if (m10 >> t) & 1), tuple(names10[t] for t in range(10) if not (m10 >> t) & 1))
+        out["n10_split_id"] = sid
+        for ch, side in (("A", "row"), ("T", "col"), ("G", "row")):
+            m = sfb(split10, table10, names10, **{f"ban_{side}_patterns": ch}).tocoo()
+            order = np.lexsort((m.col, m.row))
+            out[f"n10_ban_{side}_{ch}_r"] = m.row[order]; out[f"n10_ban_{side}_{ch}_c"] = m.col[order]
+            out[f"n10_ban_{side}_{ch}_v"] = m.data[order]
+        rk = flattening_rank_k_approximation(split10, table10).tocoo()
+        order = np.lexsort((rk.col, rk.row))
+        pick = order[:: max(1, len(order) // 300)]
+        out["n10_rank_k_shape"] = np.array(rk.shape); out["n10_rank_k_nnz"] = rk.nnz
+        out["n10_rank_k_sum"] = rk.data.sum(); out["n10_rank_k_fro"] = np.sqrt((rk.data ** 2).sum())
+        out["n10_rank_k_r"] = rk.row[pick]; out["n10_rank_k_c"] = rk.col[pick]; out["n10_rank_k_v"] = rk.data[pick]
+        # (c) frobenius_norm (matrix.py:7-14), all three branches, on the same 10-taxon split
+        import pandas as pd
+        Fs = flattening(split10, table10)
+        Fr = flattening(split10, table10, FlatFormat.reduced)
+        df = pd.DataFrame({"pattern": list(table10.keys()), "prob": list(table10.values())})
+        out["fro_sparse"] = frobenius_norm(Fs); out["fro_dense"] = frobenius_norm(Fr)
+        out["fro_table"] = frobenius_norm(None, data_table=df)
+        # (d) wall time of the reference vs the oracle's loops layer on config 1 (README: first 100 splits, reduced)
+        splits = list(splitp.all_splits(splitp.trees.balanced_newick_tree(10, 0.05)))[:100]
+        t0 = time.time()
+        ref_scores = [split_score(flattening(s, table10, FlatFormat.reduced)) for s in splits]
+        t_ref = time.time() - t0
+        t0 = time.time()
+        own_scores = [O.split_score(O.flattening(s, table10, "reduced")) for s in splits]
+        t_own = time.time() - t0
+        assert np.array_equal(np.array(ref_scores), np.array(own_scores))
+        out["time_ref_100"] = t_ref; out["time_oracle_100"] = t_own; out["time_cpus"] = os.cpu_count()
+        # (e) searched and NOT found: a matrix of rank <= 4 on which the reference's unclamped dense path returns nan
+        # (phylogenetics.py:293-300).  Its denominator adds non-negative terms to the very same partial sum that forms
+        # the numerator, so the ratio cannot exceed 1; 3000 random low-rank matrices (integer and real factors) all gave
+        # 0.0 or ~1e-8.  nan only arises from the all-zero matrix (0/0), which `degenerate` and the GPU tests cover.
+        z = np.zeros((6, 9))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            out["zero_matrix_score"] = split_score(z)
+        np.savez_compressed(os.path.join(OUT, "extras.npz"), **out)
+        print(f"extras done: reference {t_ref:.2f} s, oracle {t_own:.2f} s for 100 splits (ratio {t_own / t_ref:.2f})")
+
     # --------------------------------------------------------- degenerate cases
     if want("degenerate"):
         out = dict(versions=versions)
