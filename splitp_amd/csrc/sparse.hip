@@ -281,8 +281,15 @@ __device__ __forceinline__ int spk_class(int c) {
     return c > 4 ? 4 : (c > 2 ? 3 : c);
 }
 
-template <bool MAJOR_IS_COL, int BITS, bool PERMUTE>
-__device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned short* cnt, int D, int nmajor,
+#define SPK_MAXQ 20   // entries per lane whose counts pass B fetches up front when they live in global memory
+
+// counts of the q entries lane `lane` walks in pass B (i = first + t): from the LDS / slab copy, or - plain LDS form,
+// which keeps no copy - straight from the table in global memory, all loads issued before the first use
+template <typename CT>
+__device__ __forceinline__ u32 spk_count_at(const CT* cnt, int i) { return (u32)cnt[i]; }
+
+template <bool MAJOR_IS_COL, int BITS, bool PERMUTE, typename CT = unsigned short>
+__device__ __forceinline__ void spk_build_list(const u32* pc, const CT* cnt, int D, int nmajor,
                                                unsigned short* ptr, unsigned short* ptrp, u32* ent,
                                                unsigned short* perm, int* nwave, int* nrow, int* nquad, int* used, u32* cw,
                                                int nsort, SpkShared& sh, unsigned short* end_of = nullptr,
@@ -455,16 +462,243 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const unsigned sho
         __syncthreads();
     }
     BSTAMP(3);
-    for (int t = 0; t < q; ++t) {                         // pass B: placement (same walk as pass A)
-        const int i = lo + lane * q + t;
-        if (i >= hi) continue;
+    constexpr bool CNT_GLOBAL = !std::is_same<CT, unsigned short>::value;   // counts read from the table in global memory
+    u32 cpre[SPK_MAXQ];
+    const bool pre = CNT_GLOBAL && q <= SPK_MAXQ;
+    if (pre) {
+#pragma unroll
+        for (int t = 0; t < SPK_MAXQ; ++t) {
+            const int i = lo + lane * q + t;
+            cpre[t] = (t < q && i < hi) ? (u32)cnt[i] : 0u;
+        }
+    }
+    auto place = [&](int i, u32 c) {
         const u32 v = pc[i];
         const int mj = MAJOR_IS_COL ? (int)(v & 0xFFFF) : (int)(v >> 16);
         const int mn = MAJOR_IS_COL ? (int)(v >> 16) : (int)(v & 0xFFFF);
         const u32 old = atomicAdd(&myrow[mj / PER], 1u << (BITS * (mj % PER)));
         const int pos = ptr[mj] + (int)((old >> (BITS * (mj % PER))) & FMASK);
-        ent[pos] = (u32)mn | ((u32)cnt[i] << 16);
+        ent[pos] = (u32)mn | (c << 16);
         if (!PERMUTE && end_of) end_of[pos] = (unsigned short)mj;   // small path: group of every position
+    };
+    if (pre) {                                            // pass B: placement (same walk as pass A)
+#pragma unroll
+        for (int t = 0; t < SPK_MAXQ; ++t) {
+            const int i = lo + lane * q + t;
+            if (t < q && i < hi) place(i, cpre[t]);
+        }
+    } else {
+        for (int t = 0; t < q; ++t) {
+            const int i = lo + lane * q + t;
+            if (i < hi) place(i, (u32)cnt[i]);
+        }
+    }
+    __syncthreads();
+}
+
+// Both lists at once (plain LDS form): waves 0..7 build the CSC list while waves 8..15 build the CSR list - the same
+// stable counting sort as spk_build_list, every step executed by both halves side by side on their own list, with 8
+// wave-private counter rows each.  A list build is a chain of ~10 short barrier-separated steps that are latency-bound,
+// not throughput-bound (two passes over the table, a prefix over the counter rows, the size-class permutation, a scan):
+// run one after the other they cost 2 x 24 k cycles of a 130 k-cycle workgroup, side by side ~60 % of that.
+struct SpkListOut {
+    int nmajor;
+    unsigned short* ptr;    // build-time start of every group
+    unsigned short* ptrp;   // entry offsets in permutation order (nmajor + 1)
+    unsigned short* perm;
+    u32* ent;
+    u32* cw;                // SPK_HALF_WAVES counter rows
+    int* nwave;
+    int* nrow;
+    int* nquad;
+    int* used;
+};
+#define SPK_HALF_WAVES (SPK_WAVES / 2)
+#define SPK_HALF_THREADS (SPK_THREADS / 2)
+
+// exclusive scan of one u32 per thread over the thread's HALF of the block (both halves call it together)
+__device__ __forceinline__ u32 spk_scan_half(u32 v, SpkShared& sh, u32& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w / SPK_HALF_WAVES, wh = w % SPK_HALF_WAVES;
+    u32 x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) sh.scan[w] = x;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SPK_HALF_WAVES; ++i) {
+        const u32 sv = sh.scan[h * SPK_HALF_WAVES + i];
+        if (i < wh) base += sv;
+        tot += sv;
+    }
+    total = tot;
+    return base + x - v;
+}
+
+template <typename CT>
+__device__ __forceinline__ void spk_build_pair(const u32* pc, const CT* cnt, int D, const SpkListOut& Lc,
+                                               const SpkListOut& Lr, SpkShared& sh) {
+    constexpr int BITS = 16, PER = 2;
+    constexpr u32 FMASK = 0xFFFFu;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int h = w / SPK_HALF_WAVES, wh = w % SPK_HALF_WAVES, th = threadIdx.x % SPK_HALF_THREADS;
+    const bool is_col = h == 0;
+    // (wave-uniform selects: the half's own list)
+    const int nmajor = is_col ? Lc.nmajor : Lr.nmajor;
+    unsigned short* const ptr = is_col ? Lc.ptr : Lr.ptr;
+    unsigned short* const ptrp = is_col ? Lc.ptrp : Lr.ptrp;
+    unsigned short* const perm = is_col ? Lc.perm : Lr.perm;
+    u32* const ent = is_col ? Lc.ent : Lr.ent;
+    u32* const cw = is_col ? Lc.cw : Lr.cw;
+    u32* const bucket = sh.bucket + h * 16;               // (sh.bucket has 68 words: 2 x 10 classes fit)
+    const int stride = (nmajor + PER - 1) / PER;
+    const int q = ((D + SPK_HALF_WAVES * 64 - 1) / (SPK_HALF_WAVES * 64)) | 1;   // odd: see spk_build_list
+    const int chunk = q * 64;
+    const int lo = min(D, wh * chunk), hi = min(D, lo + chunk);
+    for (int i = th; i < SPK_HALF_WAVES * stride; i += SPK_HALF_THREADS) cw[i] = 0;
+    if (th < 16) bucket[th] = 0;
+    __syncthreads();
+    u32* const myrow = cw + wh * stride;
+    for (int t = 0; t < q; ++t) {                         // pass A: per-chunk group sizes
+        const int i = lo + lane * q + t;
+        if (i >= hi) continue;
+        const u32 v = pc[i];
+        const int mj = is_col ? (int)(v & 0xFFFF) : (int)(v >> 16);
+        atomicAdd(&myrow[mj / PER], 1u << (BITS * (mj % PER)));
+    }
+    // counts of this lane's entries for pass B: issued now, consumed ~10 k cycles later
+    constexpr bool CNT_GLOBAL = !std::is_same<CT, unsigned short>::value;
+    u32 cpre[SPK_MAXQ];
+    const bool pre = CNT_GLOBAL && q <= SPK_MAXQ;
+    if (pre) {
+#pragma unroll
+        for (int t = 0; t < SPK_MAXQ; ++t) {
+            const int i = lo + lane * q + t;
+            cpre[t] = (t < q && i < hi) ? (u32)cnt[i] : 0u;
+        }
+    }
+    __syncthreads();
+    for (int qq = th; qq < stride; qq += SPK_HALF_THREADS) {   // exclusive prefix over the 8 chunks; totals -> ptr
+        u32 run0 = 0, run1 = 0;
+        u32 words[SPK_HALF_WAVES];
+#pragma unroll
+        for (int ww = 0; ww < SPK_HALF_WAVES; ++ww) words[ww] = cw[ww * stride + qq];
+#pragma unroll
+        for (int ww = 0; ww < SPK_HALF_WAVES; ++ww) {
+            cw[ww * stride + qq] = run0 | (run1 << 16);
+            run0 += words[ww] & FMASK;
+            run1 += words[ww] >> 16;
+        }
+        if (qq * 2 < nmajor) ptr[qq * 2] = (unsigned short)run0;
+        if (qq * 2 + 1 < nmajor) ptr[qq * 2 + 1] = (unsigned short)run1;
+    }
+    __syncthreads();
+    // size classes (spk_class), largest first; wave-aggregated class counters of the half
+    const int rounds = (nmajor + SPK_HALF_THREADS - 1) / SPK_HALF_THREADS;
+    constexpr int KEEP = 4;
+    int kcls[KEEP];
+    u32 kmine[KEEP], krank[KEEP];
+    auto classify = [&](int m, int& cls, u32& mine, u32& rank) {
+        cls = m < nmajor ? spk_class(ptr[m]) : -1;
+        mine = 0;
+        u64 mymask = 0;
+#pragma unroll
+        for (int k = 0; k < SPK_NCLASS; ++k) {
+            const u64 b = __ballot(cls == k);
+            if (lane == k) mine = (u32)__popcll(b);
+            if (cls == k) mymask = b;
+        }
+        rank = (u32)__popcll(mymask & ((1ull << lane) - 1));
+    };
+    for (int r = 0; r < rounds; ++r) {
+        int cls;
+        u32 mine, rank;
+        classify(r * SPK_HALF_THREADS + th, cls, mine, rank);
+#pragma unroll
+        for (int kk = 0; kk < KEEP; ++kk)
+            if (r == kk) {
+                kcls[kk] = cls; kmine[kk] = mine; krank[kk] = rank;
+            }
+        if (lane < SPK_NCLASS && mine) atomicAdd(&bucket[lane], mine);
+    }
+    __syncthreads();
+    if (th == 0) {
+        int* const nwave = is_col ? Lc.nwave : Lr.nwave;
+        int* const nrow = is_col ? Lc.nrow : Lr.nrow;
+        int* const nquad = is_col ? Lc.nquad : Lr.nquad;
+        int* const used = is_col ? Lc.used : Lr.used;
+        u32 run = 0;
+        for (int k = SPK_NCLASS - 1; k >= 0; --k) {
+            const u32 c = bucket[k];
+            bucket[k] = run;
+            run += c;
+            if (k == SPK_NCLASS - 1) *nwave = (int)run;
+            if (k == SPK_NCLASS - 2) *nrow = (int)run - *nwave;
+            if (k == 5) *nquad = (int)run;
+            if (k == 1) *used = (int)run;
+        }
+        *nquad -= *nwave + *nrow;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < KEEP; ++r) {
+        if (r >= rounds) break;
+        const int m = r * SPK_HALF_THREADS + th;
+        u32 base = 0;
+        if (lane < SPK_NCLASS && kmine[r]) base = atomicAdd(&bucket[lane], kmine[r]);
+        base = __shfl(base, kcls[r] < 0 ? 0 : kcls[r], 64);
+        if (kcls[r] >= 0) perm[base + krank[r]] = (unsigned short)m;
+    }
+    for (int r = KEEP; r < rounds; ++r) {
+        const int m = r * SPK_HALF_THREADS + th;
+        int cls;
+        u32 mine, rank;
+        classify(m, cls, mine, rank);
+        u32 base = 0;
+        if (lane < SPK_NCLASS && mine) base = atomicAdd(&bucket[lane], mine);
+        base = __shfl(base, cls < 0 ? 0 : cls, 64);
+        if (cls >= 0) perm[base + rank] = (unsigned short)m;
+    }
+    __syncthreads();
+    {   // entry offsets in permutation order, then ptr[m] = start of group m in that layout
+        const int per = (nmajor + SPK_HALF_THREADS - 1) / SPK_HALF_THREADS;
+        const int l0 = min(nmajor, th * per), h0 = min(nmajor, l0 + per);
+        u32 sum = 0;
+        for (int i = l0; i < h0; ++i) sum += ptr[perm[i]];
+        u32 tot;
+        u32 run = spk_scan_half(sum, sh, tot);
+        for (int i = l0; i < h0; ++i) {
+            ptrp[i] = (unsigned short)run;
+            run += ptr[perm[i]];
+        }
+        if (th == 0) ptrp[nmajor] = (unsigned short)tot;
+        __syncthreads();
+        for (int i = th; i < nmajor; i += SPK_HALF_THREADS) ptr[perm[i]] = ptrp[i];
+        __syncthreads();
+    }
+    auto place = [&](int i, u32 c) {                      // pass B: placement (same walk as pass A)
+        const u32 v = pc[i];
+        const int mj = is_col ? (int)(v & 0xFFFF) : (int)(v >> 16);
+        const int mn = is_col ? (int)(v >> 16) : (int)(v & 0xFFFF);
+        const u32 old = atomicAdd(&myrow[mj / PER], 1u << (BITS * (mj % PER)));
+        const int pos = ptr[mj] + (int)((old >> (BITS * (mj % PER))) & FMASK);
+        ent[pos] = (u32)mn | (c << 16);
+    };
+    if (pre) {
+#pragma unroll
+        for (int t = 0; t < SPK_MAXQ; ++t) {
+            const int i = lo + lane * q + t;
+            if (t < q && i < hi) place(i, cpre[t]);
+        }
+    } else {
+        for (int t = 0; t < q; ++t) {
+            const int i = lo + lane * q + t;
+            if (i < hi) place(i, (u32)cnt[i]);
+        }
     }
     __syncthreads();
 }
@@ -885,7 +1119,10 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     // (a table with split counts - several rows per pattern - can have more than R entries in a column, which the 8-bit
     // sort counters of the small path do not hold: such tables take the general path)
     const bool small_sure = r_cap <= SPK_SMALL_R && (u32)Di == sh.ntab && !wide_on;   // then no CSR list is needed
-    const size_t need_build = off + (LISTS_GLOBAL ? 0 : (size_t)(D + 8) * (small_sure ? 4 : 8)) + (size_t)D * 6 +
+    // plain LDS form: no copy of the counts in LDS - pass B of the list builds fetches them from the table in global
+    // memory (all of a lane's loads issued up front), which frees 2 D bytes for a second set of sort counters
+    constexpr bool PLAIN = !HBM && !LISTS_GLOBAL;
+    const size_t need_build = off + (LISTS_GLOBAL ? 0 : (size_t)(D + 8) * (small_sure ? 4 : 8)) + (size_t)D * (PLAIN ? 4 : 6) +
                               (size_t)W * 12 + 4096 + 256;
     if (D > 65535 || n > 16 || need_build + 2048 > cap) {
         if (threadIdx.x == 0) {
@@ -919,7 +1156,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     }
     const size_t off_after_lists = off;
     u32* pc = reinterpret_cast<u32*>(carve((size_t)D * 4));
-    unsigned short* cnt = reinterpret_cast<unsigned short*>(carve((size_t)D * 2));
+    unsigned short* cnt = PLAIN ? nullptr : reinterpret_cast<unsigned short*>(carve((size_t)D * 2));
     u64* bm = reinterpret_cast<u64*>(carve((size_t)W * 8));
     u32* pf = reinterpret_cast<u32*>(carve((size_t)W * 4));
     const int* shifts = sh.shifts;
@@ -952,7 +1189,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
         for (int u = 0; u < 8; ++u) {
             const int i = base + u * SPK_THREADS + (int)threadIdx.x;
             key[u] = i < Di ? keys[i] : 0u;
-            cv[u] = i < Di ? counts[i] : 0u;
+            if (!PLAIN) cv[u] = i < Di ? counts[i] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -962,7 +1199,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             if (wide_key) cell |= lut[768 + (key[u] >> 24)];
             const u32 r = cell >> (2 * nc), c = cell & cmask;
             pc[i] = both_raw ? ((r << 16) | c) : cell;
-            cnt[i] = (unsigned short)cv[u];
+            if (!PLAIN) cnt[i] = (unsigned short)cv[u];
             if (!raw_r) {   // presence bits (a plain read first saves most of the atomics)
                 const u64 rb = 1ull << (r & 63);
                 if (!(*(volatile u64*)(bm + (r >> 6)) & rb)) atomicOr(bm + (r >> 6), rb);
@@ -1095,16 +1332,43 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     unsigned short* grp_c = grp_c_in_csr ? reinterpret_cast<unsigned short*>(csr_ent)
                                          : reinterpret_cast<unsigned short*>(base + ((build_end + cw_c + 15) & ~(size_t)15));
     unsigned short* grp_r = reinterpret_cast<unsigned short*>(base + ((build_end + cw_r + 15) & ~(size_t)15));
-    if (small)
-        spk_build_list<true, 8, false>(pc, cnt, Di, Kc, csc_ptr, nullptr, csc_ent, nullptr, nullptr, nullptr, nullptr, &sh.used_c,
-                                       cwbuf, ns_c, sh, colof);
-    else
-        spk_build_list<true, 16, true>(pc, cnt, Di, Kc, grp_c, desc_c, csc_ent, perm_c, &sh.nw_c, &sh.nr_c, &sh.nq_c, &sh.used_c,
-                                       cwbuf, ns_c, sh, nullptr, 50);
-    SSTAMP(2);
-    if (!small)
-        spk_build_list<false, 16, true>(pc, cnt, Di, R, grp_r, desc_r, csr_ent, perm_r, &sh.nw_r, &sh.nr_r, &sh.nq_r, &sh.used_r,
-                                        cwbuf_r, ns_r, sh);
+    if (PLAIN) {
+        // both lists side by side (waves 0..7 / 8..15) when two sets of 8 counter rows + both group-start arrays fit
+        const size_t pair_c = (size_t)SPK_HALF_WAVES * cw_c1, pair_r = (size_t)SPK_HALF_WAVES * cw_r1;
+        const size_t pair_gc = (((size_t)Kc + 1) * 2 + 15) & ~(size_t)15, pair_gr = (((size_t)R + 1) * 2 + 15) & ~(size_t)15;
+        const size_t pair_at = (build_end + 15) & ~(size_t)15;
+        const bool pair = !small && pair_at + pair_c + pair_r + pair_gc + pair_gr + 16 <= top;
+        if (small) {
+            spk_build_list<true, 8, false, u32>(pc, counts, Di, Kc, csc_ptr, nullptr, csc_ent, nullptr, nullptr, nullptr, nullptr,
+                                                &sh.used_c, cwbuf, ns_c, sh, colof);
+            SSTAMP(2);
+        } else if (pair) {
+            unsigned char* at = base + pair_at;
+            SpkListOut Lc{Kc, reinterpret_cast<unsigned short*>(at + pair_c + pair_r), desc_c, perm_c, csc_ent,
+                          reinterpret_cast<u32*>(at), &sh.nw_c, &sh.nr_c, &sh.nq_c, &sh.used_c};
+            SpkListOut Lr{R, reinterpret_cast<unsigned short*>(at + pair_c + pair_r + pair_gc), desc_r, perm_r, csr_ent,
+                          reinterpret_cast<u32*>(at + pair_c), &sh.nw_r, &sh.nr_r, &sh.nq_r, &sh.used_r};
+            spk_build_pair<u32>(pc, counts, Di, Lc, Lr, sh);
+            SSTAMP(2);
+        } else {
+            spk_build_list<true, 16, true, u32>(pc, counts, Di, Kc, grp_c, desc_c, csc_ent, perm_c, &sh.nw_c, &sh.nr_c, &sh.nq_c,
+                                                &sh.used_c, cwbuf, ns_c, sh, nullptr, 50);
+            SSTAMP(2);
+            spk_build_list<false, 16, true, u32>(pc, counts, Di, R, grp_r, desc_r, csr_ent, perm_r, &sh.nw_r, &sh.nr_r, &sh.nq_r,
+                                                 &sh.used_r, cwbuf_r, ns_r, sh);
+        }
+    } else {
+        if (small)
+            spk_build_list<true, 8, false>(pc, cnt, Di, Kc, csc_ptr, nullptr, csc_ent, nullptr, nullptr, nullptr, nullptr, &sh.used_c,
+                                           cwbuf, ns_c, sh, colof);
+        else
+            spk_build_list<true, 16, true>(pc, cnt, Di, Kc, grp_c, desc_c, csc_ent, perm_c, &sh.nw_c, &sh.nr_c, &sh.nq_c, &sh.used_c,
+                                           cwbuf, ns_c, sh, nullptr, 50);
+        SSTAMP(2);
+        if (!small)
+            spk_build_list<false, 16, true>(pc, cnt, Di, R, grp_r, desc_r, csr_ent, perm_r, &sh.nw_r, &sh.nr_r, &sh.nq_r, &sh.used_r,
+                                            cwbuf_r, ns_r, sh);
+    }
     SSTAMP(3);
     // ids in use on raw sides (small path: the used rows are the non-zero diagonal entries of G, checked below)
     if (degenerate(small ? 5 : sh.used_r, sh.used_c)) return 0;
@@ -1123,7 +1387,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             int myrow = -1, mycnt = 1;
             if (lane < ntop) {
                 myrow = (int)(pc[sh.top[lane]] >> 16);
-                mycnt = (int)cnt[sh.top[lane]];
+                mycnt = PLAIN ? (int)counts[sh.top[lane]] : (int)cnt[sh.top[lane]];
             }
             u64 active = __ballot(myrow >= 0);
             // (fully unrolled, constant indices: a runtime-indexed local array would live in scratch = global memory)
@@ -1901,7 +2165,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
                 spkb_product<CT, true>(keyr, minr, cntr, D, W, 0, V, 0, R, pt);
             spk_gram(X, rows, 4, 1, sh);
             top4 = (sh.S[0] + sh.S[5]) + (sh.S[10] + sh.S[15]);
-            spk_chol_factor(sh, it >= 4, trace - top4);
+            spk_chol_factor(sh, it >= 5, trace - top4);
             if (spk_converged(top4, sh.L[11], trace, it, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
                 break;

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Helpers for tools/gpu_pmc_binding.sh.
+
+  pmc_summarise.py <counter_collection.csv>          per-kernel, per-launch averages of every counter (one line each)
+  pmc_summarise.py --json <passes.txt> <kernel_stats.csv>   -> the JSON bench.py reads (profiles/r02_pmc_binding.json)
+"""
+import collections
+import csv
+import json
+import sys
+
+PHASE_OF = {"k_sparse_score": "sparse", "k_sparse_slow": "chain", "k_gram_i8": "gram", "k_eig_gv": "eigen"}
+
+
+def per_kernel(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.defaultdict(set)
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            calls[k].add(row["Dispatch_Id"])
+    for k in agg:
+        n = len(calls[k])
+        print(json.dumps({"kernel": k, "launches": n, "per_launch": {c: v / n for c, v in agg[k].items()}}))
+
+
+def to_json(passes, stats):
+    out = {}
+    for line in open(passes):
+        line = line.strip()
+        if not line.startswith("{"):
+            continue
+        rec = json.loads(line)
+        base = rec["kernel"].split("<")[0]
+        phase = PHASE_OF.get(base)
+        if phase is None:
+            continue
+        d = out.setdefault(phase, {"kernel": rec["kernel"], "launches_profiled": rec["launches"]})
+        d.update(rec["per_launch"])
+    for phase, d in out.items():
+        if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+            # MI355X_MICROARCH.md (HBM): FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads -> x2; WRITE_SIZE
+            # is exact for 16-B-per-lane stores; both are reported in KB by rocprofv3
+            d["hbm_bytes_per_launch"] = 1024.0 * (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0))
+        if "GRBM_GUI_ACTIVE" in d:
+            d["kernel_cycles_from_GRBM_GUI_ACTIVE_div_8"] = d["GRBM_GUI_ACTIVE"] / 8.0   # rocprofv3 sums the 8 XCDs
+    try:
+        with open(stats) as fh:
+            for row in csv.DictReader(fh):
+                base = row["Name"].split("(")[0].replace("void ", "").split("<")[0]
+                phase = PHASE_OF.get(base)
+                if phase in out:
+                    out[phase]["trace_avg_ns"] = float(row["AverageNs"])
+                    out[phase]["trace_calls"] = int(row["Calls"])
+    except Exception as exc:   # noqa: BLE001
+        out["_stats_error"] = str(exc)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "--json":
+        to_json(sys.argv[2], sys.argv[3])
+    else:
+        per_kernel(sys.argv[1])
