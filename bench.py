@@ -37,6 +37,7 @@ import time
 # initialisation, hence before torch is imported).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool's host driver
+os.environ.setdefault("NCCL_DEBUG", "WARN")                # no RCCL version banner on stdout: rank 0 prints ONE JSON line
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -152,12 +153,24 @@ def roofline_block(dom, dom_ms_alone, dom_ms_region, in_flight, phases_per_step,
     algo_bytes = float(len(a_arr) * (4.0 * n_sites + 4.0 * 4.0 ** n_taxa)) * per_al       # 4L + 4*4^n per split
     algo_flops = float(np.sum(2.0 * 4.0 ** n_taxa * 4.0 ** k_small)) * per_al            # 2*4^n*4^k per split
     names = {"gram": "k_gram_i8<2,int> (int8-limb MFMA Gram)", "eigen": "k_eig_gv / k_eig_rr (fp64 MFMA)",
-             "sparse": "k_sparse_score<false,false,false,false> (one workgroup per split: CSC/CSR lists + 4-wide block in LDS)",
+             "sparse": "k_sparse_score (one workgroup per split: CSC/CSR lists + 4-wide block in LDS)",
              "scatter": "k_zero_i8 + k_scatter_i8", "reindex": "k_reindex", "subscore": "k_subscore_tri",
-             "chain": "k_sparse_score<...,true> (hand-back chain)"}
+             "chain": "k_sparse_slow (persistent workgroups: lists-in-global / all-global / 8-wide forms of the sparse kernel)"}
     sec = dom_ms_alone * 1e-3
     roof = {"kernel": names.get(dom, dom), "launch_ms": dom_ms_alone, "launch_ms_in_timed_region": dom_ms_region,
             "launches_in_flight": in_flight, "phase_ms_per_step": phases_per_step, "traffic": None}
+    if dom == "subscore":
+        # SURVEY 8(d), subflattening path: per split a Gram 2 m^2 m' on the (3k+1) x (3(n-k)+1) block, Householder
+        # tridiagonalisation 4/3 m^3 and Sturm multisection (14 passes x 64 shifts x 2m); bound: fp64 VALU / latency
+        m = 3.0 * k_small + 1.0
+        mp = 3.0 * (n_taxa - k_small) + 1.0
+        flops = float(np.sum(2.0 * m * m * mp + 4.0 / 3.0 * m ** 3 + 14 * 64 * 2.0 * m)) * per_al
+        roof.update({"bound": "fp64-valu", "achieved": flops / sec / 1e12, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": flops / sec / 1e12 / FP64_MFMA_PEAK_TF, "algorithmic_flops_per_launch": flops,
+                     "note": "one wave per split, dependent chains of a few hundred fp64 operations: latency-bound by "
+                             "construction (SURVEY 8d: 'fp64 VALU / launch latency; report splits/s and achieved fp64 FLOP/s'); "
+                             "peak = the fp64 vector rate (= the fp64 matrix rate on this part)"})
+        return roof
     survey = {"scatter_phase": {"bound": "hbm", "algorithmic_bytes_per_launch": algo_bytes,
                                 "achieved": algo_bytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": algo_bytes / sec / 1e9 / HBM_PEAK_GBS},

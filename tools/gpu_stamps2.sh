@@ -18,7 +18,7 @@ splits = list(sp.all_splits(names))
 lib = dev.ctx._lib
 lib.sp_debug_spk_stamps.argtypes = [C.POINTER(C.c_longlong)]
 import torch
-for k in (5, 4, 3):
+for k in (5, 4, 3, 2):
     sub = [s for s in splits if min(len(s[0]), len(s[1])) == k]
     taxa_arr, a_arr = batch.encode_splits(sub, dev, n)
     nrep = 8
