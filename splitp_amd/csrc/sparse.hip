@@ -1166,7 +1166,6 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     // staging loop is instruction-bound: 16 waves share 4 SIMDs)
     u32* lut = reinterpret_cast<u32*>(carve(4 * 256 * 4));
     {
-        const int chunk = threadIdx.x >> 8, val = threadIdx.x & 255;   // SPK_THREADS >= 1024: one entry per thread
         for (int e = threadIdx.x; e < 1024; e += SPK_THREADS) {
             const int ch = e >> 8, v = e & 255;
             u32 out = 0;
@@ -1177,7 +1176,6 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             }
             lut[e] = out;
         }
-        (void)chunk; (void)val;
     }
     const u32 cmask = (nc >= 16) ? 0xFFFFFFFFu : ((1u << (2 * nc)) - 1);
     const bool both_raw = raw_r && raw_c;

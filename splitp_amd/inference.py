@@ -30,9 +30,6 @@ def erickson_SVD(alignment, taxa=None, method=Method.flattening, show_work=False
         taxa = [str(np.base_repr(i, base=max(i + 1, 2))) if num_taxa <= 36 else f"t{i}" for i in range(num_taxa)]
     leaf_order = [t for g in taxa for t in _flatten(g)]
 
-    class _Named(dict):
-        pass
-
     dev = as_device_alignment(alignment)
     if getattr(dev, "taxa", None) is None:
         dev.taxa = tuple(sorted(leaf_order))  # the reference resolves taxa as sorted(union of the split halves)

@@ -23,9 +23,9 @@ for trial in range(ntr):
     dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=total, taxa=names)
     dev_w = sp.DeviceAlignment.from_arrays(keys, probs, n, taxa=names, exact=False)
     res = {"fused": sp.score_splits(dev, splits, method=sp.Method.mutual_information)}
-    os.environ["SPLITP_DIVERGENCE_GLOBAL"] = "1"
+    sp.get_context().set_option("divergence_global", 1)
     res["global"] = sp.score_splits(dev, splits, method=sp.Method.mutual_information)
-    del os.environ["SPLITP_DIVERGENCE_GLOBAL"]
+    sp.get_context().set_option("divergence_global", 0)
     res["float"] = sp.score_splits(dev_w, splits, method=sp.Method.mutual_information)
     for i, spl in enumerate(splits):
         want = O.rank1_divergence_packed(keys, probs, n, [names.index(t) for t in spl[0]], [names.index(t) for t in spl[1]])
