@@ -36,4 +36,6 @@ for k in (5, 4, 3, 2):
               f"spmm_it2={o[9]-o[7]} gram2={o[40]-o[9]} orth2={o[41]-o[40]} spmm_it3={o[8]-o[41]} rest={o[11]-o[8]} total={o[11]-o[0]}")
         print(f"     CSC build: pre={o[55]-o[1]} passA={o[50]-o[55]} prefix={o[51]-o[50]} class+perm={o[52]-o[51]} scan+ptr={o[53]-o[52]} passB={o[2]-o[53]} "
               f"| spmm_it3: wave={o[30]-o[41]} row={o[32]-o[30]} quad={o[20]-o[32]} lane={o[8]-o[20]} | G: zero={o[44]-o[4]} pairs={o[45]-o[44]} conv={o[5]-o[45]}")
+        print(f"     atomic form (k >= 4): stage={o[1]-o[0]} top+init+orth={o[5]-o[1]} | it2: zero+product={o[9]-o[5]} convert+gram={o[40]-o[9]} chol+orth={o[41]-o[40]} "
+              f"| it3: zero={o[20]-o[41]} product={o[30]-o[20]} convert={o[8]-o[30]} | rest={o[11]-o[8]} total={o[11]-o[0]}")
 PY

@@ -65,6 +65,40 @@ __global__ __launch_bounds__(512) void k(long long* out, const unsigned* idx_g, 
             }
         }
         acc = (unsigned)(a0 + a1 + a2 + a3);
+    } else if (mode == 14) {  // random u64 atomic add, no return
+        unsigned long long* l64 = reinterpret_cast<unsigned long long*>(lds);
+#pragma unroll
+        for (int i = 0; i < N; ++i) atomicAdd(&l64[idx[i] >> 1], (unsigned long long)i + t);
+    } else if (mode == 15) {  // same-address u64 atomic add, no return (all lanes of a wave one word)
+        unsigned long long* l64 = reinterpret_cast<unsigned long long*>(lds);
+#pragma unroll
+        for (int i = 0; i < N; ++i) atomicAdd(&l64[i], (unsigned long long)i + t);
+    } else if (mode == 16) {  // scatter product: per step 1 random b64 read + fma + 1 random u64 atomic (x N)
+        unsigned long long* l64 = reinterpret_cast<unsigned long long*>(lds);
+        const double* ld = reinterpret_cast<const double*>(lds);
+        const double magic = 6755399441055744.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double x = __builtin_fma((double)(idx[i] & 255u), ld[idx[(i + 7) & (N - 1)] >> 1], magic);
+            atomicAdd(&l64[(idx[i] >> 1) & 8191], (unsigned long long)__double_as_longlong(x) - (unsigned long long)__double_as_longlong(magic));
+        }
+    } else if (mode == 17) {  // u64 atomics, 8 distinct addresses per wave (hot rows)
+        unsigned long long* l64 = reinterpret_cast<unsigned long long*>(lds);
+#pragma unroll
+        for (int i = 0; i < N; ++i) atomicAdd(&l64[(idx[i] >> 1) & 7], (unsigned long long)i + t);
+    } else if (mode == 18 || mode == 19) {  // u64 atomics, 28 % of the lanes on 4 hot words, the rest random over 1024 (18) / 4096 (19) words
+        unsigned long long* l64 = reinterpret_cast<unsigned long long*>(lds);
+        const unsigned span = mode == 18 ? 1023u : 4095u;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const unsigned h = idx[i];
+            const unsigned a = ((h >> 20) & 255u) < 72u ? (h & 3u) * 37u : (h >> 1) & span;
+            atomicAdd(&l64[a], (unsigned long long)i + t);
+        }
+    } else if (mode == 20) {  // u64 atomics random over 1024 words
+        unsigned long long* l64 = reinterpret_cast<unsigned long long*>(lds);
+#pragma unroll
+        for (int i = 0; i < N; ++i) atomicAdd(&l64[(idx[i] >> 1) & 1023u], (unsigned long long)i + t);
     } else if (mode == 9) {   // same-address atomics with return (all lanes one word per wave)
 #pragma unroll
         for (int i = 0; i < N; ++i) acc += atomicAdd(&lds[i], 1u);
@@ -82,8 +116,8 @@ int main() {
     for (auto& v : h) { x = x * 1664525u + 1013904223u; v = x >> 8; }
     hipMemcpy(idx, h.data(), 65536 * 4, hipMemcpyHostToDevice);
     const char* names[] = {"random b32 read", "linear b32 read", "dependent chain", "random atomic add", "random atomic add rtn",
-                           "random b64 read", "random b32 write", "team gather b64 pitch5", "random u16 read", "same-address atomic rtn", "row gather 2xb128 pitch4", "row gather 2xb128 pitch6", "row gather 4xb64 pitch5", "row gather 2xb128 pitch8"};
-    for (int mode = 0; mode < 14; ++mode) {
+                           "random b64 read", "random b32 write", "team gather b64 pitch5", "random u16 read", "same-address atomic rtn", "row gather 2xb128 pitch4", "row gather 2xb128 pitch6", "row gather 4xb64 pitch5", "row gather 2xb128 pitch8", "random u64 atomic add", "same-address u64 atomic", "read b64 + fma + atomic u64", "u64 atomic on 8 addresses", "u64 atomic 28% hot4 + 1024", "u64 atomic 28% hot4 + 4096", "u64 atomic random 1024"};
+    for (int mode = 0; mode < 21; ++mode) {
         for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k, dim3(1), dim3(512), 131072, 0, d, idx, mode);
         long long c[2];
         hipMemcpy(c, d, 16, hipMemcpyDeviceToHost);
