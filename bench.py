@@ -144,8 +144,27 @@ def spawn_ranks(args):
 
 
 # ----------------------------------------------------------------------------------------------- roofline
+def real_work(status, a_arr, n_taxa, patterns):
+    """What one launch really computes (from the status words of the last step): sparse half products of the general
+    path (smaller side >= 4 taxa; the first one is a scatter of 4 rows and not counted) x non-zeros x 4 block columns."""
+    import numpy as np
+
+    if status is None:
+        return None
+    st = np.asarray(status).reshape(-1, len(a_arr))
+    k = np.minimum(a_arr, n_taxa - a_arr)
+    general = k >= 4
+    halves = int(np.sum(np.maximum((st[:, general] >> 8) - 1, 0)))
+    dense_products = int(np.sum(st[:, ~general] >> 8))
+    return {"sparse_half_products": halves, "nnz": int(patterns), "block_columns": 4,
+            "fma": halves * int(patterns) * 4,
+            "small_side_splits": int(np.count_nonzero(~general)) * st.shape[0], "their_dense_G_products": dense_products,
+            "note": "general path: W = C^T V / Y = C W on the D non-zeros; smaller sides of <= 3 taxa iterate on the exact "
+                    "integer Gram matrix (<= 64 x 64) instead"}
+
+
 def roofline_block(dom, dom_ms_alone, dom_ms_region, in_flight, phases_per_step, n_taxa, n_sites, a_arr, n_items_per_launch,
-                   patterns, lanes):
+                   patterns, lanes, status=None):
     import numpy as np
 
     k_small = np.minimum(a_arr, n_taxa - a_arr).astype(np.float64)
@@ -210,7 +229,7 @@ def roofline_block(dom, dom_ms_alone, dom_ms_region, in_flight, phases_per_step,
                          "lds_busy_frac": lds / avail,
                          "bank_conflict_share": pmc["SQ_LDS_BANK_CONFLICT"] / lds if lds else None,
                          "valu_issue_frac": valu_quad * 4.0 / (4 * avail) if valu_quad else None,
-                         "real_work": pmc.get("real_work"),
+                         "real_work": real_work(status, a_arr, n_taxa, patterns),
                          "cycle_base": f"{N_CU} CUs x launch_ms x {CLOCK_GHZ} GHz (profiles/r02_pmc_binding.json holds the "
                                        "GRBM_GUI_ACTIVE / 8 of the profiled launches next to it)",
                          "source": "profiles/r02_pmc_binding.json"}})
@@ -494,7 +513,7 @@ def main():
         launches_per_step = ph[dom][1] / args.steps
         roof = roofline_block(dom, dom_ms_alone, ph[dom][0] / ph[dom][1], ph[dom][0] / (elapsed * 1e3),
                               {k: round(v[0] / args.steps, 5) for k, v in ph.items()}, n_taxa, n_sites, a_arr,
-                              items_rank / max(launches_per_step, 1e-9), n_patterns, n_lanes)
+                              items_rank / max(launches_per_step, 1e-9), n_patterns, n_lanes, status=status)
         if shard_splits:
             par = f"split-sharded x{world}: one alignment replicated, candidate splits dealt by cost class, all_gather of scores + status"
         elif world > 1:
