@@ -28,8 +28,14 @@ typedef int int16_t_v __attribute__((ext_vector_type(16)));
 #define GI_FLUSH 32768      // columns between int32 -> fp64 flushes
 
 // GT = int (every entry of G is known to fit: max_count * N < 2^31) or double.
+// (launch bounds: at least GI_WAVES_PER_SIMD workgroups' worth of waves per SIMD - left to itself the compiler unrolled
+// the k loop into 332 registers + scratch, i.e. ONE workgroup per CU, and the kernel sat at 7 % MFMA busy waiting for
+// its own loads: profiles/r02_pmc_dense_route_before.json)
+#ifndef GI_WAVES_PER_SIMD
+#define GI_WAVES_PER_SIMD 3
+#endif
 template <int NL, typename GT>
-__global__ __launch_bounds__(256) void k_gram_i8(const SplitDev* __restrict__ splits,
+__global__ __launch_bounds__(256, GI_WAVES_PER_SIMD) void k_gram_i8(const SplitDev* __restrict__ splits,
                                                  const GramItem* __restrict__ items,
                                                  const int2* __restrict__ dims, const uint8_t* __restrict__ mats,
                                                  GT* __restrict__ grams) {
@@ -61,14 +67,16 @@ __global__ __launch_bounds__(256) void k_gram_i8(const SplitDev* __restrict__ sp
     const int v0 = threadIdx.x, v1 = threadIdx.x + 256;
     const int r0 = v0 >> 3, c0 = (v0 & 7) * 16, r1 = v1 >> 3, c1 = (v1 & 7) * 16;
 
-    int16_t_v acc[NL][NL];
+    // one int32 accumulator set per limb weight a + b (products of equal weight share a set: NL = 2 needs 3 sets, not
+    // 4; NL = 3 needs 5, not 9); NL products of 127^2 * GI_FLUSH columns stay below 2^31
+    constexpr int NS = 2 * NL - 1;
+    static_assert((long long)NL * 127 * 127 * GI_FLUSH < (1ll << 31), "int32 partial sums");
+    int16_t_v acc[NS];
     long long facc[16];
 #pragma unroll
-    for (int a = 0; a < NL; ++a)
+    for (int w2 = 0; w2 < NS; ++w2)
 #pragma unroll
-        for (int b = 0; b < NL; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
+        for (int e = 0; e < 16; ++e) acc[w2][e] = 0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) facc[e] = 0;
 
@@ -116,19 +124,17 @@ __global__ __launch_bounds__(256) void k_gram_i8(const SplitDev* __restrict__ sp
                 for (int a = 0; a < NL; ++a)
 #pragma unroll
                     for (int b = 0; b < NL; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                        acc[a + b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a + b], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int a = 0; a < NL; ++a)
+        for (int w2 = 0; w2 < NS; ++w2) {
 #pragma unroll
-            for (int b = 0; b < NL; ++b) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    facc[e] += (long long)acc[a][b][e] << (7 * (a + b));
-                    acc[a][b][e] = 0;
-                }
+            for (int e = 0; e < 16; ++e) {
+                facc[e] += (long long)acc[w2][e] << (7 * w2);
+                acc[w2][e] = 0;
             }
+        }
     }
     // epilogue: 32x32 C/D layout is col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     // The tile goes through LDS so that both G[ti-block][tj-block] and its mirror G[tj-block][ti-block]

@@ -1864,9 +1864,14 @@ int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa
     q.slab_h = (sparse_slab_bytes(d_max, bm_words_max, false) + 255) & ~(size_t)255;
     q.slab_w = (sparse_slab_bytes(d_max, bm_words_max, true) + 255) & ~(size_t)255;
     q.slab_stride = std::max(q.slab_l, std::max(q.slab_h, q.slab_w));
-    // few items: a handful of workgroups scan them in large chunks (an empty pass is all but free); many: one workgroup
-    // per CU drawing small chunks (balance).  Huge slabs shrink the grid (8 GB pool at most).
-    q.chunk = n_items >= 16384 ? 8 : 64;
+    // Grid of the slow kernel - a matter of speed only, any grid finishes every item.  Tables the in-LDS form cannot
+    // hold by size alone (or a test's pretended LDS size): most items WILL come here, so one workgroup per CU draws small
+    // chunks (a slow item runs 30 - 500 us: balance).  Otherwise hand-backs are rare (data-dependent fits, gapless
+    // spectra) and the common case is an empty pass: a handful of workgroups scan the status words 64 at a time - each
+    // workgroup of this kernel has to wait for a CU whose whole LDS is free, which at one per CU costs the pipelined
+    // benchmark loop 3.7 % (0.1043 against 0.1006 ms per step).  Huge slabs shrink the grid (8 GB pool at most).
+    const bool expect_many = (size_t)(d_max + 8) * 8 + (size_t)d_max * 6 + 12288 > (size_t)SPK_LDS_BYTES || ctx->opt.lds_cap > 0;
+    q.chunk = expect_many ? (int)std::max<int64_t>(1, std::min<int64_t>(8, n_items / (32 * (int64_t)std::max(ctx->n_cu, 1)))) : 64;
     const int64_t nchunks = (n_items + q.chunk - 1) / q.chunk;
     int grid = (int)std::min<int64_t>(ctx->n_cu, nchunks);
     grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, std::max<int64_t>(16, ((int64_t)8 << 30) / (int64_t)q.slab_stride)));

@@ -7,10 +7,11 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
-CMD="python3 bench.py --steps 24 --warmup 4 --lanes 1 --no-cpu-baseline --spinup 0.2"
+CMD="python3 bench.py --steps ${PMC_STEPS:-24} --warmup 4 --lanes 1 --no-cpu-baseline --spinup 0.2 ${BENCH_ARGS:-}"
 : > $OUT/passes.txt
 i=0
 for pass in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM SQ_WAIT_INST_ANY TCC_HIT_sum TCC_MISS_sum" \
             "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE" \
             "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
