@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsplitp_hip.so")
+# (SPLITP_LIB: load another build of the same library instead, e.g. `make -C splitp_amd/csrc asan` - host code under
+# AddressSanitizer, device code unchanged)
+LIB_PATH = os.environ.get("SPLITP_LIB") or os.path.join(_HERE, "libsplitp_hip.so")
 
 SP_METHOD_FLATTENING = 0
 SP_METHOD_SUBFLATTENING = 1

@@ -888,6 +888,11 @@ __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double t
             if (gap && bounded && (delta <= 0.2 * tol || tail <= tol)) conv = true;
         }
     }
+#ifdef SPK_DEBUG_CONV
+    if (threadIdx.x == 0 && (blockIdx.x % 97) == 0)
+        printf("blk %d k %d s4/trace %.15f delta/s %.3e ratio %.3e rest/s %.3e lam/s %.3e conv %d\n", (int)blockIdx.x, k, s4 / trace,
+               delta / s4, ratio, (trace - s4) / s4, lam_lb / s4, (int)conv);
+#endif
     prev_ratio = ratio;
     prev_delta = delta;
     prev_sum = s4;
