@@ -1495,3 +1495,78 @@ def test_wide_block_plateau_regression(sp, monkeypatch):
     got, st = sp.score_splits(dev, spl, return_status=True)
     assert abs(got[0] - want) <= SCORE_TOL and not (st[0] & 3)
     assert abs(sp.score_splits(dev_w, spl)[0] - want) <= SCORE_TOL
+
+
+def test_plan_abi_errors_and_refcount(sp, golden):
+    """sp_plan / sp_score_plan_async misuse is answered with status codes, never a crash: NULL arguments, a split that
+    does not cover the taxa, an alignment of another taxon count, a float-weight table (no sparse route), and the
+    reference count keeps a plan alive until its last holder lets go."""
+    import ctypes as C
+    import torch
+    from splitp_amd import _lib, batch
+
+    g = golden("n10_L10k")
+    names = taxa_names(10)
+    dev = sp.DeviceAlignment.from_table(O.unpack_table(g["keys"], g["probs"], 10), taxa=names)
+    lib, ctx = dev.ctx._lib, dev.ctx
+    taxa_arr, a_arr = sp.encode_all_splits(10)
+    h = C.c_void_p()
+    assert lib.sp_plan_create(None, 10, _lib._ptr(taxa_arr, C.c_int32), _lib._ptr(a_arr, C.c_int32), 501, C.byref(h)) == _lib.SP_EINVAL
+    bad = taxa_arr.copy()
+    bad[3, 0] = bad[3, 1]                                           # a taxon twice
+    assert lib.sp_plan_create(ctx.handle, 10, _lib._ptr(bad, C.c_int32), _lib._ptr(a_arr, C.c_int32), 501, C.byref(h)) == _lib.SP_EINVAL
+    assert b"twice" in lib.sp_last_error()
+    plan = batch.SplitPlan(ctx, taxa_arr, a_arr, 10)
+    n, s = C.c_int(), C.c_int64()
+    assert lib.sp_plan_info(plan.handle, C.byref(n), C.byref(s)) == 0 and (n.value, s.value) == (10, 501)
+    sc = torch.zeros(501, dtype=torch.float64, device="cuda")
+    st = torch.zeros(501, dtype=torch.int32, device="cuda")
+    one = (C.c_void_p * 1)(dev.handle.value)
+    assert lib.sp_score_plan_async(ctx.handle, one, 1, plan.handle, None, C.c_void_p(st.data_ptr())) == _lib.SP_EINVAL
+    keys8, counts8 = np.arange(50, dtype=np.uint64), np.ones(50, dtype=np.int64)
+    dev8 = sp.DeviceAlignment.from_arrays(keys8, None, 8, counts=counts8, n_sites=50, taxa=taxa_names(8))
+    other = (C.c_void_p * 1)(dev8.handle.value)
+    assert lib.sp_score_plan_async(ctx.handle, other, 1, plan.handle, C.c_void_p(sc.data_ptr()), C.c_void_p(st.data_ptr())) == _lib.SP_EINVAL
+    dev_w = sp.DeviceAlignment.from_arrays(g["keys"], g["probs"], 10, taxa=names, exact=False)
+    fl = (C.c_void_p * 1)(dev_w.handle.value)
+    assert lib.sp_score_plan_async(ctx.handle, fl, 1, plan.handle, C.c_void_p(sc.data_ptr()), C.c_void_p(st.data_ptr())) == _lib.SP_ELIMIT
+    assert b"float weights" in lib.sp_last_error()
+    # retain / release: the Python object's finalizer drops the creator's reference, ours keeps the plan usable
+    assert lib.sp_plan_retain(plan.handle) == 0
+    handle = C.c_void_p(plan.handle.value)
+    del plan
+    import gc
+    gc.collect()
+    assert lib.sp_score_plan_async(ctx.handle, one, 1, handle, C.c_void_p(sc.data_ptr()), C.c_void_p(st.data_ptr())) == 0
+    torch.cuda.synchronize()
+    assert np.abs(sc.cpu().numpy() - g["scores"]).max() <= SCORE_TOL and not np.any(st.cpu().numpy() & 3)
+    assert lib.sp_plan_release(handle) == 0
+
+
+def test_bench_line_contract(sp):
+    """`python bench.py` (short) on this GPU: ONE JSON line on stdout with the contract's keys, the roofline block
+    (bound / achieved / peak / unit / frac / traffic + the binding counters) and a consistent value."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "60", "--warmup", "6", "--no-cpu-baseline",
+                        "--spinup", "0.2"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 60 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and d["config"]["unconverged_splits_in_timed_region"] == 0
+    assert abs(d["value"] - 501 * 60 / (d["ms_per_step"] * 60 * 1e-3)) <= 1e-6 * d["value"]
+    roof = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "survey_8d"):
+        assert key in roof, key
+    assert roof["bound"] == "lds" and 0.05 < roof["frac"] < 1.0 and roof["traffic"] > 0
+    assert 0.2 < roof["binding"]["bank_conflict_share"] < 0.8 and roof["binding"]["real_work"]["fma"] > 1e7
