@@ -24,242 +24,8 @@
 // size class depends on the arrival order of aggregated atomics - that moves groups around, never a sum.
 // A split whose arrays do not fit the 160 KiB of LDS is flagged (status 2) and re-run by the same kernel instantiated on
 // a slab of global memory (HBM = true); one that has not converged after SPK_MAXIT products goes to the dense route.
-#include "common.h"
-
-#include "eig_small.h"   // jacobi_nb / EigShared for the wide fallback block
-
-#include <cstring>
-#include <type_traits>
-#include <rocprim/rocprim.hpp>   // segmented radix sort for the big-table form
-
-#ifndef SPK_THREADS
-#define SPK_THREADS 1024
-#endif
-#define SPK_WAVES (SPK_THREADS / 64)
-#define SPK_SORT_WAVES 8    // wave-private counter rows of the counting sort (waves beyond them sit the two passes out)
-#define SPK_NB 4
-#ifndef SPK_TEAM_MAX
-#define SPK_TEAM_MAX 32     // a column / row with more entries than this is shared by the 16 lanes of a row (9..32: a quad)
-#endif
-#ifndef SPK_ROW_MAX
-#define SPK_ROW_MAX 128     // ... and with more than this by the 64 lanes of a wave
-#endif
-#define SPK_MAXIT 40        // dense products of the small-side path (cheap)
-#define SPK_MAXHALF 40      // sparse half products of the general path; a block without a spectral gap behind it goes to
-                            // the dense route long before (spk_converged)
-#define SPK_LDS_BYTES 163840
-#define SPK_SMALL_R 64
-
-#ifdef SPK_STAMPS
-__device__ long long g_spk_stamps[64];
-__device__ int g_spk_stamp_block = 0;
-#define SSTAMP(i)                                                                              \
-    do {                                                                                       \
-        __syncthreads();                                                                       \
-        if (threadIdx.x == 0 && (int)blockIdx.x == g_spk_stamp_block) g_spk_stamps[i] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-extern "C" int sp_debug_spk_stamp_block(int b) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_spk_stamp_block), &b, sizeof(int)) == hipSuccess ? 0 : 2;
-}
-extern "C" int sp_debug_spk_stamps(long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spk_stamps), sizeof(long long) * 64) == hipSuccess ? 0 : 2;
-}
-#else
-#define SSTAMP(i)
-#endif
-
-struct SpkShared {
-    double red[SPK_WAVES * 16];
-    double S[16];        // X^T X of the current block (full symmetric 4 x 4, row-major)
-    double L[12];        // its Cholesky factor: 1 / l_jj (4), l_10 l_20 l_30 l_21 l_31 l_32, pivot ratio, eigenvalue bound
-    double top4;
-    unsigned long long trace;
-    int R, Kc, nw_c, nr_c, nq_c, nw_r, nr_r, nq_r, used_c, used_r, qchunk, pad1;   // nw_* / nr_*: groups handled by a whole wave / by a 16-lane row
-    int shifts[32];
-    // (trace above and the two below: copies of the alignment metadata, fetched while the table is being staged)
-    u32 top[SPK_NTOP];
-    u32 ntop, ntab;             // ntab: rows of the table before large counts were split (== D when none was)
-    unsigned int scan[SPK_WAVES + 1];
-    unsigned int bucket[68];
-};
-
-__device__ __forceinline__ double spk_hash(unsigned a, unsigned b) {
-    unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return (double)x * (2.0 / 4294967296.0) - 1.0;
-}
-
-__device__ __forceinline__ double spk_rsqrt(double x) {
-    double y = (double)__frsqrt_rn((float)x);
-    y = y * (1.5 - 0.5 * x * y * y);
-    y = y * (1.5 - 0.5 * x * y * y);
-    y = y * (1.5 - 0.5 * x * y * y);
-    return y;
-}
-
-__device__ __forceinline__ void spk_rowcol(u64 key, const int* shifts, int nr, int nc, u32& r, u32& c) {
-    u32 rr = 0, cc = 0;
-    for (int i = 0; i < nr; ++i) rr = (rr << 2) | (u32)((key >> shifts[i]) & 3ull);
-    for (int i = 0; i < nc; ++i) cc = (cc << 2) | (u32)((key >> shifts[nr + i]) & 3ull);
-    r = rr;
-    c = cc;
-}
-
-// exclusive scan of one u32 per thread over the block; returns the exclusive prefix, total in `total`
-__device__ __forceinline__ u32 spk_scan(u32 v, SpkShared& sh, u32& total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    u32 x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    __syncthreads();
-    if (lane == 63) sh.scan[w] = x;
-    __syncthreads();
-    u32 base = 0, tot = 0;
-    for (int i = 0; i < SPK_WAVES; ++i) {
-        if (i < w) base += sh.scan[i];
-        tot += sh.scan[i];
-    }
-    total = tot;
-    return base + x - v;
-}
-
-// read of a word that other waves of the workgroup have updated with atomics (see k_sparse_score, HBM form); for LDS
-// pointers this is a plain ds_read
-template <typename T>
-__device__ __forceinline__ T spk_aload(const T* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// rank of key k in a presence bitmap with per-word exclusive popcount prefixes
-__device__ __forceinline__ u32 bm_rank(const u64* bm, const u32* pf, u32 k) {
-    return pf[k >> 6] + __popcll(spk_aload(bm + (k >> 6)) & ((1ull << (k & 63)) - 1));
-}
-
-// S = X^T X of the rows x 4 block X (row pitch `pitch` doubles) on the matrix cores: one v_mfma_f64_4x4x4 (4 blocks of
-// 4 x 4 x 4) consumes 16 rows; lane l supplies X[base + l/4][l%4] as BOTH operands (A[i][k] of block b sits in lane
-// i + 4b + 16k, B[k][j] in lane j + 4b + 16k - probed, tools/mfma_f64_4x4_probe.hip), D[i][j] of block b comes back in
-// lane j + 4b + 16i.  Blocks are summed with two shuffles, waves through LDS in a fixed order.  Ends with a barrier.
-__device__ __forceinline__ void spk_gram(const double* X, int rows, int rs, int cs, SpkShared& sh) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = lane & 3, rl = lane >> 2;
-    double acc = 0.0;
-    for (int base = w * 16; base < rows; base += SPK_WAVES * 16) {
-        const int row = base + rl;
-        const double x = row < rows ? X[row * rs + c * cs] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(x, x, acc, 0, 0, 0);
-    }
-    acc += __shfl_xor(acc, 4, 64);
-    acc += __shfl_xor(acc, 8, 64);
-    if ((lane & 12) == 0) sh.red[w * 16 + (lane >> 4) * 4 + (lane & 3)] = acc;
-    __syncthreads();
-    if (threadIdx.x < 16) {
-        double t = 0;
-        for (int i = 0; i < SPK_WAVES; ++i) t += sh.red[i * 16 + threadIdx.x];
-        sh.S[threadIdx.x] = t;
-    }
-    __syncthreads();
-}
-
-// Cholesky-QR step: S = L L^T (sh.S, factored by wave 0, broadcast through sh.L), X <- X L^-T by forward substitution per
-// row, so that X^T X = I.  A pivot below 1e-28 of the largest diagonal marks a dead direction (rank < 4): its column
-// becomes zero and stays zero.  Returns min pivot / max pivot (conditioning indicator).  Ends with a barrier.
-// Factor: wave 0 (64 lanes redundantly, no divergence) -> sh.L = 1 / l_jj (4), l_10 l_20 l_30 l_21 l_31 l_32, the pivot
-// ratio, and an estimate of the smallest eigenvalue of S (inverse iteration).
-// Ends with a barrier.
-__device__ __forceinline__ void spk_chol_factor(SpkShared& sh, bool want_lam = true, double rest = 1e300) {
-    if (threadIdx.x < 64) {
-        const double s00 = sh.S[0], s10 = sh.S[4], s20 = sh.S[8], s30 = sh.S[12];
-        const double s11 = sh.S[5], s21 = sh.S[9], s31 = sh.S[13], s22 = sh.S[10], s32 = sh.S[14], s33 = sh.S[15];
-        const double dmax = fmax(fmax(s00, s11), fmax(s22, s33));
-        const double tiny = 1e-28 * dmax;
-        const double d0 = s00;
-        const double i0 = d0 > tiny ? spk_rsqrt(d0) : 0.0;
-        const double l10 = s10 * i0, l20 = s20 * i0, l30 = s30 * i0;
-        const double d1 = fma(-l10, l10, s11);
-        const double i1 = d1 > tiny ? spk_rsqrt(d1) : 0.0;
-        const double l21 = fma(-l20, l10, s21) * i1, l31 = fma(-l30, l10, s31) * i1;
-        const double d2 = fma(-l21, l21, fma(-l20, l20, s22));
-        const double i2 = d2 > tiny ? spk_rsqrt(d2) : 0.0;
-        const double l32 = fma(-l31, l21, fma(-l30, l20, s32)) * i2;
-        const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33)));
-        const double i3 = d3 > tiny ? spk_rsqrt(d3) : 0.0;
-        const double pmin = fmin(fmin(d0 > tiny ? d0 : dmax, d1 > tiny ? d1 : dmax), fmin(d2 > tiny ? d2 : dmax, d3 > tiny ? d3 : dmax));
-        // smallest eigenvalue of S by three steps of inverse iteration through the factor (x <- S^-1 x = L^-T L^-1 x from
-        // x = 1): the Rayleigh quotient approaches it from above, fast unless it sits in a cluster (then any value of
-        // the cluster will do); a dead pivot makes S singular: 0
-        // A lower bound first, free of the serial chain below: lambda_min = det / (lambda_1 lambda_2 lambda_3) >=
-        // det (3 / trace)^3 (AM-GM), det = product of the pivots.  On real alignments it is ~0.4 lambda_min and the
-        // stop rule's tests (rest <= 0.6 lam, error bound) pass with it; only when `rest` is not clearly below it is the
-        // estimate sharpened by inverse iteration.
-        const double tr4 = (s00 + s11) + (s22 + s33);
-        const double cheap = (d0 > tiny && d1 > tiny && d2 > tiny && d3 > tiny && tr4 > 0)
-                                 ? ((d0 * d1) * (d2 * d3)) * (27.0 / (tr4 * tr4 * tr4)) : 0.0;
-        double lam_min = cheap;
-        if (want_lam && !(rest <= 0.3 * cheap)) {   // (uniform; only the convergence test reads it, from its 4th sum on)
-            double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0, mu = 0.0;
-#pragma unroll
-            for (int itv = 0; itv < 3; ++itv) {
-                // y = L^-1 x (forward), z = L^-T y (backward)
-                const double y0 = x0 * i0;
-                const double y1 = fma(-l10, y0, x1) * i1;
-                const double y2 = fma(-l21, y1, fma(-l20, y0, x2)) * i2;
-                const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, x3))) * i3;
-                const double z3 = y3 * i3;
-                const double z2 = fma(-l32, z3, y2) * i2;
-                const double z1 = fma(-l31, z3, fma(-l21, z2, y1)) * i1;
-                const double z0 = fma(-l30, z3, fma(-l20, z2, fma(-l10, z1, y0))) * i0;
-                const double xx = x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
-                const double xz = x0 * z0 + x1 * z1 + x2 * z2 + x3 * z3;      // x^T S^-1 x
-                mu = xz > 0 ? xx / xz : 0.0;                                   // Rayleigh quotient of S at x
-                const double nz = spk_rsqrt(z0 * z0 + z1 * z1 + z2 * z2 + z3 * z3 + 1e-300);
-                x0 = z0 * nz; x1 = z1 * nz; x2 = z2 * nz; x3 = z3 * nz;
-            }
-            lam_min = mu;
-        }
-        const bool full = i0 > 0 && i1 > 0 && i2 > 0 && i3 > 0;
-        const double tinv = full ? 1.0 / lam_min : 0.0;
-        if (threadIdx.x == 0) {
-            sh.L[0] = i0; sh.L[1] = i1; sh.L[2] = i2; sh.L[3] = i3;
-            sh.L[4] = l10; sh.L[5] = l20; sh.L[6] = l30; sh.L[7] = l21; sh.L[8] = l31; sh.L[9] = l32;
-            sh.L[10] = dmax > 0 ? pmin / dmax : 1.0;
-            sh.L[11] = full && tinv > 0 ? lam_min : 0.0;
-        }
-    }
-    __syncthreads();
-}
-
-// Apply: X <- X L^-T by forward substitution per row (sh.L).  Returns the pivot ratio.  Ends with a barrier.
-__device__ __forceinline__ double spk_chol_apply(double* X, int rows, int rs, int cs, SpkShared& sh) {
-    const double i0 = sh.L[0], i1 = sh.L[1], i2 = sh.L[2], i3 = sh.L[3];
-    const double l10 = sh.L[4], l20 = sh.L[5], l30 = sh.L[6], l21 = sh.L[7], l31 = sh.L[8], l32 = sh.L[9];
-    const double ratio = sh.L[10];
-    for (int row = threadIdx.x; row < rows; row += SPK_THREADS) {
-        double* x = X + row * rs;
-        const double v0 = x[0] * i0;
-        const double v1 = fma(-l10, v0, x[cs]) * i1;
-        const double v2 = fma(-l21, v1, fma(-l20, v0, x[2 * cs])) * i2;
-        const double v3 = fma(-l32, v2, fma(-l31, v1, fma(-l30, v0, x[3 * cs]))) * i3;
-        x[0] = v0; x[cs] = v1; x[2 * cs] = v2; x[3 * cs] = v3;
-    }
-    __syncthreads();
-    return ratio;
-}
-
-// Orthonormalise the block in place (its Gram matrix is already in sh.S).  One Cholesky-QR pass leaves
-// |X^T X - I| ~ eps * cond(S); count flattenings have four leading singular values of one magnitude (cond < 100), so
-// one pass is enough; an ill-conditioned block (pivot ratio < 0.05) gets up to two more passes (CholeskyQR2/3).
-// (the caller has run spk_gram + spk_chol_factor on the block)
-__device__ __forceinline__ void spk_orth(double* X, int rows, int rs, int cs, SpkShared& sh) {
-    double ratio = spk_chol_apply(X, rows, rs, cs, sh);
-    for (int pass = 0; pass < 2 && ratio < 0.05; ++pass) {
-        spk_gram(X, rows, rs, cs, sh);
-        spk_chol_factor(sh);
-        ratio = spk_chol_apply(X, rows, rs, cs, sh);
-    }
-}
+#define SPK_MAIN_TU
+#include "sparse_common.h"
 
 // Build one list grouped by `major` (CSC: compact column, CSR: compact row) as a STABLE counting sort of the
 // table order: the table is cut into SPK_SORT_WAVES contiguous chunks, wave w owns chunk w and a private row of
@@ -845,208 +611,6 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
         spk_store4(out + m * out_pitch, out_cs, a);
     }
     __syncthreads();
-}
-
-// Stop when the Ritz sum has settled AND the spectrum behind the block is known to be separated from it.
-// s_1, s_2, ... increase monotonically towards the limit with an (eventually) constant error ratio
-// rho = (sigma_5 / sigma_4)^2, so delta_k = s_k - s_(k-1) ~ the error of s_(k-1) and the error left after s_k is the
-// geometric tail delta_k rho / (1 - rho).  rho is taken as the LARGER of the last two measured ratios (early ratios are
-// optimistic: with a single ratio 20 % of the splits stopped one product early with 3e-11 left in the score).
-// The sums alone cannot tell "converged" from "stalled": when sigma_4 ~ sigma_5 the block finds three directions and a
-// mix of the 4th / 5th, and the sum stops moving with the error (lambda_4 - lambda_5) sin^2 still in it (found by the
-// randomised tests: 6e-5 in a score).  Hence the guard: everything outside the block weighs trace - s, so
-// lambda_5 <= trace - s; accept only if that is at most 0.6 of `lam_lb`, the smallest Ritz value in the block (smallest
-// eigenvalue of the Gram matrix just factored, by inverse iteration) - then lambda_5 / lambda_4 <= 0.6, no stall is
-// possible and the measured ratios are real - or if trace - s is itself below the tolerance.  A block that never
-// passes the guard runs out of half products and is handed to the dense route (16-wide block), where clusters are at home.
-// Tolerance: the score is sqrt(1 - s / trace); 1e-13 relative in s is < 1e-11 in any score >= 0.005.
-__device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double trace, int k, double& prev_sum,
-                                              double& prev_delta, double& prev_ratio) {
-    bool conv = false;
-    const double delta = fabs(s4 - prev_sum);
-    double ratio = 1.0;
-    if (k >= 3) {   // delta_2 is the first real difference, so ratios exist from k = 3 on
-        ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
-        ratio = fmin(fmax(ratio, 0.0), 0.9999);
-        if (k >= 4) {
-            const double rest = trace - s4;                    // >= lambda_5 + lambda_6 + ...
-            const double r = fmax(ratio, prev_ratio);
-            const double tail = delta * r / (1.0 - r);
-            const bool gap = rest <= 0.6 * lam_lb || rest <= 1e-13 * trace;
-            // Tolerance on s: 1e-13 relative, tightened for tiny scores (d score = d s / (2 score trace): keep it
-            // below 2e-11) down to the rounding floor of the Ritz sum (~2e-15 relative, so 4e-15 is the least asked).
-            const double sx = sqrt(fmax(rest, 0.0) * trace);   // = score * trace
-            const double tol = fmax(fmin(1e-13 * s4, 4e-11 * sx), 4e-15 * s4);
-            // Measured ratios can hide a slow component of small amplitude behind fast ones (a rank-5 flattening
-            // stopped 3e-8 early in the randomised tests).  No component is slower than lambda_5 / lambda_4 <= rho_b =
-            // rest / lam_lb per half product, and e_k <= rho (e_k + delta_k) makes delta rho_b / (1 - rho_b) a BOUND of
-            // the error left.  rest overestimates lambda_5 ~10x on real alignments, so asking the bound to meet `tol`
-            // would cost every split a half product; it is asked to keep the SCORE within 5e-11 instead
-            // (d s <= 1e-10 score trace), which the estimate-based stop already implies unless rho_b >> r.
-            const double rho_b = lam_lb > 0 ? fmin(rest / lam_lb, 0.9999) : 0.9999;
-            const bool bounded = delta * rho_b / (1.0 - rho_b) <= fmax(1e-10 * sx, 4e-15 * s4);
-            if (gap && bounded && (delta <= 0.2 * tol || tail <= tol)) conv = true;
-        }
-    }
-#ifdef SPK_DEBUG_CONV
-    if (threadIdx.x == 0 && (blockIdx.x % 97) == 0)
-        printf("blk %d k %d s4/trace %.15f delta/s %.3e ratio %.3e rest/s %.3e lam/s %.3e conv %d\n", (int)blockIdx.x, k, s4 / trace,
-               delta / s4, ratio, (trace - s4) / s4, lam_lb / s4, (int)conv);
-#endif
-    prev_ratio = ratio;
-    prev_delta = delta;
-    prev_sum = s4;
-    return conv;
-}
-
-
-// ---- wide fallback block (HBM form only) ---------------------------------------------------------------------------
-// A 4-wide block converges by lambda_5 / lambda_4 per half product: tables whose flattenings have a cluster or a slowly
-// decaying spectrum behind the 4th value (found by the randomised tests at 12 taxa, where the dense route cannot take
-// over) run out of half products.  Such splits are re-run with SPK_WB = 8 columns: the same lists and the same product
-// code (two 4-column passes), but the Ritz values are the eigenvalues of the 8 x 8 Gram matrix of the fresh block
-// (one-wave Jacobi, eig_small.h) - the top-4 sum then converges by lambda_9 / lambda_4 and a cluster at the 4th value
-// sits inside the block - and the block is re-orthonormalised as X Q D^-1/2 plus Newton-Schulz polish.
-#define SPK_WB 8
-#define SPK_MAXHALF_WIDE 600
-
-// esh.H (16 x EIG_VP, first 8 x 8 used) = X^T X of the rows x 8 column-major block X: one (i, j >= i) pair per wave and
-// turn, lanes stride the rows, fixed shuffle tree.  Ends with a barrier.
-__device__ __forceinline__ void spk_wide_gram(const double* X, int rows, int cs, EigShared& esh) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int p = w; p < SPK_WB * (SPK_WB + 1) / 2; p += SPK_WAVES) {
-        int i = 0, q = p;
-        while (q >= SPK_WB - i) { q -= SPK_WB - i; ++i; }
-        const int j = i + q;
-        const double* xi = X + (size_t)i * cs;
-        const double* xj = X + (size_t)j * cs;
-        double a = 0;
-        for (int r = lane; r < rows; r += 64) a = fma(xi[r], xj[r], a);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
-        if (lane == 0) {
-            esh.H[i * EIG_VP + j] = a;
-            esh.H[j * EIG_VP + i] = a;
-        }
-    }
-    __syncthreads();
-}
-
-// X <- X T for the 8 x 8 matrix esh.T (row-major, pitch EIG_VP): one row per thread and turn.  Ends with a barrier.
-__device__ __forceinline__ void spk_wide_apply(double* X, int rows, int cs, const EigShared& esh) {
-    for (int r = threadIdx.x; r < rows; r += SPK_THREADS) {
-        double x[SPK_WB], y[SPK_WB];
-#pragma unroll
-        for (int k = 0; k < SPK_WB; ++k) x[k] = X[(size_t)k * cs + r];
-#pragma unroll
-        for (int j = 0; j < SPK_WB; ++j) {
-            double a = 0;
-#pragma unroll
-            for (int k = 0; k < SPK_WB; ++k) a = fma(x[k], esh.T[k * EIG_VP + j], a);
-            y[j] = a;
-        }
-#pragma unroll
-        for (int j = 0; j < SPK_WB; ++j) X[(size_t)j * cs + r] = y[j];
-    }
-    __syncthreads();
-}
-
-// Rayleigh-Ritz + orthonormalisation of the fresh block X = op(X_in), X_in orthonormal: eigenvalues of X^T X are the
-// Ritz values of the operator's Gram form on span(X_in).  Out: sum of the 4 largest (top4), the 4th largest (th4), the
-// sum of all 8 (sum8).  X becomes orthonormal (dead directions - eigenvalue <= 1e-24 of the largest - become zero columns).
-__device__ __forceinline__ void spk_wide_ritz_orth(double* X, int rows, int cs, EigShared& esh, double& top4, double& th4,
-                                                   double& sum8, double* th5_out = nullptr) {
-    spk_wide_gram(X, rows, cs, esh);
-    jacobi_nb<SPK_WB>(esh);
-    double th[SPK_WB];
-    double tmax = 0;
-#pragma unroll
-    for (int k = 0; k < SPK_WB; ++k) {
-        th[k] = fmax(esh.theta[k], 0.0);
-        tmax = fmax(tmax, th[k]);
-    }
-    sum8 = 0;
-    top4 = 0;
-    th4 = 0;
-    double th5 = 0;
-#pragma unroll
-    for (int k = 0; k < SPK_WB; ++k) {
-        int rank = 0;
-#pragma unroll
-        for (int j = 0; j < SPK_WB; ++j) rank += (th[j] > th[k] || (th[j] == th[k] && j < k)) ? 1 : 0;
-        sum8 += th[k];
-        if (rank < 4) top4 += th[k];
-        if (rank == 3) th4 = th[k];
-        if (rank == 4) th5 = th[k];
-    }
-    if (th5_out) *th5_out = th5;
-    if (threadIdx.x < SPK_WB * SPK_WB) {
-        const int i = threadIdx.x / SPK_WB, j = threadIdx.x % SPK_WB;
-        const double rj = (esh.theta[j] > 1e-24 * tmax && esh.theta[j] > 0) ? 1.0 / sqrt(esh.theta[j]) : 0.0;
-        esh.T[i * EIG_VP + j] = esh.Q[i * EIG_VP + j] * rj;
-    }
-    __syncthreads();
-    spk_wide_apply(X, rows, cs, esh);
-    for (int pass = 0; pass < 6; ++pass) {   // Newton-Schulz polish: X <- X (1.5 I - 0.5 X^T X)
-        spk_wide_gram(X, rows, cs, esh);
-        double err = 0;
-#pragma unroll
-        for (int i = 0; i < SPK_WB; ++i) {
-            const bool live = esh.H[i * EIG_VP + i] > 0.25;
-#pragma unroll
-            for (int j = 0; j < SPK_WB; ++j)
-                err = fmax(err, fabs(esh.H[i * EIG_VP + j] - ((i == j && live) ? 1.0 : 0.0)));
-        }
-        __syncthreads();   // everybody has read H
-        if (err <= 4e-15) break;
-        if (threadIdx.x < SPK_WB * SPK_WB) {
-            const int i = threadIdx.x / SPK_WB, j = threadIdx.x % SPK_WB;
-            esh.T[i * EIG_VP + j] = (i == j ? 1.5 : 0.0) - 0.5 * esh.H[i * EIG_VP + j];
-        }
-        __syncthreads();
-        spk_wide_apply(X, rows, cs, esh);
-    }
-}
-
-// Stop rule of the wide block.  The slowest error component decays by lambda_9 / lambda_4 <= (trace - sum8) / th4 per half
-// product; where that bound is useful (< 0.9) it certifies the score to 5e-11 as in spk_converged, otherwise (heavy
-// tails: thousands of small eigenvalues outweigh lambda_4) the two-ratio estimate has to meet a ten times tighter tolerance.
-// The sum of the four largest Ritz values is not smooth: when the block's 4th vector is (almost exactly) the 5th
-// eigenvector of a close pair lambda_4 ~ lambda_5 - which is what the 4-wide phase hands over after a stall - the sum
-// sits on a plateau while the direction of lambda_4 is still growing out of the guard columns as the 5th Ritz value, and
-// jumps only when that value overtakes the 4th (found by the randomised tests: 1.9e-8 in a score).  So the 5th Ritz value
-// must be out of reach: either it has settled, or even four more steps of its current growth leave it below the 4th.
-__device__ __forceinline__ bool spk_wide_converged(double s4, double th4, double sum8, double trace, int k, double& prev_sum,
-                                                   double& prev_delta, double& prev_ratio, double th5, double& prev_th5) {
-    bool conv = false;
-    const double d5 = fabs(th5 - prev_th5);
-    prev_th5 = th5;
-    const double delta = fabs(s4 - prev_sum);
-    double ratio = 1.0;
-    if (k >= 3) {
-        ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
-        ratio = fmin(fmax(ratio, 0.0), 0.9999);
-        if (k >= 4) {
-            const double rest = trace - s4;
-            const double r = fmax(ratio, prev_ratio);
-            const double tail = delta * r / (1.0 - r);
-            const double sx = sqrt(fmax(rest, 0.0) * trace);
-            const double tol = fmax(fmin(1e-13 * s4, 4e-11 * sx), 4e-15 * s4);
-            const double rho_b = th4 > 0 ? fmax(trace - sum8, 0.0) / th4 : 1.0;
-            if (rho_b < 0.9) {
-                const bool bounded = delta * rho_b / (1.0 - rho_b) <= fmax(1e-10 * sx, 4e-15 * s4);
-                conv = bounded && (delta <= 0.2 * tol || tail <= tol);
-            } else {
-                conv = k >= 6 && (delta <= 0.1 * tol || tail <= 0.1 * tol);
-            }
-            const bool fifth_out_of_reach = d5 <= tol || th5 + 4.0 * d5 < th4;
-            conv = conv && fifth_out_of_reach;
-        }
-    }
-    prev_ratio = ratio;
-    prev_delta = delta;
-    prev_sum = s4;
-    return conv;
 }
 
 // status: bit 0 = iteration cap hit (score written but flagged), bit 1 = not handled here (re-score on the
@@ -1900,547 +1464,3 @@ int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa
 }
 
 
-// =====================================================================================================================
-// Big-table form: count tables with more than 65535 patterns (the 16-bit ids / offsets of the list kernels above end
-// there; 12 taxa beyond ~1 M sites, long branches), any side size, everything in global memory.
-// Per split the dense route's reindex kernel has already produced compact (row, col) for every pattern.  The two list
-// orders come from ONE stable segmented radix sort each (rocPRIM; segments = splits; keys = col resp. row, values =
-// pattern index), so every group is in table order like the counting sort above: reproducible bit for bit.
-// Products walk a sorted order in 1024 thread-chunks: a thread sums the runs inside its chunk; a run that crosses chunk
-// borders leaves partial sums (first / last run of a chunk) in LDS and its head's owner adds them up in chunk order.
-// Work is balanced whatever the group sizes (a 2|10 split has 16 rows of 6 k entries each).  Same block iteration, stop
-// rule and Cholesky-QR as above (V, W column-major in a per-workgroup slab); persistent workgroups loop over splits.
-#define SPKB_MAXHALF 40
-
-struct SpkbPart {
-    double first[SPK_THREADS][4];   // partial sums of a chunk's first run when it continues a previous chunk's run
-    double last[SPK_THREADS][4];    // ... of its last run when that continues into the next chunk
-    unsigned int flags[SPK_THREADS];   // bit 0: chunk starts inside a run; bit 1: the WHOLE chunk is inside that run
-};
-
-// out[key][0..3] = sum over the entries j of the run `key` of count * in[minor][0..3]; keys sorted (stable), perm = pattern
-// index of every sorted position, minor_of / counts indexed by pattern.  out has `nmajor` rows.  Ends with a barrier.
-// RM: `in` / `out` are row-major blocks ([row][4]: the four values of a row are ONE 32-byte access - a column-major block
-// costs four L2 sectors per entry, and the products of a 124 k-pattern table are L2-bandwidth bound); else column-major
-// with column strides ics / ocs (the 8-wide fallback block, two 4-column passes).
-template <typename CT, bool RM>
-__device__ __forceinline__ void spkb_product(const u32* __restrict__ keys, const u32* __restrict__ minor,
-                                             const CT* __restrict__ cnt, int D, const double* __restrict__ in, int ics,
-                                             double* __restrict__ out, int ocs, int nmajor, SpkbPart& pt) {
-    auto iat = [&](u32 row, int k) { return RM ? (size_t)row * 4 + k : (size_t)k * ics + row; };
-    auto oat = [&](u32 row, int k) { return RM ? (size_t)row * 4 + k : (size_t)k * ocs + row; };
-    for (int i = threadIdx.x; i < nmajor; i += SPK_THREADS) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[oat((u32)i, k)] = 0.0;
-    }
-    __syncthreads();
-    const int t = threadIdx.x;
-    const int chunk = (D + SPK_THREADS - 1) / SPK_THREADS;
-    const int lo = min(D, t * chunk), hi = min(D, lo + chunk);
-    unsigned int fl = 0;
-    // keys / minor / cnt hold the sorted order CHUNK-INTERLEAVED (k_gather_sorted): element jj of thread t's chunk sits at
-    // jj * SPK_THREADS + t, so the 64 lanes of a load read 64 consecutive words although every thread walks its own
-    // contiguous piece of the sorted order (thread-contiguous addressing measured 120 ms for 2035 splits of a 124 k table).
-    auto at = [&](int thread, int jj) { return (size_t)jj * SPK_THREADS + thread; };
-    if (lo < hi) {
-        double acc[4] = {0, 0, 0, 0};
-        u32 cur = keys[at(t, 0)];
-        bool first_run = lo > 0 && keys[at(t - 1, chunk - 1)] == cur;   // continuation of an earlier chunk's run
-        if (first_run) fl = 1;
-#pragma unroll 4
-        for (int jj = 0; jj < hi - lo; ++jj) {
-            const u32 key = keys[at(t, jj)];
-            const u32 m = minor[at(t, jj)];
-            const double c = (double)cnt[at(t, jj)];
-            double x[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = in[iat(m, k)];
-            if (key != cur) {   // the run `cur` ended inside the chunk
-                if (first_run) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) pt.first[t][k] = acc[k];
-                    first_run = false;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) out[oat(cur, k)] = acc[k];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] = 0.0;
-                cur = key;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = fma(c, x[k], acc[k]);
-        }
-        const bool goes_on = hi < D && keys[at(t + 1, 0)] == cur;
-        if (first_run) {           // the whole chunk was inside the run it started in
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pt.first[t][k] = acc[k];
-            if (goes_on) fl |= 2;
-        } else if (goes_on) {      // head in this chunk, tail in the next: finished by the fix-up below
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pt.last[t][k] = acc[k];
-            fl |= 4;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) out[oat(cur, k)] = acc[k];
-        }
-    }
-    pt.flags[t] = fl;
-    __syncthreads();
-    if (fl & 4) {   // this thread owns the head of a run that crosses chunk borders
-        const u32 key = keys[at(t, hi - lo - 1)];
-        double acc[4] = {pt.last[t][0], pt.last[t][1], pt.last[t][2], pt.last[t][3]};
-        for (int u = t + 1; u < SPK_THREADS; ++u) {
-            const unsigned int fu = pt.flags[u];
-            if (!(fu & 1)) break;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] += pt.first[u][k];
-            if (!(fu & 2)) break;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[oat(key, k)] = acc[k];
-    }
-    __syncthreads();
-}
-
-// Sorted order of every split -> chunk-interleaved streams for spkb_product: position j of a segment (thread j / chunk,
-// element j % chunk) goes to (j % chunk) * SPK_THREADS + j / chunk of the segment's padded block of chunk * SPK_THREADS.
-template <typename CT>
-__global__ void k_gather_sorted(const u32* __restrict__ key_sorted, const u32* __restrict__ perm,
-                                const u32* __restrict__ other_by_pattern, const CT* __restrict__ counts, int64_t D,
-                                int64_t total, u32* __restrict__ key_i, u32* __restrict__ minor_i, CT* __restrict__ cnt_i) {
-    // (one thread per DESTINATION word: the three stores of a wave are consecutive; scattered 4-byte stores - one thread
-    // per source position - made this kernel as expensive as the iteration itself)
-    const int64_t chunk = (D + SPK_THREADS - 1) / SPK_THREADS;
-    const int64_t dpad = chunk * SPK_THREADS;
-    const int64_t dst = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (dst >= total) return;   // total = segments * dpad here
-    const int64_t seg = dst / dpad, r = dst % dpad;
-    const int64_t j = (r % SPK_THREADS) * chunk + r / SPK_THREADS;
-    if (j >= D) return;         // padding: never read
-    const int64_t g = seg * D + j;
-    const u32 p = perm[g];
-    key_i[dst] = key_sorted[g];
-    minor_i[dst] = other_by_pattern[seg * D + p];
-    cnt_i[dst] = counts[p];
-}
-
-// CT = u32: count table (trace exact in u64);  CT = double: float-weight table (trace summed in a fixed tree).
-template <typename CT>
-__global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, const u32* __restrict__ rr_all,
-                                                            const u32* __restrict__ keyc_all, const u32* __restrict__ minc_all,
-                                                            const CT* __restrict__ cntc_all,
-                                                            const u32* __restrict__ keyr_all, const u32* __restrict__ minr_all,
-                                                            const CT* __restrict__ cntr_all,
-                                                            const CT* __restrict__ counts, const int2* __restrict__ dims,
-                                                            double* __restrict__ slabs, size_t slab_doubles,
-                                                            double* __restrict__ scores, int* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    SpkShared& sh = *reinterpret_cast<SpkShared*>(smem_b);
-    SpkbPart& pt = *reinterpret_cast<SpkbPart*>(smem_b + ((sizeof(SpkShared) + 15) & ~(size_t)15));
-    EigShared& esh = *reinterpret_cast<EigShared*>(smem_b + ((sizeof(SpkShared) + 15) & ~(size_t)15) +
-                                                   ((sizeof(SpkbPart) + 15) & ~(size_t)15));
-    const size_t lds_used_b = ((sizeof(SpkShared) + 15) & ~(size_t)15) + ((sizeof(SpkbPart) + 15) & ~(size_t)15) +
-                              ((sizeof(EigShared) + 15) & ~(size_t)15) + 16;
-    const int D = (int)D64;
-    double* slab = slabs + (size_t)blockIdx.x * slab_doubles;
-    // trace = sum count^2 (exact in u64 for counts) and the 4 heaviest patterns, once per workgroup
-    double trace;
-    if (std::is_same<CT, u32>::value) {
-        unsigned long long tr_part = 0;
-        for (int i = threadIdx.x; i < D; i += SPK_THREADS) tr_part += (unsigned long long)counts[i] * (unsigned long long)counts[i];
-        unsigned long long* red64 = reinterpret_cast<unsigned long long*>(pt.first);
-        red64[threadIdx.x] = tr_part;
-        __syncthreads();
-        for (int sft = SPK_THREADS / 2; sft >= 1; sft >>= 1) {
-            if ((int)threadIdx.x < sft) red64[threadIdx.x] += red64[threadIdx.x + sft];
-            __syncthreads();
-        }
-        trace = (double)red64[0];
-    } else {
-        double tr_part = 0;
-        for (int i = threadIdx.x; i < D; i += SPK_THREADS) tr_part += (double)counts[i] * (double)counts[i];
-        double* redd = reinterpret_cast<double*>(pt.first);
-        redd[threadIdx.x] = tr_part;
-        __syncthreads();
-        for (int sft = SPK_THREADS / 2; sft >= 1; sft >>= 1) {
-            if ((int)threadIdx.x < sft) redd[threadIdx.x] += redd[threadIdx.x + sft];
-            __syncthreads();
-        }
-        trace = redd[0];
-    }
-    __syncthreads();
-    int top_idx[4];
-    {   // four rounds of a block arg-max over (weight, lowest index)
-        double* bval = reinterpret_cast<double*>(pt.first);
-        int* bidx = reinterpret_cast<int*>(pt.last);
-        int taken[4] = {-1, -1, -1, -1};
-#pragma unroll
-        for (int round = 0; round < 4; ++round) {
-            double mv = -1.0;
-            int mi = -1;
-            for (int i = threadIdx.x; i < D; i += SPK_THREADS) {
-                const double v = (double)counts[i];
-                if (i != taken[0] && i != taken[1] && i != taken[2] && i != taken[3] && v > mv) {   // (ascending i: ties keep the lowest)
-                    mv = v;
-                    mi = i;
-                }
-            }
-            bval[threadIdx.x] = mv;
-            bidx[threadIdx.x] = mi;
-            __syncthreads();
-            for (int sft = SPK_THREADS / 2; sft >= 1; sft >>= 1) {
-                if ((int)threadIdx.x < sft) {
-                    const double ov = bval[threadIdx.x + sft];
-                    const int oi = bidx[threadIdx.x + sft];
-                    const double cv = bval[threadIdx.x];
-                    const int ci = bidx[threadIdx.x];
-                    if (ov > cv || (ov == cv && oi >= 0 && (ci < 0 || oi < ci))) {
-                        bval[threadIdx.x] = ov;
-                        bidx[threadIdx.x] = oi;
-                    }
-                }
-                __syncthreads();
-            }
-            taken[round] = bidx[0];
-            top_idx[round] = (bval[0] > 0) ? bidx[0] : -1;
-            __syncthreads();
-        }
-    }
-    for (int sid = blockIdx.x; sid < S; sid += gridDim.x) {
-        const int R = dims[sid].x, C = dims[sid].y;
-        if (min(R, C) <= 4 || !(trace > 0)) {
-            if (threadIdx.x == 0) {
-                scores[sid] = trace > 0 ? 0.0 : __builtin_nan("");
-                status[sid] = 0;
-            }
-            continue;
-        }
-        const u32* rr = rr_all + (size_t)sid * D;
-        const size_t dpad = (size_t)((D + SPK_THREADS - 1) / SPK_THREADS) * SPK_THREADS;   // chunk-interleaved blocks
-        const u32* keyc = keyc_all + (size_t)sid * dpad;
-        const u32* minc = minc_all + (size_t)sid * dpad;
-        const CT* cntc = cntc_all + (size_t)sid * dpad;
-        const u32* keyr = keyr_all + (size_t)sid * dpad;
-        const u32* minr = minr_all + (size_t)sid * dpad;
-        const CT* cntr = cntr_all + (size_t)sid * dpad;
-        const int Vp = ((R + 3) & ~3) + 4, Wp = ((C + 3) & ~3) + 4;
-        // slab: row-major 4-wide V and W ([row][4]) for the normal iteration, then the column-major 8-column blocks of
-        // the wide fallback
-        const size_t dpad16 = (size_t)D + 16;
-        // a block of up to ~2100 rows lives in the free LDS instead (V first, W if it still fits): the product that
-        // gathers from it then stays off the L2, which is what bounds this kernel (most splits have one short side)
-        double* const lds_blk = reinterpret_cast<double*>(smem_b + lds_used_b);
-        const size_t lds_free_d = ((size_t)SPK_LDS_BYTES - lds_used_b) / 8;
-        const size_t v_need = (size_t)4 * ((size_t)R + 4), w_need = (size_t)4 * ((size_t)C + 4);
-        const bool v_lds = v_need <= lds_free_d;
-        const bool w_lds = w_need <= lds_free_d - (v_lds ? v_need : 0);
-        double* V = v_lds ? lds_blk : slab;
-        double* W = w_lds ? lds_blk + (v_lds ? v_need : 0) : slab + 4 * dpad16;
-        double* V8 = slab + 8 * dpad16;
-        double* W8 = V8 + (size_t)SPK_WB * Vp;
-        // start block: unit vectors on the rows of the 4 most frequent patterns + hash noise, orthonormalised
-        int top_row[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) top_row[k] = top_idx[k] >= 0 ? (int)rr[top_idx[k]] : -1;
-        for (int i = threadIdx.x; i < Vp; i += SPK_THREADS) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                double x = 0.0;
-                if (i < R) {
-                    x = 0.02 * spk_hash((unsigned)i, (unsigned)k);
-                    bool hit = top_row[k] == i;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) hit = hit && !(q < k && top_row[q] == top_row[k]);   // a row only once
-                    if (hit) x += 1.0;
-                }
-                if (i < R) V[(size_t)i * 4 + k] = x;
-            }
-        }
-        __syncthreads();
-        spk_gram(V, R, 4, 1, sh);
-        spk_chol_factor(sh, false);
-        spk_orth(V, R, 4, 1, sh);
-        double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0, prev_th5 = 0;
-        int it = 0, conv = 0;
-        for (it = 1; it <= SPKB_MAXHALF; ++it) {
-            const bool odd = it & 1;   // odd: W = C^T V (column order)   even: V = C W (row order)
-            double* X = odd ? W : V;
-            const int rows = odd ? C : R;
-            if (odd)
-                spkb_product<CT, true>(keyc, minc, cntc, D, V, 0, W, 0, C, pt);
-            else
-                spkb_product<CT, true>(keyr, minr, cntr, D, W, 0, V, 0, R, pt);
-            spk_gram(X, rows, 4, 1, sh);
-            top4 = (sh.S[0] + sh.S[5]) + (sh.S[10] + sh.S[15]);
-            spk_chol_factor(sh, it >= 5, trace - top4);
-            if (spk_converged(top4, sh.L[11], trace, it, prev_sum, prev_delta, prev_ratio)) {
-                conv = 1;
-                break;
-            }
-            spk_orth(X, rows, 4, 1, sh);
-        }
-        if (!conv) {
-            // no certified gap behind the 4th value after SPKB_MAXHALF half products (clustered / slowly decaying
-            // spectrum): the 8-wide fallback block of the list kernels, on the same sorted orders (two 4-column passes)
-            for (int i = threadIdx.x; i < Vp; i += SPK_THREADS) {   // columns 0..3: the block so far, 4..7: noise
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    V8[(size_t)k * Vp + i] = i < R ? V[(size_t)i * 4 + k] : 0.0;
-                    V8[(size_t)(4 + k) * Vp + i] = i < R ? spk_hash((unsigned)i, (unsigned)(8 + k)) : 0.0;
-                }
-            }
-            __syncthreads();
-            double th4 = 0, sum8 = 0;
-            spk_wide_ritz_orth(V8, R, Vp, esh, top4, th4, sum8);   // here only as an orthonormaliser
-            prev_sum = 0; prev_delta = 0; prev_ratio = 1.0;
-            int wit = 1;
-            for (; wit <= SPK_MAXHALF_WIDE; ++wit) {
-                const bool odd = wit & 1;
-                double* X = odd ? W8 : V8;
-                const int rows = odd ? C : R, xcs = odd ? Wp : Vp;
-                for (int cb = 0; cb < SPK_WB; cb += 4) {
-                    if (odd)
-                        spkb_product<CT, false>(keyc, minc, cntc, D, V8 + (size_t)cb * Vp, Vp, W8 + (size_t)cb * Wp, Wp, C, pt);
-                    else
-                        spkb_product<CT, false>(keyr, minr, cntr, D, W8 + (size_t)cb * Wp, Wp, V8 + (size_t)cb * Vp, Vp, R, pt);
-                }
-                double th5;
-                spk_wide_ritz_orth(X, rows, xcs, esh, top4, th4, sum8, &th5);
-                if (spk_wide_converged(top4, th4, sum8, trace, wit, prev_sum, prev_delta, prev_ratio, th5, prev_th5)) {
-                    conv = 1;
-                    break;
-                }
-            }
-            it += wit;
-        }
-        if (threadIdx.x == 0) {
-            const double op = 1.0 - top4 / trace;
-            scores[sid] = sqrt(op > 0 ? op : 0.0);
-            status[sid] = (conv ? 0 : 1) | (it << 8);
-        }
-        __syncthreads();
-    }
-}
-
-__global__ void k_iota_segments(u32* __restrict__ out, int64_t D, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) out[i] = (u32)(i % D);
-}
-__global__ void k_segment_offsets(u32* __restrict__ off, int64_t D, int S) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= S) off[i] = (u32)((int64_t)i * D);
-}
-
-
-// Common tail of the two big-table launchers: entries gathered into sorted order, slabs, the kernel, one sync.
-template <typename CT>
-static int big_run_kernel(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, const u32* cc, const u32* keyc, const u32* permc,
-                          const u32* keyr, const u32* permr, const CT* counts, const int2* dims, int dev_cus,
-                          double* scores, int* status) {
-    DevBuf &minc = ctx->big[0], &minr = ctx->big[1], &cntc = ctx->big[2], &cntr = ctx->big[3], &slabs = ctx->big[4],
-           &kci = ctx->big[20], &kri = ctx->big[21];
-    const size_t padded = (size_t)S * (size_t)((D + SPK_THREADS - 1) / SPK_THREADS) * SPK_THREADS;
-    auto cleanup = [&]() {};   // (pooled in the context)
-    auto fail = [&](int code) { cleanup(); return code; };
-    int rc;
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(S, dev_cus));
-    // row-major 4-wide V and W (4 (D + 16) doubles each), then the column-major 8-column blocks of the wide fallback
-    const size_t slab_doubles = (size_t)(8 + 2 * SPK_WB) * ((size_t)D + 16);
-    if ((rc = minc.ensure(padded * 4)) || (rc = minr.ensure(padded * 4)) || (rc = cntc.ensure(padded * sizeof(CT))) ||
-        (rc = cntr.ensure(padded * sizeof(CT))) || (rc = kci.ensure(padded * 4)) || (rc = kri.ensure(padded * 4)) ||
-        (rc = slabs.ensure((size_t)grid * slab_doubles * 8)))
-        return fail(rc);
-    const dim3 gg((unsigned)((padded + 255) / 256));
-    hipLaunchKernelGGL(k_gather_sorted<CT>, gg, dim3(256), 0, ctx->stream, keyc, permc, rr, counts, D, (int64_t)padded,
-                       kci.as<u32>(), minc.as<u32>(), cntc.as<CT>());   // column order: the minor index is the row
-    hipLaunchKernelGGL(k_gather_sorted<CT>, gg, dim3(256), 0, ctx->stream, keyr, permr, cc, counts, D, (int64_t)padded,
-                       kri.as<u32>(), minr.as<u32>(), cntr.as<CT>());   // row order: the minor index is the column
-    const size_t lds = SPK_LDS_BYTES;   // shared structs + one or both 4-wide blocks of short sides
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_big<CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) {
-        sp_set_error("big-table form: cannot reserve %zu bytes of LDS", lds);
-        return fail(SP_EHIP);
-    }
-    hipLaunchKernelGGL(k_sparse_big<CT>, dim3(grid), dim3(SPK_THREADS), lds, ctx->stream, D, (int)S, rr, kci.as<u32>(),
-                       minc.as<u32>(), cntc.as<CT>(), kri.as<u32>(), minr.as<u32>(), cntr.as<CT>(), counts, dims,
-                       slabs.as<double>(), slab_doubles, scores, status);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the work buffers die at return
-    cleanup();
-    if (e != hipSuccess) {
-        sp_set_error("big-table form: %s", hipGetErrorString(e));
-        return SP_EHIP;
-    }
-    return SP_OK;
-}
-
-// rr / cc: compact coordinates of the D patterns for each of the S splits (reindex kernel), dims: matrix sizes.
-int launch_sparse_big(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, const u32* cc, const u32* counts,
-                      const double* weights, const int2* dims, int dev_cus, double* scores, int* status) {
-    if (S == 0) return SP_OK;
-    SP_REQUIRE(D >= 1 && D < ((int64_t)1 << 31) && S * D < ((int64_t)1 << 32), SP_ELIMIT,
-               "big-table form: %lld splits x %lld patterns per call is beyond the 2^32 entries one segmented sort takes",
-               (long long)S, (long long)D);
-    PhaseScope ps(ctx, SP_PHASE_SPARSE);
-    const size_t total = (size_t)S * (size_t)D;
-    DevBuf &iota = ctx->big[5], &keyc = ctx->big[6], &permc = ctx->big[7], &keyr = ctx->big[8], &permr = ctx->big[9],
-           &off = ctx->big[10], &tmp = ctx->big[11];
-    auto cleanup = [&]() {};   // (pooled in the context)
-    auto fail = [&](int code) { cleanup(); return code; };
-    int rc;
-    if ((rc = iota.ensure(total * 4)) || (rc = keyc.ensure(total * 4)) || (rc = permc.ensure(total * 4)) ||
-        (rc = keyr.ensure(total * 4)) || (rc = permr.ensure(total * 4)) || (rc = off.ensure((size_t)(S + 1) * 4)))
-        return fail(rc);
-    hipLaunchKernelGGL(k_iota_segments, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, iota.as<u32>(), D,
-                       (int64_t)total);
-    hipLaunchKernelGGL(k_segment_offsets, dim3((unsigned)((S + 256) / 256)), dim3(256), 0, ctx->stream, off.as<u32>(), D, (int)S);
-    unsigned bits = 1;
-    while (bits < 32 && ((int64_t)1 << bits) < D) ++bits;   // compact ids are < D
-    size_t t1 = 0;
-    hipError_t e = rocprim::segmented_radix_sort_pairs(nullptr, t1, cc, keyc.as<u32>(), iota.as<u32>(), permc.as<u32>(),
-                                                       (unsigned)total, (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits,
-                                                       ctx->stream);
-    if (e != hipSuccess) {
-        sp_set_error("big-table form: rocPRIM size query failed: %s", hipGetErrorString(e));
-        return fail(SP_EHIP);
-    }
-    if ((rc = tmp.ensure(std::max<size_t>(t1, 16)))) return fail(rc);
-    e = rocprim::segmented_radix_sort_pairs(tmp.p, t1, cc, keyc.as<u32>(), iota.as<u32>(), permc.as<u32>(), (unsigned)total,
-                                            (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits, ctx->stream);
-    if (e == hipSuccess)
-        e = rocprim::segmented_radix_sort_pairs(tmp.p, t1, rr, keyr.as<u32>(), iota.as<u32>(), permr.as<u32>(), (unsigned)total,
-                                                (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits, ctx->stream);
-    if (e != hipSuccess) {
-        sp_set_error("big-table form: segmented sort failed: %s", hipGetErrorString(e));
-        return fail(SP_EHIP);
-    }
-    const int rc2 = counts ? big_run_kernel<u32>(ctx, D, S, rr, cc, keyc.as<u32>(), permc.as<u32>(), keyr.as<u32>(), permr.as<u32>(),
-                                            counts, dims, dev_cus, scores, status)
-                           : big_run_kernel<double>(ctx, D, S, rr, cc, keyc.as<u32>(), permc.as<u32>(), keyr.as<u32>(),
-                                                    permr.as<u32>(), weights, dims, dev_cus, scores, status);
-    cleanup();
-    return rc2;
-}
-
-// ---- big-table form without the bitmap compaction: sides of more than 14 taxa -------------------------------------------
-// The reindex kernel ranks side keys through presence bitmaps of 4^k bits, which ends at k = 14.  Here the raw side keys
-// (2 bits a taxon, up to 62 bits) are sorted directly - the same stable segmented sort that orders the products - and
-// the compact id of a key is the number of run heads before it.
-__global__ __launch_bounds__(256) void k_side_keys(const u64* __restrict__ keys, int64_t D, int n,
-                                                   const int* __restrict__ split_taxa, const int* __restrict__ split_a,
-                                                   u64* __restrict__ rk, u64* __restrict__ ck) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int s = blockIdx.y;
-    if (i >= D) return;
-    const u64 key = keys[i];
-    const int* taxa = split_taxa + (size_t)s * n;
-    const int a = split_a[s];
-    u64 r = 0, c = 0;
-    for (int t = 0; t < a; ++t) r = (r << 2) | ((key >> (2 * (n - 1 - taxa[t]))) & 3ull);
-    for (int t = a; t < n; ++t) c = (c << 2) | ((key >> (2 * (n - 1 - taxa[t]))) & 3ull);
-    rk[(size_t)s * D + i] = r;
-    ck[(size_t)s * D + i] = c;
-}
-
-// One workgroup per split: compact id of every sorted position (= run heads before it), the same id scattered back to
-// the patterns, and the number of distinct keys.
-__global__ __launch_bounds__(1024) void k_compact_sorted(const u64* __restrict__ sorted_keys, const u32* __restrict__ perm,
-                                                         int64_t D64, u32* __restrict__ id_sorted,
-                                                         u32* __restrict__ id_by_pattern, int* __restrict__ dim_out,
-                                                         int dim_stride) {
-    __shared__ u32 part[1024];
-    const int D = (int)D64;
-    const size_t base = (size_t)blockIdx.x * D;
-    const u64* k = sorted_keys + base;
-    const int t = threadIdx.x;
-    const int chunk = (D + 1023) / 1024;
-    const int lo = min(D, t * chunk), hi = min(D, lo + chunk);
-    u32 heads = 0;
-    for (int j = lo; j < hi; ++j) heads += (j == 0 || k[j] != k[j - 1]) ? 1u : 0u;
-    part[t] = heads;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan (Hillis-Steele)
-        const u32 v = t >= off ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    u32 run = part[t] - heads;   // heads before this chunk
-    for (int j = lo; j < hi; ++j) {
-        run += (j == 0 || k[j] != k[j - 1]) ? 1u : 0u;
-        id_sorted[base + j] = run - 1;
-        id_by_pattern[base + perm[base + j]] = run - 1;
-    }
-    if (t == 1023) dim_out[(size_t)blockIdx.x * dim_stride] = (int)part[1023];
-}
-
-// split_taxa / split_a: host arrays of this chunk of splits.  keys: the table's pattern keys (device).
-int launch_sparse_big_keys(sp_ctx* ctx, const u64* keys, int64_t D, int n, const int32_t* split_taxa, const int32_t* split_a,
-                           int64_t S, const u32* counts, const double* weights, int dev_cus, double* scores, int* status) {
-    if (S == 0) return SP_OK;
-    SP_REQUIRE(D >= 1 && D < ((int64_t)1 << 31) && S * D < ((int64_t)1 << 32), SP_ELIMIT,
-               "big-table form: %lld splits x %lld patterns per call is beyond the 2^32 entries one segmented sort takes",
-               (long long)S, (long long)D);
-    int max_side = 1;
-    for (int64_t s = 0; s < S; ++s) max_side = std::max(max_side, std::max(split_a[s], n - split_a[s]));
-    SP_REQUIRE(max_side <= 31, SP_ELIMIT, "a split side of %d taxa does not fit a 64-bit side key", max_side);
-    PhaseScope ps(ctx, SP_PHASE_SPARSE);
-    const size_t total = (size_t)S * (size_t)D;
-    DevBuf &iota = ctx->big[5], &idc_s = ctx->big[6], &permc = ctx->big[7], &idr_s = ctx->big[8], &permr = ctx->big[9],
-           &off = ctx->big[10], &tmp = ctx->big[11], &d_taxa = ctx->big[12], &d_a = ctx->big[13], &rk = ctx->big[14],
-           &ck = ctx->big[15], &sk = ctx->big[16], &cc = ctx->big[17], &rr = ctx->big[18], &dims = ctx->big[19];
-    auto cleanup = [&]() {};   // (pooled in the context)
-    auto fail = [&](int code) { cleanup(); return code; };
-    int rc;
-    if ((rc = d_taxa.ensure((size_t)S * n * 4)) || (rc = d_a.ensure((size_t)S * 4)) || (rc = rk.ensure(total * 8)) ||
-        (rc = ck.ensure(total * 8)) || (rc = sk.ensure(total * 8)) || (rc = iota.ensure(total * 4)) ||
-        (rc = permc.ensure(total * 4)) || (rc = permr.ensure(total * 4)) || (rc = idc_s.ensure(total * 4)) ||
-        (rc = idr_s.ensure(total * 4)) || (rc = cc.ensure(total * 4)) || (rc = rr.ensure(total * 4)) ||
-        (rc = dims.ensure((size_t)S * sizeof(int2))) || (rc = off.ensure((size_t)(S + 1) * 4)))
-        return fail(rc);
-    hipError_t e = hipMemcpyAsync(d_taxa.p, split_taxa, (size_t)S * n * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_a.p, split_a, (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // (pageable host arrays of the caller)
-    if (e != hipSuccess) {
-        sp_set_error("big-table form: %s", hipGetErrorString(e));
-        return fail(SP_EHIP);
-    }
-    hipLaunchKernelGGL(k_side_keys, dim3((unsigned)((D + 255) / 256), (unsigned)S), dim3(256), 0, ctx->stream, keys, D, n,
-                       d_taxa.as<int>(), d_a.as<int>(), rk.as<u64>(), ck.as<u64>());
-    hipLaunchKernelGGL(k_iota_segments, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, iota.as<u32>(), D,
-                       (int64_t)total);
-    hipLaunchKernelGGL(k_segment_offsets, dim3((unsigned)((S + 256) / 256)), dim3(256), 0, ctx->stream, off.as<u32>(), D, (int)S);
-    const unsigned bits = (unsigned)(2 * max_side);
-    size_t t1 = 0;
-    e = rocprim::segmented_radix_sort_pairs(nullptr, t1, ck.as<u64>(), sk.as<u64>(), iota.as<u32>(), permc.as<u32>(),
-                                            (unsigned)total, (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits, ctx->stream);
-    if (e != hipSuccess) {
-        sp_set_error("big-table form: rocPRIM size query failed: %s", hipGetErrorString(e));
-        return fail(SP_EHIP);
-    }
-    if ((rc = tmp.ensure(std::max<size_t>(t1, 16)))) return fail(rc);
-    int* dimp = reinterpret_cast<int*>(dims.p);
-    e = rocprim::segmented_radix_sort_pairs(tmp.p, t1, ck.as<u64>(), sk.as<u64>(), iota.as<u32>(), permc.as<u32>(),
-                                            (unsigned)total, (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits, ctx->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_compact_sorted, dim3((unsigned)S), dim3(1024), 0, ctx->stream, sk.as<u64>(), permc.as<u32>(), D,
-                           idc_s.as<u32>(), cc.as<u32>(), dimp + 1, 2);   // .y = columns
-        e = rocprim::segmented_radix_sort_pairs(tmp.p, t1, rk.as<u64>(), sk.as<u64>(), iota.as<u32>(), permr.as<u32>(),
-                                                (unsigned)total, (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits,
-                                                ctx->stream);
-    }
-    if (e != hipSuccess) {
-        sp_set_error("big-table form: segmented sort failed: %s", hipGetErrorString(e));
-        return fail(SP_EHIP);
-    }
-    hipLaunchKernelGGL(k_compact_sorted, dim3((unsigned)S), dim3(1024), 0, ctx->stream, sk.as<u64>(), permr.as<u32>(), D,
-                       idr_s.as<u32>(), rr.as<u32>(), dimp, 2);            // .x = rows
-    const int2* dims2 = reinterpret_cast<const int2*>(dims.p);
-    const int rc2 = counts ? big_run_kernel<u32>(ctx, D, S, rr.as<u32>(), cc.as<u32>(), idc_s.as<u32>(), permc.as<u32>(),
-                                            idr_s.as<u32>(), permr.as<u32>(), counts, dims2, dev_cus, scores, status)
-                           : big_run_kernel<double>(ctx, D, S, rr.as<u32>(), cc.as<u32>(), idc_s.as<u32>(), permc.as<u32>(),
-                                                    idr_s.as<u32>(), permr.as<u32>(), weights, dims2, dev_cus, scores, status);
-    cleanup();
-    return rc2;
-}

@@ -5,7 +5,7 @@ cp ../libsplitp_hip.so /tmp/lib_orig.so
 for v in A B; do
   if [ $v = A ]; then FL="$1"; else FL="$2"; fi
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $FL -c sparse.hip -o /tmp/sparse_$v.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/lib_$v.so api.o flatten.o gram.o gram_i8.o eigen.o /tmp/sparse_$v.o subflat.o hist.o divergence.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/lib_$v.so api.o flatten.o gram.o gram_i8.o eigen.o /tmp/sparse_$v.o sparse_big.o subflat.o hist.o divergence.o
 done
 cd ../..
 for rep in 1 2; do

@@ -2,7 +2,7 @@ set -e
 cd $GRAFT_REPO_ROOT
 cd splitp_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $SPK_EXTRA -DSPK_STAMPS -c sparse.hip -o /tmp/sparse_st.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsplitp_hip.so api.o flatten.o gram.o gram_i8.o eigen.o /tmp/sparse_st.o subflat.o hist.o divergence.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsplitp_hip.so api.o flatten.o gram.o gram_i8.o eigen.o /tmp/sparse_st.o sparse_big.o subflat.o hist.o divergence.o
 cd ../..
 python - <<'PY'
 import sys, ctypes as C, numpy as np
