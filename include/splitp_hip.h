@@ -205,8 +205,10 @@ int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, const int32_t* 
  * size classes ascending, itertools.combinations order inside a class, the side holding taxon 0 first; `trivial` adds
  * the 1 | n-1 class, `size` > 0 restricts to one class).  The splits are enumerated on the device (no split list crosses
  * the boundary: the 524 267 splits of 20 taxa take 1.2 s to encode on the host and 21 ms to score).
- * method: SP_METHOD_SUBFLATTENING.  n_splits receives the number of splits; with all three output pointers NULL the call
- * only counts.  Outputs as for sp_score_splits. */
+ * method: any SP_METHOD_*.  SP_METHOD_SUBFLATTENING scores straight from the enumeration; SP_METHOD_FLATTENING on a
+ * table the sparse route takes is also PLANNED on the device (split descriptors + launch order built by a kernel from the
+ * enumeration); the other routes fetch the enumerated list once and plan on the host.  n_splits receives the number of
+ * splits; with all three output pointers NULL the call only counts.  Outputs and SP_ENOCONV as for sp_score_splits. */
 int sp_score_all_splits(sp_alignment* al, int method, int trivial, int size, int64_t* n_splits, double* scores_host,
                         void* scores_dev, int32_t* status_host);
 

@@ -262,8 +262,9 @@ def score_all_splits(pattern_probabilities, method=Method.flattening, route="aut
     (single process; `score_splits(table, all_splits(taxa))` is the distributed form)."""
     al = as_device_alignment(pattern_probabilities)
     code = _method_code(method, route)
-    if code == _lib.SP_METHOD_SUBFLATTENING and al.n_taxa <= 31:
-        # the splits are enumerated on the device (sp_score_all_splits): no split list is built or uploaded at all
+    if al.n_taxa <= 31:
+        # the splits are enumerated on the device (sp_score_all_splits): no split list is built or uploaded at all; on the
+        # default flattening route the split descriptors and the launch order are planned on the device as well
         lib = al.ctx._lib
         n = C.c_int64()
         _lib.check(lib.sp_score_all_splits(al.handle, code, int(bool(trivial)), int(size or 0), C.byref(n), None, None, None))
@@ -271,7 +272,9 @@ def score_all_splits(pattern_probabilities, method=Method.flattening, route="aut
         status = np.zeros(n.value, dtype=np.int32)
         if n.value:
             _lib.check(lib.sp_score_all_splits(al.handle, code, int(bool(trivial)), int(size or 0), C.byref(n),
-                                               _lib._ptr(scores, C.c_double), None, _lib._ptr(status, C.c_int32)))
+                                               _lib._ptr(scores, C.c_double), None, _lib._ptr(status, C.c_int32)),
+                       allow_noconv=True)
+            warn_unconverged(status)
         return (scores, status) if return_status else scores
     taxa_arr, a_arr = encode_all_splits(al.n_taxa, trivial=trivial, size=size)
     scores, status = score_encoded(al, taxa_arr, a_arr, code)

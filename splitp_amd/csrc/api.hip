@@ -866,20 +866,13 @@ static int cached_sparse_plan(sp_ctx* ctx, int n, const int32_t* split_taxa, con
     return SP_OK;
 }
 
-// Synchronous sparse route: the device chain (in-LDS kernel -> lists in global memory -> all arrays in global memory ->
-// 8-wide fallback block for sides beyond the dense route), then - the only host step - splits whose 4-wide block found no
-// certified gap and whose smaller side fits the dense route's 1024 rows are re-scored there and patched in.
-static int run_sparse_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S, bool strict) {
+// Host step of the synchronous sparse route, after the device chain has run and its status words `st` are on the host:
+// splits whose 4-wide block found no certified gap and whose smaller side fits the dense route's 1024 rows are re-scored
+// there and patched into ctx->scores / ctx->status.
+static int sparse_handback(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S,
+                           std::vector<int>& st, bool strict) {
     sp_ctx* ctx = al->ctx;
     const int n = al->n_taxa;
-    sp_plan* plan = nullptr;
-    SP_CHECK(cached_sparse_plan(ctx, n, split_taxa, split_a, S, &plan));
-    SP_CHECK(ctx->scores.ensure((size_t)S * 8));
-    SP_CHECK(ctx->status.ensure((size_t)S * 4));
-    SP_CHECK(enqueue_sparse_plan(ctx, &al, 1, plan, ctx->scores.as<double>(), ctx->status.as<int>(), false));
-    std::vector<int> st((size_t)S);
-    SP_HIP(hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SP_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<int> redo;
     for (int64_t i = 0; i < S; ++i)
         if (st[i] & 2) redo.push_back((int)i);
@@ -945,6 +938,128 @@ static int run_sparse_route(sp_alignment* al, const int32_t* split_taxa, const i
         return bail(SP_EHIP);
     }
     return bail(SP_OK);
+}
+
+// Synchronous sparse route: the device chain (in-LDS kernel -> lists in global memory -> all arrays in global memory ->
+// 8-wide fallback block for sides beyond the dense route), then - the only host step - sparse_handback.
+static int run_sparse_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S, bool strict) {
+    sp_ctx* ctx = al->ctx;
+    sp_plan* plan = nullptr;
+    SP_CHECK(cached_sparse_plan(ctx, al->n_taxa, split_taxa, split_a, S, &plan));
+    SP_CHECK(ctx->scores.ensure((size_t)S * 8));
+    SP_CHECK(ctx->status.ensure((size_t)S * 4));
+    SP_CHECK(enqueue_sparse_plan(ctx, &al, 1, plan, ctx->scores.as<double>(), ctx->status.as<int>(), false));
+    std::vector<int> st((size_t)S);
+    SP_HIP(hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    return sparse_handback(al, split_taxa, split_a, S, st, strict);
+}
+
+// ---- every split of the taxa, flattening + score, planned on the device ---------------------------------------------
+// subflat.hip's enumeration gives (taxa, a) of every split in all_splits order; k_plan_enumerated turns them into the
+// sparse kernel's split descriptors (smaller side = rows) and the heaviest-first launch order, on the device: no split
+// list, no plan crosses the boundary.
+int enumerate_all_splits(sp_ctx* ctx, int n, int trivial, int size, bool enumerate, int64_t* total_out,
+                         const int8_t** dtaxa_out, const int** da_out, std::vector<int>& sizes,
+                         std::vector<unsigned long long>& counts);   // subflat.hip
+
+struct ClassLayout {
+    int n_classes;
+    int start[17];     // first split of every size class in all_splits order (classes ascending), then the total
+    int out_start[17]; // first position of the class in the launch order (largest class first)
+};
+
+__global__ __launch_bounds__(256) void k_plan_enumerated(int n, int total, const int8_t* __restrict__ taxa,
+                                                         const int* __restrict__ a_arr, ClassLayout cl,
+                                                         SplitDev* __restrict__ out, int* __restrict__ order) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int a = a_arr[i], b = n - a;
+    const bool swap = a > b;
+    SplitDev sd;
+    memset(&sd, 0, sizeof(sd));
+    sd.nr = swap ? b : a;
+    sd.nc = swap ? a : b;
+    const int8_t* t = taxa + (size_t)i * n;
+    for (int k = 0; k < sd.nr; ++k) sd.taxa[k] = swap ? t[a + k] : t[k];
+    for (int k = 0; k < sd.nc; ++k) sd.taxa[sd.nr + k] = swap ? t[k] : t[a + k];
+    sd.rw = (int)(((1ll << (2 * sd.nr)) + 63) / 64);
+    sd.cw = (int)(((1ll << (2 * sd.nc)) + 63) / 64);
+    out[i] = sd;
+    int q = 0;
+    while (q + 1 < cl.n_classes && i >= cl.start[q + 1]) ++q;
+    order[cl.out_start[q] + (i - cl.start[q])] = i;
+}
+
+static int run_flat_all_splits(sp_alignment* al, int method, int trivial, int size, int64_t* n_out, bool score) {
+    sp_ctx* ctx = al->ctx;
+    const int n = al->n_taxa;
+    const int8_t* dtaxa = nullptr;
+    const int* da = nullptr;
+    std::vector<int> sizes;
+    std::vector<unsigned long long> counts;
+    int64_t total = 0;
+    SP_CHECK(enumerate_all_splits(ctx, n, trivial, size, score, &total, &dtaxa, &da, sizes, counts));
+    if (n_out) *n_out = total;
+    if (!score || total == 0) return SP_OK;
+    int64_t srows = 0;
+    SP_CHECK(sparse_rows(al, &srows));
+    const bool sparse_ok = al->exact && srows <= 65535 && n <= 16 && al->D > 0;
+    const bool use_sparse = (method == SP_METHOD_FLATTENING_SPARSE || (method == SP_METHOD_FLATTENING && ctx->gram_mode == 0 &&
+                                                                       !ctx->opt.force_big)) && sparse_ok;
+    // the split list on the host: only for the routes planned there, or for the (rare) dense-route hand-back
+    std::vector<int32_t> h_taxa, h_a;
+    auto fetch_list = [&]() -> int {
+        std::vector<int8_t> t8((size_t)total * n);
+        h_a.resize((size_t)total);
+        SP_HIP(hipMemcpyAsync(t8.data(), dtaxa, t8.size(), hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(hipMemcpyAsync(h_a.data(), da, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(hipStreamSynchronize(ctx->stream));
+        h_taxa.assign(t8.begin(), t8.end());
+        return SP_OK;
+    };
+    if (!use_sparse) {
+        SP_CHECK(fetch_list());
+        const int rc = sp_score_splits(al, h_taxa.data(), h_a.data(), total, method, nullptr, nullptr, nullptr);
+        return rc == SP_ENOCONV ? SP_OK : rc;   // (scores and status are in the context's buffers either way)
+    }
+    SP_REQUIRE(sizes.size() <= 16, SP_ELIMIT, "%zu size classes", sizes.size());
+    ClassLayout cl{};
+    cl.n_classes = (int)sizes.size();
+    int run = 0;
+    for (int q = 0; q < cl.n_classes; ++q) {
+        cl.start[q] = run;
+        run += (int)counts[q];
+    }
+    cl.start[cl.n_classes] = run;
+    int pos = 0;
+    int64_t bmw = 0;
+    for (int q = cl.n_classes - 1; q >= 0; --q) {   // largest smaller side first
+        cl.out_start[q] = pos;
+        pos += (int)counts[q];
+        bmw = std::max<int64_t>(bmw, (pow4(sizes[q]) + 63) / 64 + (pow4(n - sizes[q]) + 63) / 64);
+    }
+    SP_CHECK(ctx->splits.ensure((size_t)total * sizeof(SplitDev)));
+    SP_CHECK(ctx->gram_items.ensure((size_t)total * sizeof(int)));
+    SP_CHECK(ctx->scores.ensure((size_t)total * 8));
+    SP_CHECK(ctx->status.ensure((size_t)total * 4));
+    if (ctx->cache) ctx->cache->valid = false;   // ctx->splits is rewritten
+    hipLaunchKernelGGL(k_plan_enumerated, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, n, (int)total, dtaxa,
+                       da, cl, ctx->splits.as<SplitDev>(), ctx->gram_items.as<int>());
+    SP_HIP(hipGetLastError());
+    const AlDesc* descs = nullptr;
+    sp_alignment* als1[1] = {al};
+    SP_CHECK(aldescs_for(ctx, als1, 1, &descs));
+    SP_CHECK(launch_sparse_chain(ctx, descs, 1, n, ctx->splits.as<SplitDev>(), ctx->gram_items.as<int>(), total,
+                                 ctx->scores.as<double>(), ctx->status.as<int>(), srows, bmw, false));
+    std::vector<int> st((size_t)total);
+    SP_HIP(hipMemcpyAsync(st.data(), ctx->status.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    bool any = false;
+    for (int v : st) any |= (v & 2) != 0;
+    if (!any) return SP_OK;
+    SP_CHECK(fetch_list());
+    return sparse_handback(al, h_taxa.data(), h_a.data(), total, st, method == SP_METHOD_FLATTENING_SPARSE);
 }
 
 int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S);  // subflat.hip
@@ -1119,19 +1234,32 @@ extern "C" int sp_score_all_splits(sp_alignment* al, int method, int trivial, in
     SP_REQUIRE(al, SP_EINVAL, "alignment is NULL");
     sp_ctx* ctx = al->ctx;
     SP_HIP(hipSetDevice(ctx->device));
-    SP_REQUIRE(method == SP_METHOD_SUBFLATTENING, SP_EINVAL,
-               "sp_score_all_splits enumerates on the device for SP_METHOD_SUBFLATTENING only (method %d: pass the "
-               "split list to sp_score_splits)", method);
     const bool score = scores_host || scores_dev || status_host;
     SP_REQUIRE(!score || al->D > 0, SP_EINVAL, "empty pattern table");
     int64_t n = 0;
-    SP_CHECK(run_subflat_all_splits(al, trivial, size, &n, score));
+    if (method == SP_METHOD_SUBFLATTENING) {
+        SP_CHECK(run_subflat_all_splits(al, trivial, size, &n, score));
+    } else {
+        SP_REQUIRE(method == SP_METHOD_FLATTENING || method == SP_METHOD_FLATTENING_DENSE ||
+                   method == SP_METHOD_FLATTENING_SPARSE || method == SP_METHOD_MUTUAL_INFORMATION, SP_EINVAL,
+                   "unknown method %d", method);
+        SP_CHECK(run_flat_all_splits(al, method, trivial, size, &n, score));
+    }
     if (n_splits) *n_splits = n;
     if (!score || n == 0) return SP_OK;
     if (scores_dev) SP_HIP(hipMemcpyAsync(scores_dev, ctx->scores.p, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (scores_host) SP_HIP(hipMemcpyAsync(scores_host, ctx->scores.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (status_host) SP_HIP(hipMemcpyAsync(status_host, ctx->status.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (scores_host || status_host) SP_HIP(hipStreamSynchronize(ctx->stream));
+    if (status_host) {
+        int64_t bad = 0;
+        for (int64_t i = 0; i < n; ++i) bad += status_host[i] & 1;
+        if (bad) {
+            sp_set_error("%lld of %lld splits hit the iteration cap of their eigen-solver: their scores are upper estimates "
+                         "(status bit 0)", (long long)bad, (long long)n);
+            return SP_ENOCONV;
+        }
+    }
     return SP_OK;
     });
 }

@@ -635,25 +635,27 @@ static unsigned long long binom_host(int nn, int kk) {
     return c;
 }
 
-// Number of splits all_splits yields, and - when scores are asked for - their subflattening scores in that order.
-int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int64_t* n_out, bool score) {
-    sp_ctx* ctx = al->ctx;
-    const int n = al->n_taxa;
+// The splits all_splits yields, enumerated on the device into ctx->coords: taxa_out[total][n] (int8: the side holding
+// taxon 0, then the other side, both in taxon order) and a_out[total].  `enumerate` = false only counts.  sizes / counts:
+// the size classes in order and their populations.
+int enumerate_all_splits(sp_ctx* ctx, int n, int trivial, int size, bool enumerate, int64_t* total_out,
+                         const int8_t** dtaxa_out, const int** da_out, std::vector<int>& sizes,
+                         std::vector<unsigned long long>& counts) {
     SP_REQUIRE(n >= 2 && n <= 31, SP_ELIMIT, "split enumeration supports 2..31 taxa (got %d)", n);
     SP_REQUIRE(size >= 0 && size <= n / 2, SP_EINVAL, "size %d out of range [0, %d]", size, n / 2);
-    std::vector<int> sizes;
+    sizes.clear();
+    counts.clear();
     if (size > 0) sizes.push_back(size);
     else for (int b = trivial ? 1 : 2; b <= n / 2; ++b) sizes.push_back(b);
     int64_t total = 0;
-    std::vector<unsigned long long> counts;
     for (int b : sizes) {
         const bool even = 2 * b == n;
         const unsigned long long c = even ? binom_host(n - 1, b - 1) : binom_host(n, b);
         counts.push_back(c);
         total += (int64_t)c;
     }
-    if (n_out) *n_out = total;
-    if (!score || total == 0) return SP_OK;
+    if (total_out) *total_out = total;
+    if (!enumerate || total == 0) return SP_OK;
     SP_REQUIRE(total < ((int64_t)1 << 31), SP_ELIMIT, "%lld splits: more than one call takes", (long long)total);
     std::vector<unsigned long long> bt(33 * 33, 0);
     for (int i = 0; i < 33; ++i)
@@ -666,16 +668,33 @@ int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int64_t* n_o
     SP_HIP(hipMemcpyAsync(ctx->misc2.p, bt.data(), bt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));   // bt is a host temporary
     int64_t off = 0;
-    int kmax = 0;
     for (size_t q = 0; q < sizes.size(); ++q) {
         const int b = sizes[q];
         if (counts[q] == 0) continue;
         hipLaunchKernelGGL(k_enumerate_splits, dim3((unsigned)((counts[q] + 255) / 256)), dim3(256), 0, ctx->stream, n, b,
                            2 * b == n ? 1 : 0, counts[q], ctx->misc2.as<unsigned long long>(), dtaxa + (size_t)off * n, da + off);
         off += (int64_t)counts[q];
-        kmax = std::max(kmax, b);
     }
     SP_HIP(hipGetLastError());
+    *dtaxa_out = dtaxa;
+    *da_out = da;
+    return SP_OK;
+}
+
+// Number of splits all_splits yields, and - when scores are asked for - their subflattening scores in that order.
+int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int64_t* n_out, bool score) {
+    sp_ctx* ctx = al->ctx;
+    const int8_t* dtaxa = nullptr;
+    const int* da = nullptr;
+    std::vector<int> sizes;
+    std::vector<unsigned long long> counts;
+    int64_t total = 0;
+    SP_CHECK(enumerate_all_splits(ctx, al->n_taxa, trivial, size, score, &total, &dtaxa, &da, sizes, counts));
+    if (n_out) *n_out = total;
+    if (!score || total == 0) return SP_OK;
+    int kmax = 0;
+    for (size_t q = 0; q < sizes.size(); ++q)
+        if (counts[q]) kmax = std::max(kmax, sizes[q]);
     return launch_subscore(al, dtaxa, da, total, kmax);
 }
 

@@ -1467,8 +1467,11 @@ def test_score_all_splits_matches_host_enumeration(sp):
         cnt = C.c_int64()
         _lib.check(dev.ctx._lib.sp_score_all_splits(dev.handle, _lib.SP_METHOD_SUBFLATTENING, 0, 0, C.byref(cnt), None, None, None))
         assert cnt.value == len(list(sp.all_splits(names)))
+    # (the flattening routes enumerate on the device too since round 2: test_score_all_splits_flattening_planned_on_device)
+    _lib.check(dev.ctx._lib.sp_score_all_splits(dev.handle, _lib.SP_METHOD_FLATTENING, 0, 0, C.byref(cnt), None, None, None))
+    assert cnt.value == len(list(sp.all_splits(names)))
     with pytest.raises(ValueError):
-        _lib.check(dev.ctx._lib.sp_score_all_splits(dev.handle, _lib.SP_METHOD_FLATTENING, 0, 0, C.byref(cnt), None, None, None))
+        _lib.check(dev.ctx._lib.sp_score_all_splits(dev.handle, 99, 0, 0, C.byref(cnt), None, None, None))
 
 
 def test_wide_block_plateau_regression(sp, monkeypatch):
@@ -1570,3 +1573,39 @@ def test_bench_line_contract(sp):
         assert key in roof, key
     assert roof["bound"] == "lds" and 0.05 < roof["frac"] < 1.0 and roof["traffic"] > 0
     assert 0.2 < roof["binding"]["bank_conflict_share"] < 0.8 and roof["binding"]["real_work"]["fma"] > 1e7
+
+
+def test_score_all_splits_flattening_planned_on_device(sp, golden):
+    """score_all_splits on the flattening routes: the splits are enumerated AND (default route) planned on the device -
+    same scores, bit for bit, as the host-planned call on list(all_splits(taxa)); trivial class, one size class, the
+    dense route, the mutual-information score and a float-weight table (host-planned fallbacks) included."""
+    g = golden("n10_L100k")
+    names = taxa_names(10)
+    dev = sp.DeviceAlignment.from_table(O.unpack_table(g["keys"], g["probs"], 10), taxa=names)
+    splits = list(sp.all_splits(names))
+    got, st = sp.score_all_splits(dev, return_status=True)
+    assert np.array_equal(got, sp.score_splits(dev, splits)) and not np.any(st & 3)
+    assert np.abs(got - g["scores"]).max() <= SCORE_TOL
+    triv = list(sp.all_splits(names, trivial=True))
+    assert np.array_equal(sp.score_all_splits(dev, trivial=True), sp.score_splits(dev, triv))
+    four = list(sp.all_splits(names, size=4))
+    assert np.array_equal(sp.score_all_splits(dev, size=4), sp.score_splits(dev, four)) and len(four) == 210
+    assert np.array_equal(sp.score_all_splits(dev, route="dense"), sp.score_splits(dev, splits, route="dense"))
+    assert np.array_equal(sp.score_all_splits(dev, method=sp.Method.mutual_information),
+                          sp.score_splits(dev, splits, method=sp.Method.mutual_information))
+    dev_w = sp.DeviceAlignment.from_arrays(g["keys"], g["probs"], 10, taxa=names, exact=False)
+    assert np.abs(sp.score_all_splits(dev_w) - g["scores"]).max() <= SCORE_TOL
+    # 12 taxa (most splits beyond the LDS form: the device chain) and a forced hand-back to the dense route
+    from splitp_amd import simulation as sim
+    from splitp_amd import synthetic as syn
+    d12 = sim.generate_device_alignment(syn.balanced_tree(12), sim.JukesCantor(), 50_000, seed=4, branch_length=0.05)
+    d12.taxa = tuple(taxa_names(12))
+    s12 = sp.score_all_splits(d12)
+    assert len(s12) == 2035 and np.array_equal(s12, sp.score_splits(d12, list(sp.all_splits(taxa_names(12)))))
+    rng = np.random.default_rng(3)
+    rk = np.unique(rng.integers(0, 4 ** 10, size=3000).astype(np.uint64))
+    rc = rng.integers(1, 40, size=len(rk)).astype(np.int64)
+    flat = sp.DeviceAlignment.from_arrays(rk, None, 10, counts=rc, n_sites=int(rc.sum()), taxa=names)
+    fa, fst = sp.score_all_splits(flat, size=3, return_status=True)
+    fb = sp.score_splits(flat, list(sp.all_splits(names, size=3)))
+    assert np.array_equal(fa, fb) and not np.any(fst & 2)
