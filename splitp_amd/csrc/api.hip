@@ -183,7 +183,8 @@ extern "C" int sp_ctx_destroy(sp_ctx* c) {
         }
     for (auto e : c->timer.pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->splits, &c->bitmaps, &c->coords, &c->dims, &c->mats,  &c->grams,  &c->eigws,
-                      &c->scores, &c->status,  &c->misc,   &c->misc2, &c->gram_items, &c->aldescs, &c->slabs, &c->chain};
+                      &c->scores, &c->status,  &c->misc,   &c->misc2, &c->gram_items, &c->aldescs, &c->slabs, &c->chain,
+                      &c->splits_launch};
     if (c->cache && c->cache->sparse) (void)sp_plan_release(c->cache->sparse);
     delete c->cache;
     for (auto* b : bufs) b->release();
@@ -763,13 +764,18 @@ extern "C" int sp_plan_create(sp_ctx* ctx, int n_taxa, const int32_t* split_taxa
     for (const SplitDev& sd : pl->splits) pl->bm_words_max = std::max<int64_t>(pl->bm_words_max, (int64_t)sd.rw + sd.cw);
     int rc = SP_OK;
     const size_t s1 = (size_t)std::max<int64_t>(n_splits, 1);
-    if ((rc = pl->splits_dev.ensure(s1 * sizeof(SplitDev))) || (rc = pl->order_dev.ensure(s1 * sizeof(int)))) {
+    if ((rc = pl->splits_dev.ensure(s1 * sizeof(SplitDev))) || (rc = pl->launch_dev.ensure(s1 * sizeof(SplitDev)))) {
         sp_plan_release(pl);
         return rc;
     }
     if (n_splits > 0) {
+        std::vector<SplitDev> launch((size_t)n_splits);
+        for (int64_t b = 0; b < n_splits; ++b) {
+            launch[b] = pl->splits[order[b]];
+            launch[b].cls = order[b];
+        }
         hipError_t e = hipMemcpy(pl->splits_dev.p, pl->splits.data(), (size_t)n_splits * sizeof(SplitDev), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(pl->order_dev.p, order.data(), (size_t)n_splits * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(pl->launch_dev.p, launch.data(), (size_t)n_splits * sizeof(SplitDev), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             sp_plan_release(pl);
             sp_set_error("sp_plan_create: upload failed: %s", hipGetErrorString(e));
@@ -796,7 +802,7 @@ extern "C" int sp_plan_release(sp_plan* plan) {
     (void)hipSetDevice(plan->device);
     (void)hipDeviceSynchronize();   // kernels of any lane may still be reading it
     plan->splits_dev.release();
-    plan->order_dev.release();
+    plan->launch_dev.release();
     delete plan;
     return SP_OK;
     });
@@ -830,8 +836,8 @@ static int enqueue_sparse_plan(sp_ctx* ctx, sp_alignment* const* als, int n_al, 
     }
     const AlDesc* descs = nullptr;
     SP_CHECK(aldescs_for(ctx, als, n_al, &descs));
-    return launch_sparse_chain(ctx, descs, n_al, plan->n, plan->splits_dev.as<SplitDev>(), plan->order_dev.as<int>(),
-                               plan->S, scores, status, dmax, plan->bm_words_max, wide_all);
+    return launch_sparse_chain(ctx, descs, host_aldesc(als[0]), n_al, plan->n, plan->splits_dev.as<SplitDev>(),
+                               plan->launch_dev.as<SplitDev>(), plan->S, scores, status, dmax, plan->bm_words_max, wide_all);
 }
 
 extern "C" int sp_score_plan_async(sp_ctx* lane, sp_alignment* const* als, int n_al, sp_plan* plan, void* scores_dev,
@@ -971,7 +977,7 @@ struct ClassLayout {
 
 __global__ __launch_bounds__(256) void k_plan_enumerated(int n, int total, const int8_t* __restrict__ taxa,
                                                          const int* __restrict__ a_arr, ClassLayout cl,
-                                                         SplitDev* __restrict__ out, int* __restrict__ order) {
+                                                         SplitDev* __restrict__ out, SplitDev* __restrict__ launch) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int a = a_arr[i], b = n - a;
@@ -988,7 +994,8 @@ __global__ __launch_bounds__(256) void k_plan_enumerated(int n, int total, const
     out[i] = sd;
     int q = 0;
     while (q + 1 < cl.n_classes && i >= cl.start[q + 1]) ++q;
-    order[cl.out_start[q] + (i - cl.start[q])] = i;
+    sd.cls = i;
+    launch[cl.out_start[q] + (i - cl.start[q])] = sd;
 }
 
 static int run_flat_all_splits(sp_alignment* al, int method, int trivial, int size, int64_t* n_out, bool score) {
@@ -1040,18 +1047,19 @@ static int run_flat_all_splits(sp_alignment* al, int method, int trivial, int si
         bmw = std::max<int64_t>(bmw, (pow4(sizes[q]) + 63) / 64 + (pow4(n - sizes[q]) + 63) / 64);
     }
     SP_CHECK(ctx->splits.ensure((size_t)total * sizeof(SplitDev)));
-    SP_CHECK(ctx->gram_items.ensure((size_t)total * sizeof(int)));
+    SP_CHECK(ctx->splits_launch.ensure((size_t)total * sizeof(SplitDev)));
     SP_CHECK(ctx->scores.ensure((size_t)total * 8));
     SP_CHECK(ctx->status.ensure((size_t)total * 4));
     if (ctx->cache) ctx->cache->valid = false;   // ctx->splits is rewritten
     hipLaunchKernelGGL(k_plan_enumerated, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, n, (int)total, dtaxa,
-                       da, cl, ctx->splits.as<SplitDev>(), ctx->gram_items.as<int>());
+                       da, cl, ctx->splits.as<SplitDev>(), ctx->splits_launch.as<SplitDev>());
     SP_HIP(hipGetLastError());
     const AlDesc* descs = nullptr;
     sp_alignment* als1[1] = {al};
     SP_CHECK(aldescs_for(ctx, als1, 1, &descs));
-    SP_CHECK(launch_sparse_chain(ctx, descs, 1, n, ctx->splits.as<SplitDev>(), ctx->gram_items.as<int>(), total,
-                                 ctx->scores.as<double>(), ctx->status.as<int>(), srows, bmw, false));
+    SP_CHECK(launch_sparse_chain(ctx, descs, host_aldesc(al), 1, n, ctx->splits.as<SplitDev>(),
+                                 ctx->splits_launch.as<SplitDev>(), total, ctx->scores.as<double>(), ctx->status.as<int>(),
+                                 srows, bmw, false));
     std::vector<int> st((size_t)total);
     SP_HIP(hipMemcpyAsync(st.data(), ctx->status.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));

@@ -112,6 +112,7 @@ struct sp_ctx {
     PhaseTimer timer;
     // workspace pools (see DESIGN.md "HBM layout")
     DevBuf splits;     // SplitDev[n_splits]
+    DevBuf splits_launch;   // ... and in launch order (device-planned all-splits call)
     DevBuf bitmaps;    // presence bitmaps + rank prefixes
     DevBuf coords;     // compact (row, col) of every (split, pattern)
     DevBuf dims;       // int2 (R, C) per split
@@ -174,7 +175,7 @@ struct SplitDev {
     int32_t rcap;        // allocated rows (multiple of 64)
     int64_t g_off;       // element offset of the Gram matrix in the gram pool
     int32_t g_pitch;     // Gram pitch (= rcap)
-    int32_t cls;         // size class (for launch grouping)
+    int32_t cls;         // launch-ordered copies (sp_plan::launch_dev): the split's index in the list
     int64_t ev_off;      // element offset of the 16 x rcap iteration blocks (V^T, Y) in the eigen pools
 };
 
@@ -214,7 +215,8 @@ struct sp_plan {
     std::vector<SplitDev> splits;   // host copy
     std::vector<int32_t> taxa, a;   // the list as given (content key of the internal plan cache)
     int64_t bm_words_max = 0;       // largest rw + cw among the splits (slab sizing)
-    DevBuf splits_dev, order_dev;
+    DevBuf splits_dev;   // SplitDev[S], list order (the slow kernel and the dense route index it by split)
+    DevBuf launch_dev;   // SplitDev[S], launch order (heaviest first), each with its split index in `cls`
 };
 
 struct PhaseScope {
@@ -256,9 +258,9 @@ int launch_sparse_big_keys(sp_ctx* ctx, const u64* keys, int64_t D, int n, const
                            int64_t S, const u32* counts, const double* weights, int dev_cus, double* scores, int* status);
 int launch_sparse_big(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, const u32* cc, const u32* counts,
                       const double* weights, const int2* dims, int dev_cus, double* scores, int* status);
-int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,
-                        const int* order_dev, int64_t S, double* scores, int* status, int64_t d_max, int64_t bm_words_max,
-                        bool wide_all);
+int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, const AlDesc& al0, int n_al, int n_taxa,
+                        const SplitDev* splits_dev, const SplitDev* launch_dev, int64_t S, double* scores, int* status,
+                        int64_t d_max, int64_t bm_words_max, bool wide_all);
 int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta,
                        unsigned long long trace_override, int64_t orig_rows);
 template <typename T>

@@ -631,8 +631,8 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
 // its early exits with scores / status of the item written by thread 0 and returns the status word (the same value in
 // every thread: all exit conditions are uniform); the caller barriers before LDS is reused.
 template <bool HBM, bool WIDE, bool LISTS_GLOBAL>
-__device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, const AlDesc* __restrict__ als, int ai,
-                                              int sid, int n, const SplitDev* __restrict__ splits, int S,
+__device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, const AlDesc& ad, int ai, int sid, int n,
+                                              const SplitDev& sp, int S,
                                               double* __restrict__ scores_all, int* __restrict__ status_all,
                                               unsigned char* __restrict__ slab, size_t slab_bytes, size_t lds_cap,
                                               int wide_cap) {
@@ -646,13 +646,12 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     // global memory, which is what lets a 13 k-pattern table keep its staging arrays, counters and the V / W blocks in LDS)
     static_assert(!(HBM && LISTS_GLOBAL), "LISTS_GLOBAL is a variant of the LDS form");
     const size_t cap = HBM ? slab_bytes : ((lds_cap && !LISTS_GLOBAL) ? lds_cap : (size_t)SPK_LDS_BYTES);
-    const u32* __restrict__ keys = als[ai].keys32;
-    const u32* __restrict__ counts = als[ai].counts;
-    const SpkMeta* __restrict__ meta = als[ai].meta;
-    const int64_t D = als[ai].D;
+    const u32* __restrict__ keys = ad.keys32;
+    const u32* __restrict__ counts = ad.counts;
+    const SpkMeta* __restrict__ meta = ad.meta;
+    const int64_t D = ad.D;
     double* __restrict__ scores = scores_all + (int64_t)ai * S;
     int* __restrict__ status = status_all + (int64_t)ai * S;
-    const SplitDev& sp = splits[sid];
     const int nr = sp.nr, nc = sp.nc, rw = sp.rw, cw = sp.cw;
     if (threadIdx.x < 32) {
         const int t = threadIdx.x < nr + nc ? sp.taxa[threadIdx.x] : 0;
@@ -734,6 +733,21 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     // tables (4 taxa each) built here - 3 look-ups + 2 ORs per pattern instead of 4 instructions per taxon (the
     // staging loop is instruction-bound: 16 waves share 4 SIMDs)
     u32* lut = reinterpret_cast<u32*>(carve(4 * 256 * 4));
+    // The table's keys (and counts) come from global memory, SPK_SU loads in flight per thread; the plain LDS form issues
+    // its first - for every table it can hold, only - batch HERE, before the look-up tables are built, and consumes it
+    // after the barrier: under load a batch waits 4 - 5 k cycles for the L2, and the old 8-load batches took two of them
+    // for a 8.2 k-pattern table (34 patterns in the second).
+    constexpr int SPK_SU = PLAIN ? 10 : 8;
+    u32 key[SPK_SU], cv[SPK_SU];
+    auto load_batch = [&](int base0) {
+#pragma unroll
+        for (int u = 0; u < SPK_SU; ++u) {
+            const int i = base0 + u * SPK_THREADS + (int)threadIdx.x;
+            key[u] = i < Di ? keys[i] : 0u;
+            if (!PLAIN) cv[u] = i < Di ? counts[i] : 0u;
+        }
+    };
+    if (PLAIN) load_batch(0);
     {
         for (int e = threadIdx.x; e < 1024; e += SPK_THREADS) {
             const int ch = e >> 8, v = e & 255;
@@ -750,17 +764,11 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     const bool both_raw = raw_r && raw_c;
     const bool wide_key = n > 12;   // bits 24..31 in use
     __syncthreads();   // bitmaps are zero
-    for (int base = 0; base < Di; base += SPK_THREADS * 8) {   // 8 global loads in flight per thread
-        u32 key[8], cv[8];
+    for (int base0 = 0; base0 < Di; base0 += SPK_THREADS * SPK_SU) {
+        if (!PLAIN || base0 > 0) load_batch(base0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + u * SPK_THREADS + (int)threadIdx.x;
-            key[u] = i < Di ? keys[i] : 0u;
-            if (!PLAIN) cv[u] = i < Di ? counts[i] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + u * SPK_THREADS + (int)threadIdx.x;
+        for (int u = 0; u < SPK_SU; ++u) {
+            const int i = base0 + u * SPK_THREADS + (int)threadIdx.x;
             if (i >= Di) continue;
             u32 cell = lut[key[u] & 255u] | lut[256 + ((key[u] >> 8) & 255u)] | lut[512 + ((key[u] >> 16) & 255u)];
             if (wide_key) cell |= lut[768 + (key[u] >> 24)];
@@ -1223,19 +1231,27 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
 }
 
 // ---- the kernels around spk_score_one ---------------------------------------------------------------------------------
-// k_sparse_score: grid = n_al * S workgroups, block b scores split order[b / n_al] of alignment b % n_al (heaviest
-// splits of every alignment first) in the in-LDS form; score / status index = alignment * S + split.  Block 0 also
-// zeroes the work-queue head of the slow kernel queued behind it on the same stream.
-__global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __restrict__ als, int n_al, int n,
-                                                              const SplitDev* __restrict__ splits,
-                                                              const int* __restrict__ order, int S,
+// k_sparse_score: grid = n_al * S workgroups, block b scores the (b / n_al)-th split of the launch order (heaviest splits
+// of every alignment first) of alignment b % n_al in the in-LDS form; score / status index = alignment * S + split.
+// Block 0 also zeroes the work-queue head of the slow kernel queued behind it on the same stream.
+// A workgroup's first loads are all one hop from the kernel arguments: `launch` holds the split descriptors IN launch
+// order with the split's own index in `cls` (no order[] -> splits[] chain), and a single alignment's descriptor comes by
+// value (no als[] -> keys chain).  Under load a dependent global load costs 2.5 - 5 k cycles, and the staging of a late
+// workgroup used to wait for three of them in a row (24 k cycles against 13 k for the first workgroups of a launch).
+__global__ __launch_bounds__(SPK_THREADS) void k_sparse_score(const AlDesc* __restrict__ als, const AlDesc al0, int n_al,
+                                                              int n, const SplitDev* __restrict__ launch, int S,
                                                               double* __restrict__ scores_all,
                                                               int* __restrict__ status_all, int* __restrict__ queue_head,
                                                               size_t lds_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (queue_head && blockIdx.x == 0 && threadIdx.x == 0) *queue_head = 0;
-    (void)spk_score_one<false, false, false>(smem, als, (int)(blockIdx.x % n_al), order[blockIdx.x / n_al], n, splits, S,
-                                             scores_all, status_all, nullptr, 0, lds_cap, 0);
+    const int ai = (int)(blockIdx.x % n_al);
+    const SplitDev& sp = launch[blockIdx.x / n_al];
+    if (n_al == 1)
+        (void)spk_score_one<false, false, false>(smem, al0, 0, sp.cls, n, sp, S, scores_all, status_all, nullptr, 0, lds_cap, 0);
+    else
+        (void)spk_score_one<false, false, false>(smem, als[ai], ai, sp.cls, n, sp, S, scores_all, status_all, nullptr, 0,
+                                                 lds_cap, 0);
 }
 
 // k_sparse_slow: the hand-back chain ON THE DEVICE, queued behind k_sparse_score - no host round trip.  A fixed grid of
@@ -1264,8 +1280,8 @@ __device__ __noinline__ int spk_score_slow(const AlDesc* __restrict__ als, int a
                                            int* __restrict__ status_all, unsigned char* __restrict__ slab,
                                            size_t slab_bytes, int wide_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    return spk_score_one<HBM, WIDE, LISTS_GLOBAL>(smem, als, ai, sid, n, splits, S, scores_all, status_all, slab, slab_bytes,
-                                                  0, wide_cap);
+    return spk_score_one<HBM, WIDE, LISTS_GLOBAL>(smem, als[ai], ai, sid, n, splits[sid], S, scores_all, status_all, slab,
+                                                  slab_bytes, 0, wide_cap);
 }
 
 __global__ __launch_bounds__(SPK_THREADS) void k_sparse_slow(const AlDesc* __restrict__ als, int n_al, int n,
@@ -1414,9 +1430,9 @@ size_t sparse_slab_bytes(int64_t D, int64_t bm_words, bool wide) {
 // kernel, and queued behind it the slow kernel that finishes - on the device - whatever the first one handed back.
 // d_max / bm_words_max: largest table / bitmap size among the items (slab sizing).  wide_all: see k_sparse_slow.
 // Afterwards a status word has bit 1 set only for splits left to the dense route (wide_all = false).
-int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa, const SplitDev* splits_dev,
-                        const int* order_dev, int64_t S, double* scores, int* status, int64_t d_max, int64_t bm_words_max,
-                        bool wide_all) {
+int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, const AlDesc& al0, int n_al, int n_taxa,
+                        const SplitDev* splits_dev, const SplitDev* launch_dev, int64_t S, double* scores, int* status,
+                        int64_t d_max, int64_t bm_words_max, bool wide_all) {
     if (S == 0 || n_al == 0) return SP_OK;
     const int64_t n_items = S * n_al;
     SP_REQUIRE(n_items < ((int64_t)1 << 31), SP_ELIMIT, "sparse route: %lld items in one call (limit 2^31)", (long long)n_items);
@@ -1453,7 +1469,7 @@ int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, int n_al, int n_taxa
     {
         PhaseScope ps(ctx, SP_PHASE_SPARSE);
         hipLaunchKernelGGL(k_sparse_score, dim3((unsigned)n_items), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream, als_dev,
-                           n_al, n_taxa, splits_dev, order_dev, (int)S, scores, status, q.head, (size_t)ctx->opt.lds_cap);
+                           al0, n_al, n_taxa, launch_dev, (int)S, scores, status, q.head, (size_t)ctx->opt.lds_cap);
         SP_HIP(hipGetLastError());
     }
     PhaseScope ps(ctx, SP_PHASE_CHAIN);
