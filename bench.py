@@ -37,7 +37,6 @@ import time
 # initialisation, hence before torch is imported).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool's host driver
-os.environ.setdefault("NCCL_DEBUG", "WARN")                # no RCCL version banner on stdout: rank 0 prints ONE JSON line
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -209,8 +208,12 @@ def roofline_block(dom, dom_ms_alone, dom_ms_region, in_flight, phases_per_step,
         except Exception:
             pmc = None
     if dom in ("gram", "eigen"):
+        # dense route: the executed work differs from SURVEY 8(d)'s fp64 count (compact upper-triangular problem, int8 limbs
+        # for the Gram, 16-wide block products for the eigen rounds), so no fraction of the fp64 peak is claimed for it
         roof.update({"bound": "mfma", "achieved": survey["gram_phase"]["achieved"], "peak": FP64_MFMA_PEAK_TF,
-                     "unit": "TFLOP/s", "frac": survey["gram_phase"]["frac"]})
+                     "unit": "TFLOP/s", "frac": None,
+                     "note": "achieved = SURVEY 8(d)'s algorithmic fp64 Gram flops / this phase's duration; the kernels execute "
+                             "other (less) work - see DESIGN.md section 4 for their own counters (k_gram_i8: 7 % MFMA busy)"})
         if pmc:
             roof["traffic"] = pmc.get("hbm_bytes_per_launch")
         return roof
@@ -234,6 +237,13 @@ def roofline_block(dom, dom_ms_alone, dom_ms_region, in_flight, phases_per_step,
                                        "GRBM_GUI_ACTIVE / 8 of the profiled launches next to it)",
                          "source": "profiles/r02_pmc_binding.json"}})
         roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+        return roof
+    if dom == "chain":
+        roof.update({"bound": "lds", "achieved": None, "peak": N_CU * CLOCK_GHZ * 1e9 / 1e12, "unit": "T LDS-array cycles/s",
+                     "frac": None,
+                     "note": "the slow forms of the sparse kernel (entry lists / every array in global memory): L2-latency "
+                             "bound variants of k_sparse_score; no PMC profile of this kernel is committed, so no binding "
+                             "fraction is claimed"})
         return roof
     roof.update({"bound": "hbm", "achieved": survey["scatter_phase"]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": None if dom == "sparse" else survey["scatter_phase"]["frac"],
@@ -290,12 +300,24 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
+        # RCCL prints a version banner to STDOUT when its communicator is created; rank 0's stdout carries ONE JSON line,
+        # so file descriptor 1 points at stderr until the communicator exists (forced here by a first barrier)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
         try:
-            opts = dist.ProcessGroupNCCL.Options()
-            opts.is_high_priority_stream = not args.no_hipri   # the all-gather competes with queued scoring workgroups
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
-        except (TypeError, AttributeError):                     # older / newer torch without these options
-            dist.init_process_group("nccl")
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = not args.no_hipri   # the all-gather competes with queued scoring workgroups
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
+            except (TypeError, AttributeError):                     # older / newer torch without these options
+                dist.init_process_group("nccl")
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     else:
         torch.cuda.set_device(0)
     dev_t = torch.device("cuda", torch.cuda.current_device())

@@ -24,7 +24,7 @@ for k in (5, 4, 3, 2):
     nrep = 8
     sc = torch.zeros(nrep * len(sub), dtype=torch.float64, device="cuda")
     st = torch.zeros(nrep * len(sub), dtype=torch.int32, device="cuda")
-    for blk in (0, nrep * len(sub) - 1):
+    for blk in (0, (nrep * len(sub)) // 2 + 3, nrep * len(sub) - 1):
         lib.sp_debug_spk_stamp_block(blk)
         for rep in range(2):
             batch.score_encoded_multi_async([dev] * nrep, taxa_arr, a_arr, sc.data_ptr(), st.data_ptr())
