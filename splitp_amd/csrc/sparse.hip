@@ -630,7 +630,7 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
 // LDS size for the plain LDS form (test switch: exercises the hand-back chain on small tables).  Returns through any of
 // its early exits with scores / status of the item written by thread 0 and returns the status word (the same value in
 // every thread: all exit conditions are uniform); the caller barriers before LDS is reused.
-template <bool HBM, bool WIDE, bool LISTS_GLOBAL>
+template <bool HBM, bool WIDE, bool LISTS_GLOBAL, bool W_GLOBAL = false>
 __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, const AlDesc& ad, int ai, int sid, int n,
                                               const SplitDev& sp, int S,
                                               double* __restrict__ scores_all, int* __restrict__ status_all,
@@ -645,6 +645,11 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     // (LISTS_GLOBAL: the LDS form with its two entry lists - written once, read sequentially - in a small slab of
     // global memory, which is what lets a 13 k-pattern table keep its staging arrays, counters and the V / W blocks in LDS)
     static_assert(!(HBM && LISTS_GLOBAL), "LISTS_GLOBAL is a variant of the LDS form");
+    // W_GLOBAL: the lists-in-global form with the column-side block W in the slab as well.  A 4|8 split of a 12-taxon
+    // table has ~5000 used columns: W alone is the whole LDS, but V (256 rows), the staged table and the sort counters
+    // fit - so only the products' gathers of W (L2 hits, thousands in flight) and the Gram / Cholesky-QR passes over W
+    // leave the LDS, not the whole build as in the all-global form (331 -> 260 us of one CU per item).
+    static_assert(!W_GLOBAL || LISTS_GLOBAL, "W_GLOBAL is a variant of the lists-in-global form");
     const size_t cap = HBM ? slab_bytes : ((lds_cap && !LISTS_GLOBAL) ? lds_cap : (size_t)SPK_LDS_BYTES);
     const u32* __restrict__ keys = ad.keys32;
     const u32* __restrict__ counts = ad.counts;
@@ -707,7 +712,8 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     unsigned char* const lslab = LISTS_GLOBAL ? slab : nullptr;
     // (LISTS_GLOBAL: the group descriptors / permutations of both lists - read in sequence by the products - go there too)
     const size_t gdesc_bytes = (((size_t)max((long long)D, 1024ll) + 2) * 2 + 15) & ~(size_t)15;
-    if (LISTS_GLOBAL && 2 * list_bytes + 4 * gdesc_bytes > slab_bytes) {
+    const size_t wslab_off = 2 * list_bytes + 4 * gdesc_bytes;   // W_GLOBAL: W sits behind the lists and descriptors
+    if (LISTS_GLOBAL && wslab_off + (W_GLOBAL ? ((size_t)max((long long)D, 1024ll) + 8) * SPK_NB * 8 : 0) > slab_bytes) {
         if (threadIdx.x == 0) {
             scores[sid] = 0.0;
             status[sid] = 2;
@@ -856,19 +862,24 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     unsigned short* desc_r = small ? nullptr : carve_desc(1, (size_t)(R + 1) * 2);
     unsigned short* perm_c = small ? nullptr : carve_desc(2, (size_t)Kc * 2);
     unsigned short* perm_r = small ? nullptr : carve_desc(3, (size_t)R * 2);
-    unsigned short* csc_ptr = small ? reinterpret_cast<unsigned short*>(carve_top((size_t)(Kc + 1) * 2)) : nullptr;
+    // (small path: the column pointers and - below - the column of every list position; with the lists in global memory
+    // they go there as well, into two of the four descriptor slots: what stays in LDS then is the staged table, the sort
+    // counters and G, which is what lets the 3|9 splits of a 12-taxon table - 9 k columns - stay out of the all-global form)
+    unsigned short* csc_ptr = small ? carve_desc(0, (size_t)(Kc + 1) * 2) : nullptr;
     const size_t build_end = reinterpret_cast<unsigned char*>(bm) - base;
     // V and W are column-major: four arrays of Rp / Kcp doubles.  A lane's four gathers then go to four arrays -
     // measured 9 % faster than four consecutive doubles of one row (fewer LDS bank conflicts), and no row padding.
     // (+ 4: the four columns of one row start on different banks - the dense small-side product reads them together)
     const int Kcp = ((Kc + 3) & ~3) + 4;
     const int Vp = Rp + 4;
+    // (W_GLOBAL keeps the column-major layout: row-major [column id][4] - one 32-byte access per gathered row - measured
+    // the same, 267 against 259 us per item: the passes over W wait on L2 latency, not on sectors)
     const int v_rs = 1, v_cs = Vp, w_rs = 1, w_cs = Kcp;
     const size_t base_iter = off_after_lists + (size_t)Vp * NBC * 8 + 16;
     const int Gp = R | 1;   // odd row pitch of the dense G: a pitch of 64 doubles puts every row on the same LDS bank
-    const size_t need_iter = base_iter + (small ? (size_t)R * Gp * 8 : (size_t)Kcp * NBC * 8);
+    const size_t need_iter = base_iter + (small ? (size_t)R * Gp * 8 : ((W_GLOBAL ? 0 : (size_t)Kcp * NBC * 8)));
     // small path: column of every CSC position (for the entry-parallel Gram below), carved from the top as well
-    unsigned short* colof = small ? reinterpret_cast<unsigned short*>(carve_top((size_t)Di * 2)) : nullptr;
+    unsigned short* colof = small ? carve_desc(2, (size_t)Di * 2) : nullptr;
     // counters: rows of 16-bit (8-bit when a group cannot exceed 255 entries) fields
     const bool bits8 = small;   // a column has at most R <= 64 entries
     // every wave gets its own row when that fits (shorter chunks per lane), else the first SPK_SORT_WAVES waves sort
@@ -882,7 +893,12 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     const int ns_c_lds = HBM ? (int)min((size_t)SPK_WAVES, lds_free / max(cw_c1, (size_t)4)) : 0;
     const int ns_r_lds = (HBM && !small) ? (int)min((size_t)SPK_WAVES, lds_free / max(cw_r1, (size_t)4)) : 0;
     const bool cwc_lds = ns_c_lds >= 4, cwr_lds = ns_r_lds >= 4;
-    const int ns_c = cwc_lds ? ns_c_lds : (build_end + SPK_WAVES * cw_c1 <= top ? SPK_WAVES : SPK_SORT_WAVES);
+    auto rows_that_fit = [&](size_t row_bytes, size_t extra) {   // 16, 8, 4, 2 or 1 wave-private counter rows
+        int ns = SPK_WAVES;
+        while (ns > 1 && build_end + (size_t)ns * row_bytes + extra + 16 > top) ns >>= 1;
+        return ns;
+    };
+    const int ns_c = cwc_lds ? ns_c_lds : rows_that_fit(cw_c1, 0);
     const int ns_r = cwr_lds ? ns_r_lds
                              : (build_end + SPK_WAVES * cw_r1 + grp_r_probe + 16 <= top ? SPK_WAVES : SPK_SORT_WAVES);
     const size_t cw_c = cwc_lds ? 0 : (size_t)ns_c * cw_c1;                  // bytes taken behind the staging arrays
@@ -1007,7 +1023,8 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     // V and W / G are laid out over the (now dead) staging area
     off = off_after_lists;
     double* V = reinterpret_cast<double*>(carve((size_t)Vp * NBC * 8));
-    double* Wb = reinterpret_cast<double*>(base + off);   // large: W (Kc x 4);  small: G (R x R)
+    double* Wb = (W_GLOBAL && !small) ? reinterpret_cast<double*>(lslab + wslab_off)
+                                      : reinterpret_cast<double*>(base + off);   // large: W (Kc x 4);  small: G (R x R)
     if (small) {
         // exact Gram G = C C^T: all pairs of entries inside every column, accumulated with integer LDS atomics (exact,
         // order independent).  One thread per CSC position i of a column of n entries takes the pairs (i, i + d mod n),
@@ -1274,14 +1291,14 @@ struct SpkSlow {
     int wide_cap;                    // half-product cap of the wide block (0 = SPK_MAXHALF_WIDE; tests of SP_ENOCONV lower it)
 };
 
-template <bool HBM, bool WIDE, bool LISTS_GLOBAL>
+template <bool HBM, bool WIDE, bool LISTS_GLOBAL, bool W_GLOBAL = false>
 __device__ __noinline__ int spk_score_slow(const AlDesc* __restrict__ als, int ai, int sid, int n,
                                            const SplitDev* __restrict__ splits, int S, double* __restrict__ scores_all,
                                            int* __restrict__ status_all, unsigned char* __restrict__ slab,
                                            size_t slab_bytes, int wide_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    return spk_score_one<HBM, WIDE, LISTS_GLOBAL>(smem, als[ai], ai, sid, n, splits[sid], S, scores_all, status_all, slab,
-                                                  slab_bytes, 0, wide_cap);
+    return spk_score_one<HBM, WIDE, LISTS_GLOBAL, W_GLOBAL>(smem, als[ai], ai, sid, n, splits[sid], S, scores_all, status_all,
+                                                            slab, slab_bytes, 0, wide_cap);
 }
 
 __global__ __launch_bounds__(SPK_THREADS) void k_sparse_slow(const AlDesc* __restrict__ als, int n_al, int n,
@@ -1326,6 +1343,11 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_slow(const AlDesc* __res
             if (st == 2) {
                 __syncthreads();
                 st = spk_score_slow<false, false, true>(als, ai, sid, n, splits, S, scores_all, status_all, slab, q.slab_l, 0);
+            }
+            if (st == 2) {   // ... then with W in global memory too
+                __syncthreads();
+                st = spk_score_slow<false, false, true, true>(als, ai, sid, n, splits, S, scores_all, status_all, slab, q.slab_l,
+                                                              0);
             }
             if (st == 2) {
                 __syncthreads();
@@ -1415,7 +1437,8 @@ int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t 
 size_t sparse_list_slab_bytes(int64_t D) {
     const size_t list_bytes = ((size_t)(D + 8) * 4 + 15) & ~(size_t)15;
     const size_t gdesc_bytes = (((size_t)std::max<int64_t>(D, 1024) + 2) * 2 + 15) & ~(size_t)15;
-    return (2 * list_bytes + 4 * gdesc_bytes + 255) & ~(size_t)255;
+    const size_t w_bytes = ((size_t)std::max<int64_t>(D, 1024) + 8) * SPK_NB * 8;   // the W_GLOBAL variant's block
+    return (2 * list_bytes + 4 * gdesc_bytes + w_bytes + 255) & ~(size_t)255;
 }
 
 // Bytes of global memory one workgroup of the HBM form needs for a table of D patterns whose bitmaps take `bm_words`
