@@ -211,6 +211,15 @@ int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, const int32_t* 
  * splits; with all three output pointers NULL the call only counts.  Outputs and SP_ENOCONV as for sp_score_splits. */
 int sp_score_all_splits(sp_alignment* al, int method, int trivial, int size, int64_t* n_splits, double* scores_host,
                         void* scores_dev, int32_t* status_host);
+/* One shard of the same enumeration for multi-GPU runs ("index-mod-P within each class"): rank shard_rank of
+ * shard_world scores the combinations shard_rank, shard_rank + shard_world, ... of EVERY size class - an equal share of
+ * every cost class, nothing but two integers crosses the boundary.  Its n_splits results come class by class, in
+ * enumeration order inside a class: the j-th result of class q is split (class start) + shard_rank + j * shard_world of
+ * all_splits (splitp_amd/batch.py shard_layout un-permutes the all-gathered buffers).  status_dev: optional device
+ * buffer for the status words (so that scores and status can be written straight into a collective's send buffer). */
+int sp_score_all_splits_shard(sp_alignment* al, int method, int trivial, int size, int shard_rank, int shard_world,
+                              int64_t* n_splits, double* scores_host, void* scores_dev, int32_t* status_host,
+                              void* status_dev);
 
 /* Asynchronous form for pipelines that keep everything on the device (benchmark loop, multi-GPU all-gather):
  * enqueues the scoring of the splits on the context's stream and returns without any host synchronisation.

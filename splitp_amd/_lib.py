@@ -35,7 +35,7 @@ SYMBOLS = (
     "sp_flatten_indices", "sp_flatten_reduced_prepare", "sp_flatten_reduced_fetch", "sp_flatten_dense_counts",
     "sp_subflatten", "sp_moment_matrix",
     "sp_score_matrix_f64", "sp_score_coo_f64", "sp_divergence_matrix_f64", "sp_score_splits", "sp_score_splits_async",
-    "sp_score_splits_multi_async", "sp_score_all_splits",
+    "sp_score_splits_multi_async", "sp_score_all_splits", "sp_score_all_splits_shard",
     "sp_plan_create", "sp_plan_retain", "sp_plan_release", "sp_plan_info", "sp_score_plan_async",
 )
 
@@ -104,6 +104,7 @@ def load():
         "sp_score_splits_async": [vp, P(C.c_int32), P(C.c_int32), i64, i32, vp, vp],
         "sp_score_splits_multi_async": [P(vp), i32, P(C.c_int32), P(C.c_int32), i64, vp, vp],
         "sp_score_all_splits": [vp, i32, i32, i32, P(i64), P(dbl), vp, P(C.c_int32)],
+        "sp_score_all_splits_shard": [vp, i32, i32, i32, i32, i32, P(i64), P(dbl), vp, P(C.c_int32), vp],
         "sp_plan_create": [vp, i32, P(C.c_int32), P(C.c_int32), i64, P(vp)],
         "sp_plan_retain": [vp],
         "sp_plan_release": [vp],

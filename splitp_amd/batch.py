@@ -256,29 +256,90 @@ def gather_scores(local_scores, shards, n_total, group=None, device_tensor=None,
     return (out, status) if return_status else out
 
 
+def shard_layout(n_taxa, world_size, trivial=False, size=None):
+    """How sp_score_all_splits_shard deals all_splits(taxa) to `world_size` ranks: inside every size class rank r takes
+    the combinations r, r + P, ...  Returns (index arrays per rank into the all_splits order, total number of splits);
+    rank r's results come in exactly the order of its index array.  Pure arithmetic (no device)."""
+    from math import comb
+
+    n = int(n_taxa)
+    sizes = [size] if size is not None else list(range(1 if trivial else 2, n // 2 + 1))
+    per_rank = [[] for _ in range(world_size)]
+    start = 0
+    for bal in sizes:
+        cnt = comb(n - 1, bal - 1) if 2 * bal == n else comb(n, bal)
+        for r in range(world_size):
+            per_rank[r].append(np.arange(start + r, start + cnt, world_size, dtype=np.int64))
+        start += cnt
+    return [np.concatenate(x) if x else np.zeros(0, dtype=np.int64) for x in per_rank], start
+
+
 def score_all_splits(pattern_probabilities, method=Method.flattening, route="auto", trivial=False, size=None,
-                     return_status=False):
-    """Scores of every split of the table's taxa, in `all_splits` order, without building the Python split objects
-    (single process; `score_splits(table, all_splits(taxa))` is the distributed form)."""
+                     return_status=False, distributed=None, group=None):
+    """Scores of every split of the table's taxa, in `all_splits` order, without building the Python split objects.
+
+    distributed=None: use torch.distributed if it is initialised with world_size > 1 (every rank must call this; every
+    rank receives all scores).  Each rank then enumerates and scores ITS shard on the device - the combinations rank,
+    rank + P, ... of every size class, an equal share of every cost class -, the kernels' scores and status
+    go straight into the send buffer of ONE all_gather, and the host un-permutes (`shard_layout`).  No split list exists
+    anywhere: this is BASELINE config 4's partition (20 taxa, 524 267 splits over 8 GPUs, 4 MiB of scores)."""
     al = as_device_alignment(pattern_probabilities)
     code = _method_code(method, route)
+    use_dist = distributed
+    if use_dist is None:
+        try:
+            import torch.distributed as dist
+
+            use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        except Exception:
+            use_dist = False
+    if use_dist:
+        import torch
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        shards, total = shard_layout(al.n_taxa, world, trivial=trivial, size=size)
+        per = max(len(s) for s in shards)
+        nccl = dist.get_backend(group) == "nccl"
+        if nccl:
+            send = torch.zeros(packed_width(per), dtype=torch.float64,
+                               device=torch.device("cuda", torch.cuda.current_device()))
+            score_all_splits_shard(al, code, trivial, size, rank, world, scores_dev_ptr=send.data_ptr(),
+                                   status_dev_ptr=send.data_ptr() + per * 8)
+            out, status = gather_scores(None, shards, total, group=group, device_tensor=send, return_status=True)
+        else:
+            loc, loc_st = score_all_splits_shard(al, code, trivial, size, rank, world)
+            out, status = gather_scores(loc, shards, total, group=group, local_status=loc_st, return_status=True)
+        warn_unconverged(status)
+        return (out, status) if return_status else out
     if al.n_taxa <= 31:
         # the splits are enumerated on the device (sp_score_all_splits): no split list is built or uploaded at all; on the
         # default flattening route the split descriptors and the launch order are planned on the device as well
-        lib = al.ctx._lib
-        n = C.c_int64()
-        _lib.check(lib.sp_score_all_splits(al.handle, code, int(bool(trivial)), int(size or 0), C.byref(n), None, None, None))
-        scores = np.empty(n.value, dtype=np.float64)
-        status = np.zeros(n.value, dtype=np.int32)
-        if n.value:
-            _lib.check(lib.sp_score_all_splits(al.handle, code, int(bool(trivial)), int(size or 0), C.byref(n),
-                                               _lib._ptr(scores, C.c_double), None, _lib._ptr(status, C.c_int32)),
-                       allow_noconv=True)
-            warn_unconverged(status)
+        scores, status = score_all_splits_shard(al, code, trivial, size, 0, 1)
+        warn_unconverged(status)
         return (scores, status) if return_status else scores
     taxa_arr, a_arr = encode_all_splits(al.n_taxa, trivial=trivial, size=size)
     scores, status = score_encoded(al, taxa_arr, a_arr, code)
     return (scores, status) if return_status else scores
+
+
+def score_all_splits_shard(al, method_code, trivial, size, rank, world, scores_dev_ptr=None, status_dev_ptr=None):
+    """sp_score_all_splits_shard: this rank's share of all_splits, enumerated and scored on the device.  With device
+    pointers: enqueue only (results land there); else returns (scores, status) host arrays."""
+    lib = al.ctx._lib
+    n = C.c_int64()
+    args = (al.handle, method_code, int(bool(trivial)), int(size or 0), int(rank), int(world))
+    if scores_dev_ptr is not None:
+        _lib.check(lib.sp_score_all_splits_shard(*args, C.byref(n), None, C.c_void_p(scores_dev_ptr), None,
+                                                 C.c_void_p(status_dev_ptr) if status_dev_ptr else None))
+        return n.value
+    _lib.check(lib.sp_score_all_splits_shard(*args, C.byref(n), None, None, None, None))
+    scores = np.empty(n.value, dtype=np.float64)
+    status = np.zeros(n.value, dtype=np.int32)
+    if n.value:
+        _lib.check(lib.sp_score_all_splits_shard(*args, C.byref(n), _lib._ptr(scores, C.c_double), None,
+                                                 _lib._ptr(status, C.c_int32), None), allow_noconv=True)
+    return scores, status
 
 
 def score_splits(pattern_probabilities, splits, method=Method.flattening, distributed=None, group=None,

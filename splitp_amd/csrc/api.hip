@@ -965,8 +965,8 @@ static int run_sparse_route(sp_alignment* al, const int32_t* split_taxa, const i
 // subflat.hip's enumeration gives (taxa, a) of every split in all_splits order; k_plan_enumerated turns them into the
 // sparse kernel's split descriptors (smaller side = rows) and the heaviest-first launch order, on the device: no split
 // list, no plan crosses the boundary.
-int enumerate_all_splits(sp_ctx* ctx, int n, int trivial, int size, bool enumerate, int64_t* total_out,
-                         const int8_t** dtaxa_out, const int** da_out, std::vector<int>& sizes,
+int enumerate_all_splits(sp_ctx* ctx, int n, int trivial, int size, bool enumerate, int shard_rank, int shard_world,
+                         int64_t* total_out, const int8_t** dtaxa_out, const int** da_out, std::vector<int>& sizes,
                          std::vector<unsigned long long>& counts);   // subflat.hip
 
 struct ClassLayout {
@@ -998,7 +998,8 @@ __global__ __launch_bounds__(256) void k_plan_enumerated(int n, int total, const
     launch[cl.out_start[q] + (i - cl.start[q])] = sd;
 }
 
-static int run_flat_all_splits(sp_alignment* al, int method, int trivial, int size, int64_t* n_out, bool score) {
+static int run_flat_all_splits(sp_alignment* al, int method, int trivial, int size, int shard_rank, int shard_world,
+                               int64_t* n_out, bool score) {
     sp_ctx* ctx = al->ctx;
     const int n = al->n_taxa;
     const int8_t* dtaxa = nullptr;
@@ -1006,7 +1007,7 @@ static int run_flat_all_splits(sp_alignment* al, int method, int trivial, int si
     std::vector<int> sizes;
     std::vector<unsigned long long> counts;
     int64_t total = 0;
-    SP_CHECK(enumerate_all_splits(ctx, n, trivial, size, score, &total, &dtaxa, &da, sizes, counts));
+    SP_CHECK(enumerate_all_splits(ctx, n, trivial, size, score, shard_rank, shard_world, &total, &dtaxa, &da, sizes, counts));
     if (n_out) *n_out = total;
     if (!score || total == 0) return SP_OK;
     int64_t srows = 0;
@@ -1233,29 +1234,32 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
     });
 }
 
-int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int64_t* n_out, bool score);  // subflat.hip
+int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int shard_rank, int shard_world, int64_t* n_out,
+                           bool score);  // subflat.hip
 
 // Every split of the table's taxa in the reference's all_splits order (splits.py:39-59), enumerated on the device.
-extern "C" int sp_score_all_splits(sp_alignment* al, int method, int trivial, int size, int64_t* n_splits,
-                                   double* scores_host, void* scores_dev, int32_t* status_host) {
-    return sp_guard("sp_score_all_splits", [&]() -> int {
+extern "C" int sp_score_all_splits_shard(sp_alignment* al, int method, int trivial, int size, int shard_rank,
+                                         int shard_world, int64_t* n_splits, double* scores_host, void* scores_dev,
+                                         int32_t* status_host, void* status_dev) {
+    return sp_guard("sp_score_all_splits_shard", [&]() -> int {
     SP_REQUIRE(al, SP_EINVAL, "alignment is NULL");
     sp_ctx* ctx = al->ctx;
     SP_HIP(hipSetDevice(ctx->device));
-    const bool score = scores_host || scores_dev || status_host;
+    const bool score = scores_host || scores_dev || status_host || status_dev;
     SP_REQUIRE(!score || al->D > 0, SP_EINVAL, "empty pattern table");
     int64_t n = 0;
     if (method == SP_METHOD_SUBFLATTENING) {
-        SP_CHECK(run_subflat_all_splits(al, trivial, size, &n, score));
+        SP_CHECK(run_subflat_all_splits(al, trivial, size, shard_rank, shard_world, &n, score));
     } else {
         SP_REQUIRE(method == SP_METHOD_FLATTENING || method == SP_METHOD_FLATTENING_DENSE ||
                    method == SP_METHOD_FLATTENING_SPARSE || method == SP_METHOD_MUTUAL_INFORMATION, SP_EINVAL,
                    "unknown method %d", method);
-        SP_CHECK(run_flat_all_splits(al, method, trivial, size, &n, score));
+        SP_CHECK(run_flat_all_splits(al, method, trivial, size, shard_rank, shard_world, &n, score));
     }
     if (n_splits) *n_splits = n;
     if (!score || n == 0) return SP_OK;
     if (scores_dev) SP_HIP(hipMemcpyAsync(scores_dev, ctx->scores.p, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (status_dev) SP_HIP(hipMemcpyAsync(status_dev, ctx->status.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     if (scores_host) SP_HIP(hipMemcpyAsync(scores_host, ctx->scores.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (status_host) SP_HIP(hipMemcpyAsync(status_host, ctx->status.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (scores_host || status_host) SP_HIP(hipStreamSynchronize(ctx->stream));
@@ -1270,6 +1274,11 @@ extern "C" int sp_score_all_splits(sp_alignment* al, int method, int trivial, in
     }
     return SP_OK;
     });
+}
+
+extern "C" int sp_score_all_splits(sp_alignment* al, int method, int trivial, int size, int64_t* n_splits,
+                                   double* scores_host, void* scores_dev, int32_t* status_host) {
+    return sp_score_all_splits_shard(al, method, trivial, size, 0, 1, n_splits, scores_host, scores_dev, status_host, nullptr);
 }
 
 // Generic matrix: upload (transposed if needed so the smaller side indexes rows), Gram, eigen.

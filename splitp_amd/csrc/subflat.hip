@@ -596,10 +596,14 @@ int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t
 // balanced class n/2|n/2: taxon 0 plus every (n/2 - 1)-subset of the others); the side holding taxon 0 first, both sides in
 // taxon order.  Building those 524 267 Python tuples for 20 taxa costs seconds, encoding them 1.2 s, scoring them 21 ms:
 // here thread i un-ranks combination i of its class (combinatorial number system) and writes the taxon list itself.
+// Shards (multi-GPU, SURVEY 8e "index-mod-P within each class"): rank r of P enumerates the combinations r, r + P, ... of
+// every class; thread `local` writes combination local * P + r at position local.
 __global__ __launch_bounds__(256) void k_enumerate_splits(int n, int bal, int even, unsigned long long count,
                                                           const unsigned long long* __restrict__ binom,   // [33][33]
-                                                          int8_t* __restrict__ taxa_out, int* __restrict__ a_out) {
-    const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+                                                          int8_t* __restrict__ taxa_out, int* __restrict__ a_out,
+                                                          unsigned shard_rank, unsigned shard_world) {
+    const unsigned long long local = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long idx = local * shard_world + shard_rank;
     if (idx >= count) return;
     const int m = even ? n - 1 : n, r = even ? bal - 1 : bal, base = even ? 1 : 0;
     unsigned int member = even ? 1u : 0u;
@@ -618,14 +622,14 @@ __global__ __launch_bounds__(256) void k_enumerate_splits(int n, int bal, int ev
     }
     const unsigned int all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
     const unsigned int first = (member & 1u) ? member : (~member & all);   // the side that holds taxon 0
-    int8_t* out = taxa_out + idx * (unsigned long long)n;
+    int8_t* out = taxa_out + local * (unsigned long long)n;
     int pos = 0;
     for (int t = 0; t < n; ++t)
         if (first & (1u << t)) out[pos++] = (int8_t)t;
     const int a = pos;
     for (int t = 0; t < n; ++t)
         if (!(first & (1u << t))) out[pos++] = (int8_t)t;
-    a_out[idx] = a;
+    a_out[local] = a;
 }
 
 static unsigned long long binom_host(int nn, int kk) {
@@ -638,9 +642,12 @@ static unsigned long long binom_host(int nn, int kk) {
 // The splits all_splits yields, enumerated on the device into ctx->coords: taxa_out[total][n] (int8: the side holding
 // taxon 0, then the other side, both in taxon order) and a_out[total].  `enumerate` = false only counts.  sizes / counts:
 // the size classes in order and their populations.
-int enumerate_all_splits(sp_ctx* ctx, int n, int trivial, int size, bool enumerate, int64_t* total_out,
-                         const int8_t** dtaxa_out, const int** da_out, std::vector<int>& sizes,
+int enumerate_all_splits(sp_ctx* ctx, int n, int trivial, int size, bool enumerate, int shard_rank, int shard_world,
+                         int64_t* total_out, const int8_t** dtaxa_out, const int** da_out, std::vector<int>& sizes,
                          std::vector<unsigned long long>& counts) {
+    // (counts = this shard's share of every class: combinations shard_rank, shard_rank + shard_world, ...)
+    SP_REQUIRE(shard_world >= 1 && shard_rank >= 0 && shard_rank < shard_world, SP_EINVAL, "shard %d of %d", shard_rank,
+               shard_world);
     SP_REQUIRE(n >= 2 && n <= 31, SP_ELIMIT, "split enumeration supports 2..31 taxa (got %d)", n);
     SP_REQUIRE(size >= 0 && size <= n / 2, SP_EINVAL, "size %d out of range [0, %d]", size, n / 2);
     sizes.clear();
@@ -648,11 +655,15 @@ int enumerate_all_splits(sp_ctx* ctx, int n, int trivial, int size, bool enumera
     if (size > 0) sizes.push_back(size);
     else for (int b = trivial ? 1 : 2; b <= n / 2; ++b) sizes.push_back(b);
     int64_t total = 0;
+    std::vector<unsigned long long> full;
     for (int b : sizes) {
         const bool even = 2 * b == n;
         const unsigned long long c = even ? binom_host(n - 1, b - 1) : binom_host(n, b);
-        counts.push_back(c);
-        total += (int64_t)c;
+        full.push_back(c);
+        const unsigned long long mine = c > (unsigned long long)shard_rank
+                                            ? (c - shard_rank + shard_world - 1) / (unsigned long long)shard_world : 0ull;
+        counts.push_back(mine);
+        total += (int64_t)mine;
     }
     if (total_out) *total_out = total;
     if (!enumerate || total == 0) return SP_OK;
@@ -672,7 +683,8 @@ int enumerate_all_splits(sp_ctx* ctx, int n, int trivial, int size, bool enumera
         const int b = sizes[q];
         if (counts[q] == 0) continue;
         hipLaunchKernelGGL(k_enumerate_splits, dim3((unsigned)((counts[q] + 255) / 256)), dim3(256), 0, ctx->stream, n, b,
-                           2 * b == n ? 1 : 0, counts[q], ctx->misc2.as<unsigned long long>(), dtaxa + (size_t)off * n, da + off);
+                           2 * b == n ? 1 : 0, full[q], ctx->misc2.as<unsigned long long>(), dtaxa + (size_t)off * n, da + off,
+                           (unsigned)shard_rank, (unsigned)shard_world);
         off += (int64_t)counts[q];
     }
     SP_HIP(hipGetLastError());
@@ -682,14 +694,16 @@ int enumerate_all_splits(sp_ctx* ctx, int n, int trivial, int size, bool enumera
 }
 
 // Number of splits all_splits yields, and - when scores are asked for - their subflattening scores in that order.
-int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int64_t* n_out, bool score) {
+int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int shard_rank, int shard_world, int64_t* n_out,
+                           bool score) {
     sp_ctx* ctx = al->ctx;
     const int8_t* dtaxa = nullptr;
     const int* da = nullptr;
     std::vector<int> sizes;
     std::vector<unsigned long long> counts;
     int64_t total = 0;
-    SP_CHECK(enumerate_all_splits(ctx, al->n_taxa, trivial, size, score, &total, &dtaxa, &da, sizes, counts));
+    SP_CHECK(enumerate_all_splits(ctx, al->n_taxa, trivial, size, score, shard_rank, shard_world, &total, &dtaxa, &da, sizes,
+                                  counts));
     if (n_out) *n_out = total;
     if (!score || total == 0) return SP_OK;
     int kmax = 0;

@@ -131,3 +131,62 @@ def test_score_splits_distributed_path_gloo(tmp_path):
     mp.spawn(_worker_score_splits, args=(2, port, out), nprocs=2, join=True)
     res = np.load(out)
     assert res[0] == 1 and res[1] == 2 ** 5 - 6 - 1 and 0 < res[2] < res[1]
+
+
+def _worker_all_splits(rank, world, port, out_path):
+    """batch.score_all_splits(distributed=True): shard_layout + ONE all_gather + un-permute, device call stubbed."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from splitp_amd import batch
+
+    n = 9
+
+    class FakeAlignment:
+        n_taxa = n
+
+    ta, aa = batch.encode_all_splits(n)
+    shards, total = batch.shard_layout(n, world)
+    truth = 0.001 * np.arange(total) + 1.0            # the "score" of split i in all_splits order
+
+    def fake_shard(al, method_code, trivial, size, r, w, scores_dev_ptr=None, status_dev_ptr=None):
+        assert (r, w) == (rank, world)
+        idx, _ = batch.shard_layout(n, w, trivial=trivial, size=size)
+        return truth[idx[r]].copy(), ((idx[r] % 5).astype(np.int32) << 8)
+
+    batch.score_all_splits_shard = fake_shard
+    batch.as_device_alignment = lambda table, device=None: FakeAlignment()
+    got, st = batch.score_all_splits(FakeAlignment(), distributed=True, return_status=True)
+    ok = total == len(aa) and np.array_equal(got, truth) and np.array_equal(st >> 8, np.arange(total) % 5)
+    tchk = torch.tensor([float(ok)])
+    dist.all_reduce(tchk, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        np.save(out_path, np.array([int(tchk.item()), total, len(shards[0])], dtype=np.int64))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_score_all_splits_distributed_gloo(tmp_path):
+    out = str(tmp_path / "res3.npy")
+    port = _free_port()
+    mp.spawn(_worker_all_splits, args=(2, port, out), nprocs=2, join=True)
+    res = np.load(out)
+    assert res[0] == 1 and res[1] == 2 ** 8 - 9 - 1 and abs(2 * res[2] - res[1]) <= 4
+
+
+def test_shard_layout_is_a_partition_in_all_splits_order():
+    sys.path.insert(0, ROOT)
+    from splitp_amd import batch
+
+    for n in (4, 5, 8, 10, 11):
+        for kw in ({}, {"trivial": True}, {"size": 2}, {"size": n // 2}):
+            _, aa = batch.encode_all_splits(n, **kw)
+            for world in (1, 2, 3, 8):
+                shards, total = batch.shard_layout(n, world, **kw)
+                assert total == len(aa)
+                assert np.array_equal(np.sort(np.concatenate(shards)), np.arange(total))
+                k = np.minimum(aa, n - aa)
+                for kk in np.unique(k):            # every rank gets an equal share (+-1) of every size class
+                    share = [int(np.count_nonzero(k[s] == kk)) for s in shards]
+                    assert max(share) - min(share) <= 1, (n, kw, world, kk, share)

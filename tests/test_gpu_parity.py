@@ -1609,3 +1609,36 @@ def test_score_all_splits_flattening_planned_on_device(sp, golden):
     fa, fst = sp.score_all_splits(flat, size=3, return_status=True)
     fb = sp.score_splits(flat, list(sp.all_splits(names, size=3)))
     assert np.array_equal(fa, fb) and not np.any(fst & 2)
+
+
+def test_score_all_splits_shards(sp, golden):
+    """sp_score_all_splits_shard: rank r of P enumerates the combinations r, r + P, ... of every size class on the device;
+    the shards of P = 1, 2, 3 and 8 ranks, un-permuted with batch.shard_layout, reproduce the full call bit for bit -
+    subflattening (16 taxa) and the device-planned flattening route (10 taxa), scores and status into device buffers."""
+    import torch
+    from splitp_amd import batch, _lib
+
+    g = golden("n10_L100k")
+    names = taxa_names(10)
+    dev = sp.DeviceAlignment.from_table(O.unpack_table(g["keys"], g["probs"], 10), taxa=names)
+    g16 = golden("n16_L4k")
+    dev16 = sp.DeviceAlignment.from_table(O.unpack_table(g16["keys"], g16["probs"], 16), taxa=taxa_names(16))
+    for al, code in ((dev, _lib.SP_METHOD_FLATTENING), (dev16, _lib.SP_METHOD_SUBFLATTENING), (dev, _lib.SP_METHOD_SUBFLATTENING)):
+        full, st_full = batch.score_all_splits_shard(al, code, False, None, 0, 1)
+        for world in (2, 3, 8):
+            shards, total = batch.shard_layout(al.n_taxa, world)
+            assert total == len(full)
+            out = np.full(total, np.nan)
+            for r in range(world):
+                per = len(shards[r])
+                buf = torch.zeros(batch.packed_width(per), dtype=torch.float64, device="cuda")
+                n_loc = batch.score_all_splits_shard(al, code, False, None, r, world, scores_dev_ptr=buf.data_ptr(),
+                                                     status_dev_ptr=buf.data_ptr() + per * 8)
+                torch.cuda.synchronize()
+                host = buf.cpu().numpy()
+                assert n_loc == per and not np.any(host[per:].view(np.int32)[:per] & 3)
+                out[shards[r]] = host[:per]
+            assert np.array_equal(out, full), (code, world)
+    assert np.abs(batch.score_all_splits_shard(dev, _lib.SP_METHOD_FLATTENING, False, None, 0, 1)[0] - g["scores"]).max() <= SCORE_TOL
+    one_class, _ = batch.score_all_splits_shard(dev, _lib.SP_METHOD_FLATTENING, False, 4, 1, 3)
+    assert np.array_equal(one_class, sp.score_all_splits(dev, size=4)[1::3])
