@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 BRANCH = 0.05
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MFMA_PEAK_TF = 78.6     # AMD MI355X FP64 matrix peak; the local guide has no f64 row (77.7 measured)
+INT8_MFMA_PEAK_TOPS = 5033.0  # dense int8: 256 CUs x 4 SIMDs x 65536 ops per v_mfma_i32_32x32x32_i8 / 32 cycles x 2.4 GHz (guide: 2x the bf16 rate)
 N_CU = 256
 CLOCK_GHZ = 2.4              # MI355X_MICROARCH.md: max clock
 WORKLOADS = {
@@ -208,14 +209,43 @@ def roofline_block(dom, dom_ms_alone, dom_ms_region, in_flight, phases_per_step,
         except Exception:
             pmc = None
     if dom in ("gram", "eigen"):
-        # dense route: the executed work differs from SURVEY 8(d)'s fp64 count (compact upper-triangular problem, int8 limbs
-        # for the Gram, 16-wide block products for the eigen rounds), so no fraction of the fp64 peak is claimed for it
-        roof.update({"bound": "mfma", "achieved": survey["gram_phase"]["achieved"], "peak": FP64_MFMA_PEAK_TF,
-                     "unit": "TFLOP/s", "frac": None,
-                     "note": "achieved = SURVEY 8(d)'s algorithmic fp64 Gram flops / this phase's duration; the kernels execute "
-                             "other (less) work - see DESIGN.md section 4 for their own counters (k_gram_i8: 7 % MFMA busy)"})
-        if pmc:
-            roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+        # Dense route (the north-star pipeline).  Its longest single kernel is the int8-limb MFMA Gram, so `roofline` is
+        # that kernel on EXECUTED work: int8 operations one launch issues to the matrix cores (rocprofv3
+        # SQ_INSTS_VALU_MFMA_MOPS_I8 x 512, profiles/r02_pmc_dense_route.json - compact matrices, upper triangle, 2 x 2 limb
+        # products) / the Gram phase's duration measured live here, against the dense int8 peak; the scatter phase is
+        # reported the same way on the HBM bytes its two kernels move (PMC) against the HBM peak.
+        dpmc = {}
+        dpath = os.path.join(ROOT, "profiles", "r02_pmc_dense_route.json")
+        if os.path.exists(dpath):
+            try:
+                dpmc = json.load(open(dpath))
+            except Exception:
+                dpmc = {}
+        g = dpmc.get("gram") or {}
+        gram_s = phases_per_step.get("gram", 0.0) * 1e-3
+        ops = g.get("SQ_INSTS_VALU_MFMA_MOPS_I8", 0.0) * 512.0
+        roof.update({"kernel": "k_gram_i8_big<2,int> (int8-limb MFMA Gram, 128 x 128 tiles)",
+                     "launch_ms": phases_per_step.get("gram"), "bound": "mfma",
+                     "achieved": ops / gram_s / 1e12 if ops and gram_s else None, "peak": INT8_MFMA_PEAK_TOPS,
+                     "unit": "TOP/s (int8)",
+                     "frac": ops / gram_s / 1e12 / INT8_MFMA_PEAK_TOPS if ops and gram_s else None,
+                     "executed_int8_ops_per_launch": ops or None,
+                     "traffic": g.get("hbm_bytes_per_launch"),
+                     "note": "executed work, not SURVEY 8(d)'s fp64 count of the uncompacted problem (kept under survey_8d); "
+                             "peak = 256 CUs x 4 SIMDs x one v_mfma_i32_32x32x32_i8 (65536 ops) per 32 cycles x 2.4 GHz"})
+        if g.get("SQ_VALU_MFMA_BUSY_CYCLES") and g.get("kernel_cycles_from_GRBM_GUI_ACTIVE_div_8"):
+            roof["mfma_busy_frac_pmc"] = g["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * N_CU * g["kernel_cycles_from_GRBM_GUI_ACTIVE_div_8"])
+        zs = [dpmc.get("zero") or {}, dpmc.get("scatter") or {}]
+        sc_bytes = sum(z.get("hbm_bytes_per_launch", 0.0) for z in zs)
+        sc_s = phases_per_step.get("scatter", 0.0) * 1e-3
+        if sc_bytes and sc_s:
+            roof["scatter_phase"] = {"kernels": "k_zero_i8 + k_scatter_i8", "bound": "hbm", "ms": phases_per_step.get("scatter"),
+                                     "hbm_bytes_per_launch_pmc": sc_bytes, "achieved": sc_bytes / sc_s / 1e9,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sc_bytes / sc_s / 1e9 / HBM_PEAK_GBS}
+        roof["eigen_phase"] = {"ms": phases_per_step.get("eigen"),
+                               "note": "16-wide block iteration: G V products (k_eig_gv: G streamed from HBM once per "
+                                       "product) + per-split Rayleigh-Ritz (k_eig_rr: one wave's 16 x 16 Jacobi, latency-"
+                                       "bound); long and short sides as two concurrent pipelines"}
         return roof
     if dom == "sparse" and pmc:
         # What binds k_sparse_score is the LDS array and VALU issue, not HBM.  The binding

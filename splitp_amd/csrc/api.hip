@@ -127,6 +127,8 @@ extern "C" int sp_ctx_create(int device, void* stream, sp_ctx** out) {
     c->opt.big_by_keys = env_flag("SPLITP_BIG_BY_KEYS");
     c->opt.subscore_jacobi = env_flag("SPLITP_SUBSCORE_JACOBI");
     c->opt.divergence_global = env_flag("SPLITP_DIVERGENCE_GLOBAL");
+    c->opt.gram_tile64 = env_flag("SPLITP_GRAM_TILE64");
+    c->opt.eigen_one_stream = env_flag("SPLITP_EIGEN_ONE_STREAM");
     if (const char* hs = getenv("SPLITP_HIST_SORT")) c->opt.hist_sort = hs[0] == '1' ? 1 : (hs[0] == '0' ? 0 : -1);
     if (const char* lc = getenv("SPLITP_DEBUG_LDS_CAP")) c->opt.lds_cap = atoll(lc);
     *out = c;
@@ -142,6 +144,8 @@ static long long* option_slot(sp_ctx* c, const char* name, int** as_int) {
     else if (!strcmp(name, "divergence_global")) *as_int = &c->opt.divergence_global;
     else if (!strcmp(name, "hist_sort")) *as_int = &c->opt.hist_sort;
     else if (!strcmp(name, "wide_cap")) *as_int = &c->opt.wide_cap;
+    else if (!strcmp(name, "gram_tile64")) *as_int = &c->opt.gram_tile64;
+    else if (!strcmp(name, "eigen_one_stream")) *as_int = &c->opt.eigen_one_stream;
     else if (!strcmp(name, "lds_cap")) return &c->opt.lds_cap;
     return nullptr;
 }
@@ -189,6 +193,12 @@ extern "C" int sp_ctx_destroy(sp_ctx* c) {
     delete c->cache;
     for (auto* b : bufs) b->release();
     for (auto& b : c->big) b.release();
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+        (void)hipEventDestroy(c->ev_fork);
+        (void)hipEventDestroy(c->ev_join);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SP_OK;
@@ -435,10 +445,19 @@ static int plan_splits(int n, int64_t D, const int32_t* split_taxa, const int32_
     return SP_OK;
 }
 
+static GramItem* big_items_ptr(sp_ctx* ctx, const Plan& plan) {
+    return reinterpret_cast<GramItem*>(reinterpret_cast<int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
+                                                              plan.row_items.size()) + round_up(plan.order.size(), 2));
+}
+
 static int upload_items(sp_ctx* ctx, const Plan& plan) {
     if (plan.gram_items.empty()) return SP_OK;
     const size_t ng = plan.gram_items.size(), nr = plan.row_items.size(), no = plan.order.size();
-    SP_CHECK(ctx->gram_items.ensure((ng + nr) * sizeof(GramItem) + no * sizeof(int)));
+    const size_t nb = plan.gram_items_big.size();
+    SP_CHECK(ctx->gram_items.ensure((ng + nr + nb) * sizeof(GramItem) + round_up(no, 2) * sizeof(int)));
+    if (nb)   // layout: 64-tiles | row blocks | order (padded to 8 bytes) | 128-tiles
+        SP_HIP(hipMemcpyAsync(big_items_ptr(ctx, plan), plan.gram_items_big.data(), nb * sizeof(GramItem),
+                              hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(hipMemcpyAsync(ctx->gram_items.as<GramItem>() + ng + nr, plan.order.data(), no * sizeof(int),
                           hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(hipMemcpyAsync(ctx->gram_items.p, plan.gram_items.data(), ng * sizeof(GramItem), hipMemcpyHostToDevice,
@@ -613,8 +632,14 @@ static int run_dense_route(sp_alignment* al, const Plan& plan, bool plan_on_devi
                                         al->counts.as<u32>(), ctx->mats.as<uint8_t>()));
         // G entries are bounded by max_i sum_c C[i][c]^2 <= max_count * N: store int32 when that fits
         g_i32 = (unsigned long long)al->max_count * (unsigned long long)al->N < (1ull << 31);
-        SP_CHECK(launch_gram_i8(ctx, nl, g_i32, sdev, ctx->gram_items.as<GramItem>(), (int64_t)plan.gram_items.size(),
-                                dims, ctx->mats.as<uint8_t>(), ctx->grams.p));
+        int64_t kmax = 0;
+        for (const SplitDev& sd : plan.splits) kmax = std::max<int64_t>(kmax, sd.pitch);
+        if (kmax <= 65536 && !plan.gram_items_big.empty() && ctx->opt.gram_tile64 == 0)
+            SP_CHECK(launch_gram_i8_big(ctx, nl, g_i32, sdev, big_items_ptr(ctx, plan), (int64_t)plan.gram_items_big.size(),
+                                        dims, ctx->mats.as<uint8_t>(), ctx->grams.p));
+        else   // K beyond one int32 chunk (tables of > 65536 patterns): the 64 x 64 form flushes into int64 as it goes
+            SP_CHECK(launch_gram_i8(ctx, nl, g_i32, sdev, ctx->gram_items.as<GramItem>(), (int64_t)plan.gram_items.size(),
+                                    dims, ctx->mats.as<uint8_t>(), ctx->grams.p));
     } else if (al->exact) {
         SP_CHECK(ctx->mats.ensure(plan.mat_elems * 4));
         SP_CHECK(launch_zero_scatter<u32>(ctx, sdev, plan.splits, D, dims, rr_ptr(ctx), cc_ptr(ctx, S, D),
@@ -632,7 +657,7 @@ static int run_dense_route(sp_alignment* al, const Plan& plan, bool plan_on_devi
                           ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
                           reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
                                                        plan.row_items.size()),
-                          ctx->scores.as<double>(), ctx->status.as<int>()));
+                          ctx->scores.as<double>(), ctx->status.as<int>(), (int64_t)plan.n_row_a, (int64_t)plan.n_order_a));
     return SP_OK;
 }
 
@@ -1338,7 +1363,7 @@ extern "C" int sp_score_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, i
                           ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
                           reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
                                                        plan.row_items.size()),
-                          ctx->scores.as<double>(), ctx->status.as<int>()));
+                          ctx->scores.as<double>(), ctx->status.as<int>(), (int64_t)plan.n_row_a, (int64_t)plan.n_order_a));
     SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;
@@ -1430,7 +1455,7 @@ extern "C" int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* c
                           ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
                           reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
                                                        plan.row_items.size()),
-                          ctx->scores.as<double>(), ctx->status.as<int>()));
+                          ctx->scores.as<double>(), ctx->status.as<int>(), (int64_t)plan.n_row_a, (int64_t)plan.n_order_a));
     SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;

@@ -100,6 +100,8 @@ struct CtxOptions {
     int divergence_global = 0;  // global-memory form of the mutual-information score
     int hist_sort = -1;         // -1 auto, 0 direct bins, 1 sort + run-length encode
     int wide_cap = 0;           // half-product cap of the wide fallback block (0 = built-in 600)
+    int gram_tile64 = 0;        // int8 Gram of the dense route on the 64 x 64-tile kernel instead of 128 x 128
+    int eigen_one_stream = 0;   // dense route's eigen phase on the context's stream only (no side stream for the short sides)
     long long lds_cap = 0;      // pretend the LDS is this small (plain LDS form of the sparse kernel)
 };
 
@@ -132,6 +134,10 @@ struct sp_ctx {
     std::vector<AlDesc> aldescs_host;
     PlanCache* cache = nullptr;
     int n_cu = 256;
+    // dense route, eigen phase: the splits whose smaller side is short (<= EIG_SMALL_ROWS rows: a third of the LDS, three
+    // workgroups per CU) run as a pipeline of their own on this internal stream, next to the long sides on `stream`
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 struct sp_alignment {
@@ -190,7 +196,11 @@ struct Plan {
     std::vector<SplitDev> splits;
     std::vector<GramItem> gram_items;   // upper-triangle 64 x 64 tiles, heaviest splits first
     std::vector<GramItem> row_items;    // 64-row blocks (ti = block index) for the G V product
+    std::vector<GramItem> gram_items_big;   // upper-triangle 128 x 128 tiles (int8 Gram), longest K first
     std::vector<int> order;             // split ids, heaviest first (block -> split map of the per-split kernels)
+    // eigen phase classes: the first n_order_a entries of `order` / n_row_a entries of `row_items` belong to the splits
+    // with more than EIG_SMALL_ROWS allocated rows, the rest to the short sides (each part XCD-interleaved by itself)
+    size_t n_order_a = 0, n_row_a = 0;
     size_t bm_words = 0, pf_words = 0, mat_elems = 0, g_elems = 0, ev_elems = 0;
 };
 
@@ -227,6 +237,7 @@ struct PhaseScope {
     ~PhaseScope();
 };
 
+#define EIG_SMALL_ROWS 256   // eigen phase: sides up to this many rows form the class that runs three workgroups per CU
 #define EIG_MAXR 1024   // rows of the smaller side the dense route's eigen kernels hold in LDS (eig_small.h: 8 waves x 8 tiles x 16)
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int64_t pow4(int k) { return (int64_t)1 << (2 * k); }
@@ -249,6 +260,8 @@ int launch_zero_scatter_i8(sp_ctx* ctx, int nl, const SplitDev* splits_dev, cons
                            int64_t D, const int2* dims, const u32* rr, const u32* cc, const u32* vals, uint8_t* mats);
 int launch_gram_i8(sp_ctx* ctx, int nl, bool g_i32, const SplitDev* splits_dev, const GramItem* items_dev,
                    int64_t n_items, const int2* dims, const uint8_t* mats, void* grams);
+int launch_gram_i8_big(sp_ctx* ctx, int nl, bool g_i32, const SplitDev* splits_dev, const GramItem* items_dev,
+                       int64_t n_items, const int2* dims, const uint8_t* mats, void* grams);
 int launch_divergence(sp_ctx* ctx, bool exact, int64_t D, int64_t S, const u32* rr, const u32* cc, const u32* counts,
                       const double* weights, double n_total, unsigned long long* marg, double* out);
 int launch_divergence_matrix(sp_ctx* ctx, const double* m_dev, int64_t rows, int64_t cols, double* scratch, double* out);
@@ -269,4 +282,4 @@ int launch_gram(sp_ctx* ctx, const SplitDev* splits_dev, const GramItem* items_d
 void build_gram_items(Plan& plan);
 int launch_eigen(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits, const int2* dims,
                  const void* grams, bool g_i32, const GramItem* rowblocks_dev, int64_t n_rowblocks,
-                 const int* order_dev, double* scores, int* status);
+                 const int* order_dev, double* scores, int* status, int64_t n_rowblocks_a = -1, int64_t n_splits_a = -1);

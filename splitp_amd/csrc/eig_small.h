@@ -6,6 +6,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef EIG_STAMP
+#define EIG_STAMP(i)   // cycle stamps of the diagnostic build (eigen.hip, -DEIG_STAMPS)
+#endif
+
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 #define EIG_THREADS 512
@@ -21,6 +25,7 @@ struct EigShared {
     double G1[EIG_B * EIG_VP];  // V^T G V of the current block (first power of G: the values the score is taken from)
     double T[EIG_B * EIG_VP];   // L^-T (upper triangular), dead columns zeroed
     double top4;
+    double sum_all, theta4;   // ritz_orth_nb: sum of all NB Ritz values and the 4th largest (certified stop of the dense route)
     double part[(EIG_WAVES / 2) * 256];  // cross-wave reduction buffer (two waves share a slot)
     double red[EIG_WAVES];
     double theta[EIG_B];
@@ -118,26 +123,31 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // Jacobi rotation (c, s) for the symmetric 2 x 2 [app apq; apq aqq].  The angle is evaluated in f32
 // (cheap), c = rsqrt(1 + t^2) and s = t c in fp64, so the rotation is orthogonal to fp64 accuracy for
 // ANY t - an inexact angle only leaves a residual ~1e-7 |apq| that the next sweep removes.
+// One wave runs the whole Jacobi with nothing to overlap its latencies, so this is a dependent chain that is paid
+// 15 times a sweep: tau comes from the hardware fp64 reciprocal (the quotient of two fp64 numbers needs no scaling
+// into the f32 range first - the round-1 form spent most of its time in ilogb / scalbn), the f32 part uses the
+// hardware reciprocal and square root.
+// (branch-free: a lane needs two rotations per round and the compiler interleaves the two dependent chains only when
+// they are straight-line code; with the `if`s of the round-1 form they ran one after the other)
 __device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, double& c, double& s) {
-    c = 1.0;
-    s = 0.0;
-    if (apq * apq > 1e-40 * fabs(app * aqq) && apq != 0.0) {
-        // (both operands brought to O(1) by an exact power of two first: the entries of nearly dead directions - 1e-45 on
-        // a probability-scaled table - are below the f32 range and gave 0 / 0 = nan, found by the randomised tests)
-        const double d = aqq - app;
-        const int ex = -ilogb(fmax(fabs(d), fabs(apq)));
-        const float num = (float)scalbn(d, ex), den = 2.0f * (float)scalbn(apq, ex);
-        float tf;
-        if (fabsf(num) > 1e18f * fabsf(den)) {
-            tf = den / (2.0f * num);  // tiny angle; avoids inf / nan in the f32 quotient
-        } else {
-            const float tau = num / den;
-            tf = (tau >= 0.f ? 1.0f : -1.0f) / (fabsf(tau) + sqrtf(1.0f + tau * tau));
-        }
-        const double t = (double)tf;
-        c = rsqrt_nr(1.0 + t * t);
-        s = t * c;
-    }
+    // A coupling below 1e-15 of its two diagonal entries is rounding noise and moves no eigenvalue (second order: 1e-30),
+    // but between two (nearly) EQUAL diagonal entries it would be 'removed' by a 45 degree rotation: the orthonormalised
+    // strong columns of ritz_orth_nb's second pass (Gram block = I + noise) were scrambled that way every round, the
+    // next round's projected matrix was full again and its Jacobi needed 6 sweeps instead of starting near-diagonal.
+    const bool rot = apq * apq > 1e-30 * fabs(app * aqq) && apq != 0.0;
+    const double d = aqq - app;
+    const double tau = d * __builtin_amdgcn_rcp(2.0 * apq);
+    // general angle in f32 (|tau| <= 1e18 keeps tau^2 inside the f32 range; an inf / nan tau takes the other form)
+    const float tf = (float)tau;
+    const float r = __builtin_amdgcn_rcpf(fabsf(tf) + __builtin_amdgcn_sqrtf(1.0f + tf * tf));
+    const double t_gen = (double)copysignf(r, tf);
+    // tiny angle t = 1 / (2 tau) = apq / d; apq so small that its reciprocal is inf, or d = 0 next to it: no rotation
+    double t_tiny = apq * __builtin_amdgcn_rcp(d);
+    t_tiny = fabs(t_tiny) <= 1e-17 ? t_tiny : 0.0;
+    double t = fabs(tau) <= 1e18 ? t_gen : t_tiny;
+    t = rot ? t : 0.0;
+    c = rsqrt_nr(1.0 + t * t);   // exactly 1 for t = 0
+    s = t * c;
 }
 
 // Eigen-decomposition of the symmetric positive semi-definite 16 x 16 matrix sh.H by parallel-order
@@ -156,9 +166,13 @@ __device__ __forceinline__ void jacobi_nb(EigShared& sh) {
         const int pa = act ? lane / NP : 0, pb = act ? lane % NP : 0;
         for (int e = lane; e < EIG_B * EIG_B; e += 64) sh.Q[(e >> 4) * EIG_VP + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
         wave_sync_lds();
+#pragma unroll 1
         for (int sweep = 0; sweep < 15; ++sweep) {
-            double rel = 0, dmx = 0;
-            for (int k = 0; k < NB; ++k) dmx = fmax(dmx, fabs(sh.H[k * EIG_VP + k]));
+            double dmx = lane < NB ? fabs(sh.H[lane * EIG_VP + lane]) : 0.0;
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) dmx = fmax(dmx, __shfl_xor(dmx, d, 64));
+            dmx = __shfl(dmx, 0, 64);
+            bool open = false;   // some coupling is still above 1e-11 of its two diagonal entries (v^2 > 1e-22 h_ii h_jj)
             for (int e = lane; e < EIG_B * EIG_B; e += 64) {
                 const int i = e >> 4, j = e & 15;
                 if (i < j && j < NB) {
@@ -166,19 +180,47 @@ __device__ __forceinline__ void jacobi_nb(EigShared& sh) {
                     const double dd = fabs(sh.H[i * EIG_VP + i] * sh.H[j * EIG_VP + j]);
                     // couplings below 1e-20 of the largest eigenvalue cannot matter (directions that small are
                     // noise or dead) and would otherwise keep the sweeps going on rounding residue
-                    if (v * v > 1e-40 * dmx * dmx) rel = fmax(rel, dd > 0 ? v * v / dd : 1.0);
+                    open = open || (v * v > 1e-40 * dmx * dmx && !(v * v <= 1e-22 * dd));
                 }
             }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) rel = fmax(rel, __shfl_xor(rel, d, 64));
+            const double rel = __builtin_amdgcn_ballot_w64(open) != 0ull ? 1.0 : 0.0;
+#ifdef EIG_STAMPS
+            if (blockIdx.x == 0 && g_eig_stamp_on && g_eig_stamps[39] == 0 && sweep < 10) {
+                double mx = 0; int nopen = 0;
+                for (int e = lane; e < EIG_B * EIG_B; e += 64) {
+                    const int i = e >> 4, j = e & 15;
+                    if (i < j && j < NB) {
+                        const double v = sh.H[i * EIG_VP + j];
+                        const double dd = fabs(sh.H[i * EIG_VP + i] * sh.H[j * EIG_VP + j]);
+                        mx = fmax(mx, fabs(v) / dmx);
+                        nopen += (v * v > 1e-40 * dmx * dmx && !(v * v <= 1e-22 * dd)) ? 1 : 0;
+                    }
+                }
+                for (int d = 32; d >= 1; d >>= 1) { mx = fmax(mx, __shfl_xor(mx, d, 64)); nopen += __shfl_xor(nopen, d, 64); }
+                if (lane == 0) g_eig_stamps[24 + sweep] = (long long)(-log10(mx + 1e-300) * 10) * 1000 + nopen;
+                if (lane < 16 && sweep == 0) g_eig_stamps[56 + (lane & 7)] = 0;
+            }
+#endif
+#ifdef EIG_STAMPS
+            if (lane == 0 && blockIdx.x == 0 && g_eig_stamp_on) {
+                const int slot = g_eig_stamps[39] < 8 ? (int)g_eig_stamps[39] : 7;   // [39] = Jacobi calls so far
+                g_eig_stamps[40 + slot] = sweep;
+                g_eig_stamps[48 + slot] = (long long)(rel * 1e30 < 9e18 ? rel * 1e30 : 9e18);
+            }
+#endif
             if (!(rel > 1e-22)) break;
+#ifndef EIG_JACOBI_UNROLL
+#pragma unroll 1
+#endif
             for (int round = 0; round < NB - 1; ++round) {
                 int ip, iq, jp, jq;  // rows of pair a, cols of pair b
-                if (pa == 0) { ip = NB - 1; iq = round; }
-                else { ip = (round + pa) % (NB - 1); iq = (round + (NB - 1) - pa) % (NB - 1); }
+                // (round + pa and round + NB - 1 - pa are below 2 (NB - 1): one conditional subtraction, no division)
+                const int a1 = round + pa, a2 = round + (NB - 1) - pa, b1 = round + pb, b2 = round + (NB - 1) - pb;
+                ip = pa == 0 ? NB - 1 : (a1 >= NB - 1 ? a1 - (NB - 1) : a1);
+                iq = pa == 0 ? round : (a2 >= NB - 1 ? a2 - (NB - 1) : a2);
                 if (ip > iq) { const int t = ip; ip = iq; iq = t; }
-                if (pb == 0) { jp = NB - 1; jq = round; }
-                else { jp = (round + pb) % (NB - 1); jq = (round + (NB - 1) - pb) % (NB - 1); }
+                jp = pb == 0 ? NB - 1 : (b1 >= NB - 1 ? b1 - (NB - 1) : b1);
+                jq = pb == 0 ? round : (b2 >= NB - 1 ? b2 - (NB - 1) : b2);
                 if (jp > jq) { const int t = jp; jp = jq; jq = t; }
                 const double hpp = sh.H[ip * EIG_VP + jp], hpq = sh.H[ip * EIG_VP + jq];
                 const double hqp = sh.H[iq * EIG_VP + jp], hqq = sh.H[iq * EIG_VP + jq];
@@ -209,6 +251,9 @@ __device__ __forceinline__ void jacobi_nb(EigShared& sh) {
             }
         }
         if (lane < EIG_B) sh.theta[lane] = lane < NB ? sh.H[lane * EIG_VP + lane] : 0.0;
+#ifdef EIG_STAMPS
+        if (lane == 0 && blockIdx.x == 0 && g_eig_stamp_on) g_eig_stamps[39] += 1;
+#endif
     }
     __syncthreads();
 }
@@ -223,9 +268,18 @@ __device__ __forceinline__ void jacobi_nb(EigShared& sh) {
 // (zero columns: exactly singular input, or R < 16).  No Cholesky, no serial 16-step chains, and no
 // data-dependent fallback path.  When `values_only` the block is left untouched after the Jacobi.
 template <int NB, int VP>
+__device__ __forceinline__ void polish_nb(double* X, int Rp, EigShared& sh);
+
+template <int NB, int VP>
 __device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh) {
     gram_nb<NB, VP>(X, Rp, sh, sh.H);
+    EIG_STAMP(10);
+#ifdef EIG_STAMPS
+    if (blockIdx.x == 0 && g_eig_stamp_on && threadIdx.x < 256) g_eig_dump[threadIdx.x] = sh.H[(threadIdx.x >> 4) * EIG_VP + (threadIdx.x & 15)];
+    __syncthreads();
+#endif
     jacobi_nb<NB>(sh);
+    EIG_STAMP(11);
     bool weak;
     // top-4 sum + T = P D^-1/2 (256 threads)
     {
@@ -241,9 +295,19 @@ __device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh) {
                 rank += (o > th || (o == th && j < lane)) ? 1 : 0;
             }
             double pick = (lane < EIG_B && rank < 4) ? th : 0.0;
+            double all = lane < EIG_B ? fmax(th, 0.0) : 0.0;
+            double fourth = (lane < EIG_B && rank == 3) ? th : 0.0;
 #pragma unroll
-            for (int d = 8; d >= 1; d >>= 1) pick += __shfl_xor(pick, d, 64);
-            if (lane == 0) sh.top4 = pick;
+            for (int d = 8; d >= 1; d >>= 1) {
+                pick += __shfl_xor(pick, d, 64);
+                all += __shfl_xor(all, d, 64);
+                fourth += __shfl_xor(fourth, d, 64);
+            }
+            if (lane == 0) {
+                sh.top4 = pick;
+                sh.sum_all = all;
+                sh.theta4 = fourth;
+            }
         }
         // S = Y^T Y carries absolute rounding errors of ~1e-16 dmax, so an eigenvalue below ~3e-15 dmax is noise, and
         // normalising a column by the square root of noise made X^T X explode in the polish below (nan scores on a
@@ -267,6 +331,7 @@ __device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh) {
         __syncthreads();
     }
     rowmul_nb<NB, VP>(X, Rp, sh.T);
+    EIG_STAMP(12);
     if (weak) {
         gram_nb<NB, VP>(X, Rp, sh, sh.H);
         jacobi_nb<NB>(sh);
@@ -279,6 +344,15 @@ __device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh) {
         __syncthreads();
         rowmul_nb<NB, VP>(X, Rp, sh.T);
     }
+    polish_nb<NB, VP>(X, Rp, sh);
+    EIG_STAMP(23);
+}
+
+// Newton-Schulz polish of a nearly orthonormal R x NB block in LDS: X <- X (1.5 I - 0.5 X^T X) until
+// ||X^T X - I||_max <= 2e-15 (columns whose squared norm is below 0.25 are dead and stay as they are).  Converges
+// quadratically from any block with ||X^T X - I||_2 < 1.  Ends with a barrier.
+template <int NB, int VP>
+__device__ __forceinline__ void polish_nb(double* X, int Rp, EigShared& sh) {
     for (int iter = 0; iter < 10; ++iter) {
         gram_nb<NB, VP>(X, Rp, sh, sh.H);
         double err = 0;
@@ -297,9 +371,26 @@ __device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh) {
         double emx = 0;
         for (int k = 0; k < EIG_WAVES; ++k) emx = fmax(emx, sh.red[k]);
         __syncthreads();
+        EIG_STAMP(13 + iter);
         if (emx <= 2e-15) break;
         rowmul_nb<NB, VP>(X, Rp, sh.T);
     }
+}
+
+// Orthonormalise a block whose columns are already close to orthogonal (the start block: unit vectors + 2 % noise):
+// columns scaled to unit length, then the polish.  No eigen-decomposition - the span is what matters to the iteration,
+// and a 16 x 16 Jacobi from a full matrix is 9 sweeps of one wave (~190 k cycles, the bulk of k_eig_init in round 1).
+template <int NB, int VP>
+__device__ __forceinline__ void orth_near_nb(double* X, int Rp, EigShared& sh) {
+    gram_nb<NB, VP>(X, Rp, sh, sh.H);
+    if (threadIdx.x < 256) {
+        const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+        const double dj = sh.H[j * EIG_VP + j];
+        sh.T[i * EIG_VP + j] = (i == j && i < NB && dj > 0) ? rsqrt_nr(dj) : 0.0;
+    }
+    __syncthreads();
+    rowmul_nb<NB, VP>(X, Rp, sh.T);
+    polish_nb<NB, VP>(X, Rp, sh);
 }
 
 // First-power Rayleigh-Ritz for the final score.  The iteration itself works on G^2 (ritz_orth_nb): its Ritz values
@@ -314,10 +405,19 @@ __device__ __forceinline__ void proj_first_power(const double* Y, int Rp, const 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int fr = lane & 15, fk = lane >> 4;
     double4_t acc = {0, 0, 0, 0};
-    for (int r0 = w * 4; r0 < Rp; r0 += EIG_WAVES * 4) {
-        const double a = Vt[(int64_t)fr * vp + r0 + fk];
-        const double b = Y[(r0 + fk) * VP + fr];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    // 16 rows a step: a lane loads 4 consecutive entries of its V^T row (32 B; the 4 lanes of a row read one 128-B
+    // segment) and issues 4 MFMAs, MFMA j summing the rows {r0 + 4 g + j : g = 0..3} - the access rule of k_eig_gv.
+    // (One 8-byte load per MFMA, 16 rows x 4 scattered doubles per wave-instruction, cost 24 k cycles on a 1024-row side.)
+    typedef double f64x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll 4
+    for (int r0 = w * 16; r0 < Rp; r0 += EIG_WAVES * 16) {
+        const double* __restrict__ p = Vt + (int64_t)fr * vp + r0 + 4 * fk;
+        const f64x2_t v01 = *reinterpret_cast<const f64x2_t*>(p), v23 = *reinterpret_cast<const f64x2_t*>(p + 2);
+        const double* y = Y + (r0 + 4 * fk) * VP + fr;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v01.x, y[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v01.y, y[VP], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v23.x, y[2 * VP], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v23.y, y[3 * VP], acc, 0, 0, 0);
     }
     reduce16(acc, sh, sh.G1);
 }
@@ -392,6 +492,22 @@ __device__ __forceinline__ bool update_convergence(double s4, int it, double& pr
     prev_delta = delta;
     prev_sum = s4;
     return conv;
+}
+
+// Certified stop (round 2; the sparse route's rule (c), DESIGN 3a, carried over to the 16-wide block).  Everything outside
+// the block weighs rest = trace - (sum of all 16 Ritz values) >= lambda_17, the 4th Ritz value theta_4 <= lambda_4, so no
+// component of the top-4 sum's error decays slower than q = (rest / theta_4)^2 per product (Ritz values are second order
+// in the angle) and what is still missing after a step of size delta is at most delta q / (1 - q).  Phylogenetic
+// flattenings have rest / theta_4 ~ 1e-3: the bound certifies the sum after the 3rd product, where the two-ratio rule of
+// update_convergence cannot speak before the 4th - one G V product and one Rayleigh-Ritz round less for every split.
+__device__ __forceinline__ bool certified_stop(double s4, double delta, int it, double trace, const EigShared& sh) {
+    if (it < 3) return false;
+    const double rest = trace - sh.sum_all;
+    if (!(rest >= 0.0) || !(sh.theta4 > 0.0)) return false;
+    const double rho = rest / sh.theta4;
+    if (!(rho < 0.25)) return false;
+    const double q = rho * rho;
+    return delta * q / (1.0 - q) <= 1e-15 * s4;
 }
 
 // Final acceptance, shared by k_eig_rr and k_eig_finish (uniform).  `g2_conv`: the G^2 sums have settled this round.

@@ -24,22 +24,26 @@
 // inside one workgroup, capped at EIG_MAXIT (status bit 0).
 #include "common.h"
 
-#include "eig_small.h"
-
 #ifdef EIG_STAMPS
 __device__ long long g_eig_stamps[64];
+__device__ int g_eig_stamp_on;   // set by the kernel under the stamps
+__device__ double g_eig_dump[256];   // projected matrix of workgroup 0 in the stamped round
 #define STAMP(i)                                                                         \
     do {                                                                                 \
         __syncthreads();                                                                 \
-        if (threadIdx.x == 0 && blockIdx.x == 0) g_eig_stamps[i] = __builtin_amdgcn_s_memtime(); \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && g_eig_stamp_on) g_eig_stamps[i] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#define EIG_STAMP(i) STAMP(i)
 #else
 #define STAMP(i)
 #endif
 
+#include "eig_small.h"
+
 #define gram16 gram_nb<16, EIG_VP>
 #define rowmul16 rowmul_nb<16, EIG_VP>
 #define ritz_orth16 ritz_orth_nb<16, EIG_VP>
+#define orth_near16 orth_near_nb<16, EIG_VP>
 
 // ---- per split: trace, degenerate cases, start block -------------------------------------------------
 template <typename GT>
@@ -104,17 +108,20 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_init(const SplitDev* __rest
         V[row * EIG_VP + col] = row < R ? 0.02 * hash_unit(row, col) : 0.0;
     }
     __syncthreads();
+    // (no early exit on rank >= EIG_B: with the data-dependent exit every iteration waited for its own LDS read, 2048
+    // dependent reads per thread on a 1024-row side = 85 us of k_eig_init; as a plain counted loop the reads pipeline)
     for (int i = threadIdx.x; i < R; i += EIG_THREADS) {
         const double di = dg[i];
         int rank = 0;
-        for (int j = 0; j < R && rank < EIG_B; ++j) {
+#pragma unroll 8
+        for (int j = 0; j < Rp; ++j) {      // (padding entries are -1: never ahead of a diagonal entry of a PSD matrix)
             const double dj = dg[j];
             rank += (dj > di || (dj == di && j < i)) ? 1 : 0;
         }
         if (rank < EIG_B) V[i * EIG_VP + rank] += 1.0;
     }
     __syncthreads();
-    ritz_orth16(V, Rp, sh);  // here only as an orthonormaliser (the start block is not G times anything)
+    orth_near16(V, Rp, sh);  // unit columns + Newton-Schulz polish (the start block is nearly orthogonal as it stands)
     store_vt(V, Rp, vt_pool + sp.ev_off, sp.rcap);
     if (threadIdx.x == 0) states[sid] = st;
 }
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void k_eig_gv(const GramItem* __restrict__ ite
     const GT* __restrict__ g = grams + sp.g_off + (int64_t)(row0 + fr) * sp.g_pitch + 4 * fk;
     const double* __restrict__ v = vt_pool + sp.ev_off + (int64_t)fr * sp.rcap + 4 * fk;
     double4_t acc = {0, 0, 0, 0};
-#pragma unroll 4
+#pragma unroll 8
     for (int k0 = 0; k0 < Rp; k0 += 16) {
         double a[4];
         G4<GT>::load(g + k0, a);
@@ -195,20 +202,31 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_rr(const SplitDev* __restri
     double* __restrict__ Vt = vt_pool + sp.ev_off;
     const double* __restrict__ Y = y_pool + sp.ev_off;
     const int vp = sp.rcap;
+#ifdef EIG_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        g_eig_stamp_on = (st.it == EIG_STAMP_ROUND);
+        if (g_eig_stamp_on) g_eig_stamps[39] = 0;
+    }
+    __syncthreads();
+#endif
     STAMP(0);
     // Y -> LDS working block
+#pragma unroll 8
     for (int e = threadIdx.x; e < Rp * EIG_B; e += EIG_THREADS) V[(e >> 4) * EIG_VP + (e & 15)] = Y[e];
     __syncthreads();
     STAMP(1);
     proj_first_power<EIG_VP>(V, Rp, Vt, vp, sh);  // G1 = V^T G V on the block that produced Y (kept for the final score)
+    STAMP(4);
     ritz_orth16(V, Rp, sh);  // Ritz values (sh.top4) + next orthonormal block in one pass
     STAMP(2);
     st.it += 1;
     st.top4 = sh.top4;
     const double g2_sum = sh.top4;
-    const bool g2_conv = update_convergence(g2_sum, st.it, st.prev_sum, st.prev_delta, st.prev_ratio);
+    bool g2_conv = update_convergence(g2_sum, st.it, st.prev_sum, st.prev_delta, st.prev_ratio);
+    g2_conv = g2_conv || certified_stop(g2_sum, st.prev_delta, st.it, st.trace, sh);
     // (the score comes from the first-power Ritz values of the same subspace; sets st.top4)
     if (accept_first_power(g2_conv, g2_sum, st, sh)) {
+        STAMP(5);
         if (threadIdx.x == 0) {
             st.done = 1;
             states[sid] = st;
@@ -291,7 +309,8 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_finish(const SplitDev* __re
         st.top4 = sh.top4;
         ran = 1;
         const double g2_sum = sh.top4;
-        const bool g2_conv = update_convergence(g2_sum, st.it, st.prev_sum, st.prev_delta, st.prev_ratio);
+        bool g2_conv = update_convergence(g2_sum, st.it, st.prev_sum, st.prev_delta, st.prev_ratio);
+        g2_conv = g2_conv || certified_stop(g2_sum, st.prev_delta, st.it, st.trace, sh);
         if (accept_first_power(g2_conv, g2_sum, st, sh)) {
             converged = 1;
             break;
@@ -311,7 +330,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_finish(const SplitDev* __re
 template <typename GT>
 static int launch_eigen_t(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits,
                           const int2* dims, const GT* grams, const GramItem* rowblocks_dev, int64_t n_rowblocks,
-                          const int* order_dev, double* scores, int* status) {
+                          const int* order_dev, double* scores, int* status, int64_t n_rowblocks_a, int64_t n_splits_a) {
     int maxr = 0;
     size_t ev_elems = 0;
     for (const auto& s : splits) {
@@ -328,7 +347,8 @@ static int launch_eigen_t(sp_ctx* ctx, const SplitDev* splits_dev, const std::ve
     double* vt = reinterpret_cast<double*>(ctx->eigws.as<unsigned char>() + st_bytes);
     double* yp = vt + ev_elems;
     PhaseScope ps(ctx, SP_PHASE_EIGEN);
-    const size_t lds = ((sizeof(EigShared) + 15) & ~(size_t)15) + (size_t)maxr * EIG_VP * sizeof(double);
+    const size_t lds_head = (sizeof(EigShared) + 15) & ~(size_t)15;
+    const size_t lds = lds_head + (size_t)maxr * EIG_VP * sizeof(double);
     static size_t attr = 0;
     if (lds > attr) {
         SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eig_init<GT>),
@@ -339,32 +359,64 @@ static int launch_eigen_t(sp_ctx* ctx, const SplitDev* splits_dev, const std::ve
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = lds;
     }
-    hipLaunchKernelGGL(k_eig_init<GT>, dim3((unsigned)S), dim3(EIG_THREADS), lds, ctx->stream, splits_dev, dims, grams,
-                       states, vt, scores, status, order_dev);
-    for (int round = 0; round < EIG_NFAST; ++round) {
-        hipLaunchKernelGGL(k_eig_gv<GT>, dim3((unsigned)n_rowblocks), dim3(256), 0, ctx->stream, rowblocks_dev,
-                           splits_dev, dims, grams, states, vt, yp);
-        hipLaunchKernelGGL(k_eig_rr, dim3((unsigned)S), dim3(EIG_THREADS), lds, ctx->stream, splits_dev, dims, states,
-                           vt, yp, scores, status, order_dev);
+    // One pipeline = init, EIG_NFAST x (G V product over all row blocks, per-split Rayleigh-Ritz), finisher.  Every kernel
+    // touches only the states / blocks / scores of its own splits, so two disjoint sets of splits are two independent
+    // pipelines.
+    auto pipeline = [&](hipStream_t stream, const int* order, size_t n_s, const GramItem* rowblocks, int64_t n_rb,
+                        size_t lds_bytes) {
+        if (n_s == 0) return;
+        hipLaunchKernelGGL(k_eig_init<GT>, dim3((unsigned)n_s), dim3(EIG_THREADS), lds_bytes, stream, splits_dev, dims,
+                           grams, states, vt, scores, status, order);
+        for (int round = 0; round < EIG_NFAST; ++round) {
+            hipLaunchKernelGGL(k_eig_gv<GT>, dim3((unsigned)n_rb), dim3(256), 0, stream, rowblocks, splits_dev, dims, grams,
+                               states, vt, yp);
+            hipLaunchKernelGGL(k_eig_rr, dim3((unsigned)n_s), dim3(EIG_THREADS), lds_bytes, stream, splits_dev, dims, states,
+                               vt, yp, scores, status, order);
+        }
+        hipLaunchKernelGGL(k_eig_finish<GT>, dim3((unsigned)n_s), dim3(EIG_THREADS), lds_bytes, stream, splits_dev, grams,
+                           states, vt, scores, status, order);
+    };
+    // The per-split work is one wave's 16 x 16 Jacobi whatever the size of the side, and a workgroup sized for a
+    // 1024-row side (139 KB of LDS) owns its CU: 501 splits were two rounds of workgroups per kernel.  The short sides
+    // (<= EIG_SMALL_ROWS rows: 48 KB, three workgroups per CU) therefore run as a pipeline of their own on the context's
+    // side stream, concurrently with the long sides: one fork after the Gram kernel, one join before the scores are read.
+    const bool two = n_splits_a > 0 && (size_t)n_splits_a < S && n_rowblocks_a >= 0 && ctx->opt.eigen_one_stream == 0;
+    if (two && !ctx->side) {
+        SP_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        SP_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        SP_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     }
-    hipLaunchKernelGGL(k_eig_finish<GT>, dim3((unsigned)S), dim3(EIG_THREADS), lds, ctx->stream, splits_dev, grams,
-                       states, vt, scores, status, order_dev);
+    if (two) {
+        const size_t lds_small = lds_head + (size_t)EIG_SMALL_ROWS * EIG_VP * sizeof(double);
+        SP_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        SP_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        pipeline(ctx->stream, order_dev, (size_t)n_splits_a, rowblocks_dev, n_rowblocks_a, lds);
+        pipeline(ctx->side, order_dev + n_splits_a, S - (size_t)n_splits_a, rowblocks_dev + n_rowblocks_a,
+                 n_rowblocks - n_rowblocks_a, lds_small);
+        SP_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+        SP_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    } else {
+        pipeline(ctx->stream, order_dev, S, rowblocks_dev, n_rowblocks, lds);
+    }
     SP_HIP(hipGetLastError());
     return SP_OK;
 }
 
 int launch_eigen(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits, const int2* dims,
                  const void* grams, bool g_i32, const GramItem* rowblocks_dev, int64_t n_rowblocks,
-                 const int* order_dev, double* scores, int* status) {
+                 const int* order_dev, double* scores, int* status, int64_t n_rowblocks_a, int64_t n_splits_a) {
     if (splits.empty()) return SP_OK;
     if (g_i32)
         return launch_eigen_t<int>(ctx, splits_dev, splits, dims, (const int*)grams, rowblocks_dev, n_rowblocks,
-                                   order_dev, scores, status);
+                                   order_dev, scores, status, n_rowblocks_a, n_splits_a);
     return launch_eigen_t<double>(ctx, splits_dev, splits, dims, (const double*)grams, rowblocks_dev, n_rowblocks,
-                                  order_dev, scores, status);
+                                  order_dev, scores, status, n_rowblocks_a, n_splits_a);
 }
 
 #ifdef EIG_STAMPS
+extern "C" int sp_debug_eig_dump(double* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eig_dump), sizeof(double) * 256) == hipSuccess ? 0 : 2;
+}
 extern "C" int sp_debug_eig_stamps(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eig_stamps), sizeof(long long) * 64) == hipSuccess ? 0 : 2;
 }

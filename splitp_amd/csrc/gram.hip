@@ -16,6 +16,9 @@
 #include "common.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+// staging registers as native vectors (arrays of HIP's double2 / uint4 structs are memcpy'd and can end up in scratch)
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
 
 #define G_TILE 64
 #define G_KS 32
@@ -25,11 +28,11 @@ template <typename T>
 struct PanelRegs;
 template <>
 struct PanelRegs<u32> {
-    uint4 v[2];  // 64 rows x 8 uint4 per panel = 512 vectors / 256 threads
+    u32x4g v[2];  // 64 rows x 8 uint4 per panel = 512 vectors / 256 threads
 };
 template <>
 struct PanelRegs<double> {
-    double2 v[4];  // 64 rows x 16 double2 = 1024 vectors / 256 threads
+    f64x2 v[4];  // 64 rows x 16 double2 = 1024 vectors / 256 threads
 };
 
 __device__ __forceinline__ void panel_load(PanelRegs<u32>& r, const u32* __restrict__ base, int64_t pitch, int row0,
@@ -38,7 +41,7 @@ __device__ __forceinline__ void panel_load(PanelRegs<u32>& r, const u32* __restr
     for (int i = 0; i < 2; ++i) {
         const int v = threadIdx.x + i * 256;  // 0..511
         const int row = v >> 3, cv = v & 7;
-        r.v[i] = *reinterpret_cast<const uint4*>(base + (int64_t)(row0 + row) * pitch + k0 + cv * 4);
+        r.v[i] = *reinterpret_cast<const u32x4g*>(base + (int64_t)(row0 + row) * pitch + k0 + cv * 4);
     }
 }
 __device__ __forceinline__ void panel_store(const PanelRegs<u32>& r, double* s) {
@@ -47,8 +50,8 @@ __device__ __forceinline__ void panel_store(const PanelRegs<u32>& r, double* s) 
         const int v = threadIdx.x + i * 256;
         const int row = v >> 3, cv = v & 7;
         double* d = s + row * G_PITCH + cv * 4;
-        *reinterpret_cast<double2*>(d) = make_double2((double)r.v[i].x, (double)r.v[i].y);
-        *reinterpret_cast<double2*>(d + 2) = make_double2((double)r.v[i].z, (double)r.v[i].w);
+        *reinterpret_cast<f64x2*>(d) = (f64x2){(double)r.v[i].x, (double)r.v[i].y};
+        *reinterpret_cast<f64x2*>(d + 2) = (f64x2){(double)r.v[i].z, (double)r.v[i].w};
     }
 }
 __device__ __forceinline__ void panel_load(PanelRegs<double>& r, const double* __restrict__ base, int64_t pitch,
@@ -57,7 +60,7 @@ __device__ __forceinline__ void panel_load(PanelRegs<double>& r, const double* _
     for (int i = 0; i < 4; ++i) {
         const int v = threadIdx.x + i * 256;  // 0..1023
         const int row = v >> 4, cv = v & 15;
-        r.v[i] = *reinterpret_cast<const double2*>(base + (int64_t)(row0 + row) * pitch + k0 + cv * 2);
+        r.v[i] = *reinterpret_cast<const f64x2*>(base + (int64_t)(row0 + row) * pitch + k0 + cv * 2);
     }
 }
 __device__ __forceinline__ void panel_store(const PanelRegs<double>& r, double* s) {
@@ -65,7 +68,7 @@ __device__ __forceinline__ void panel_store(const PanelRegs<double>& r, double* 
     for (int i = 0; i < 4; ++i) {
         const int v = threadIdx.x + i * 256;
         const int row = v >> 4, cv = v & 15;
-        *reinterpret_cast<double2*>(s + row * G_PITCH + cv * 2) = r.v[i];
+        *reinterpret_cast<f64x2*>(s + row * G_PITCH + cv * 2) = r.v[i];
     }
 }
 
@@ -166,18 +169,38 @@ void build_gram_items(Plan& plan) {
         return x.pitch > y.pitch;
     });
     plan.order = order;
-    std::vector<std::vector<GramItem>> gs(8), rs(8);
+    std::vector<std::vector<GramItem>> gs(8), rs(8), rs_b(8);
+    plan.n_order_a = 0;
     for (size_t pos = 0; pos < order.size(); ++pos) {
         const int sid = order[pos];
         const int x = (int)(pos & 7);
         const int tiles = plan.splits[sid].rcap / G_TILE;
+        const bool long_side = plan.splits[sid].rcap > EIG_SMALL_ROWS;   // (order is sorted by rcap: the long sides come first)
+        if (long_side) plan.n_order_a = pos + 1;
         for (int ti = 0; ti < tiles; ++ti) {
-            rs[x].push_back({sid, (int16_t)ti, 0});
+            (long_side ? rs : rs_b)[x].push_back({sid, (int16_t)ti, 0});
             for (int tj = ti; tj < tiles; ++tj) gs[x].push_back({sid, (int16_t)ti, (int16_t)tj});
         }
     }
     interleave8(gs, plan.gram_items);
-    interleave8(rs, plan.row_items);
+    std::vector<GramItem> ra, rb2;
+    interleave8(rs, ra);
+    interleave8(rs_b, rb2);
+    plan.n_row_a = ra.size();
+    plan.row_items = ra;
+    plan.row_items.insert(plan.row_items.end(), rb2.begin(), rb2.end());
+    // 128 x 128 tiles of the int8 kernel (gram_i8.hip: k_gram_i8_big).  A tile costs ~its K extent, and a short side has
+    // ONE tile with the longest K of all: longest K first, so that those workgroups do not form the tail of the launch.
+    std::vector<int> by_k(order);
+    std::stable_sort(by_k.begin(), by_k.end(), [&](int a, int b) { return plan.splits[a].pitch > plan.splits[b].pitch; });
+    std::vector<std::vector<GramItem>> bs(8);
+    for (size_t pos = 0; pos < by_k.size(); ++pos) {
+        const int sid = by_k[pos];
+        const int tiles = (plan.splits[sid].rcap + 127) / 128;
+        for (int ti = 0; ti < tiles; ++ti)
+            for (int tj = ti; tj < tiles; ++tj) bs[pos & 7].push_back({sid, (int16_t)ti, (int16_t)tj});
+    }
+    interleave8(bs, plan.gram_items_big);
 }
 
 template <typename T>

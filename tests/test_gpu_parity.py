@@ -327,11 +327,49 @@ def test_gram_kernels_agree_bitwise(sp, golden):
         s_f64 = sp.score_splits(dev, sub, route="dense")
         dev.ctx.set_gram_mode("auto")
         assert np.array_equal(s_i8, s_f64), (length, int(counts.max()), np.abs(s_i8 - s_f64).max())
+        dev.ctx.set_option("gram_tile64", 1)           # round-1 kernel (64 x 64 tiles) against the 128 x 128-tile kernel
+        s_t64 = sp.score_splits(dev, sub, route="dense")
+        dev.ctx.set_option("gram_tile64", 0)
+        assert np.array_equal(s_i8, s_t64), (length, np.abs(s_i8 - s_t64).max())
+        dev.ctx.set_option("eigen_one_stream", 1)      # eigen phase as one pipeline instead of long sides | short sides
+        s_one = sp.score_splits(dev, sub, route="dense")
+        dev.ctx.set_option("eigen_one_stream", 0)
+        assert np.array_equal(s_i8, s_one), (length, np.abs(s_i8 - s_one).max())
         for i in (0, 60, 150):
             a, b = sub[i]
             M = O.reduced_flattening_packed(keys, counts.astype(np.float64), 10, [names.index(t) for t in a],
                                             [names.index(t) for t in b])[0]
             assert abs(O.dense_split_score(M) - s_i8[i]) <= SCORE_TOL
+
+
+def test_gram_big_tiles_ragged_shapes(sp):
+    """128 x 128-tile int8 Gram on shapes whose rows in use are not a multiple of 128 (padding rows are loaded as zeros,
+    never read), single-tile short sides, 6 - 10 taxa: bit-identical to the 64 x 64-tile kernel and to the fp64 MFMA
+    Gram, and equal to the oracle."""
+    from splitp_amd import synthetic as syn
+
+    for n, length, branch, seed in ((6, 3000, 0.08, 11), (8, 20_000, 0.1, 12), (8, 6000, 0.3, 13), (10, 30_000, 0.03, 14),
+                                    (10, 2500, 0.3, 15)):
+        names = taxa_names(n)
+        sites = syn.simulate_sites(n, length, branch, seed=seed)
+        keys, counts = syn.pattern_table(sites)
+        dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=length, taxa=names)
+        splits = list(sp.all_splits(names))
+        sub = splits[:: max(1, len(splits) // 90)]
+        s_big = sp.score_splits(dev, sub, route="dense")
+        dev.ctx.set_option("gram_tile64", 1)
+        s_t64 = sp.score_splits(dev, sub, route="dense")
+        dev.ctx.set_option("gram_tile64", 0)
+        dev.ctx.set_gram_mode("f64")
+        s_f64 = sp.score_splits(dev, sub, route="dense")
+        dev.ctx.set_gram_mode("auto")
+        assert np.array_equal(s_big, s_t64), (n, np.abs(s_big - s_t64).max())
+        assert np.array_equal(s_big, s_f64), (n, np.abs(s_big - s_f64).max())
+        for i in range(0, len(sub), max(1, len(sub) // 6)):
+            a, b = sub[i]
+            M = O.reduced_flattening_packed(keys, counts.astype(np.float64), n, [names.index(t) for t in a],
+                                            [names.index(t) for t in b])[0]
+            assert abs(O.dense_split_score(M) - s_big[i]) <= SCORE_TOL, (n, i)
 
 
 def test_routes_agree(sp, golden):

@@ -9,7 +9,8 @@ import csv
 import json
 import sys
 
-PHASE_OF = {"k_sparse_score": "sparse", "k_sparse_slow": "chain", "k_gram_i8": "gram", "k_eig_gv": "eigen"}
+PHASE_OF = {"k_sparse_score": "sparse", "k_sparse_slow": "chain", "k_gram_i8": "gram", "k_gram_i8_big": "gram", "k_eig_gv": "eigen",
+            "k_eig_rr": "eigen_rr", "k_zero_i8": "zero", "k_scatter_i8": "scatter", "k_eig_init": "eigen_init", "k_reindex": "reindex"}
 
 
 def per_kernel(path):
