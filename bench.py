@@ -370,7 +370,14 @@ def main():
     # ---- candidate splits: the full all_splits list, or this rank's shard of it -------------------------------
     taxa_all, a_all = sp.encode_all_splits(n_taxa)
     n_splits_total = len(a_all)
-    if shard_splits:
+    # subflattening workloads (configs 3 / 4): the splits are enumerated on the device (sp_score_all_splits_shard) - no
+    # split list crosses the boundary; a rank's shard = the combinations rank, rank + P, ... of every size class
+    enum_on_device = method_name == "subflattening"
+    if shard_splits and enum_on_device:
+        shards, _ = batch.shard_layout(n_taxa, world)
+        mine = shards[rank]
+        per = max(len(s) for s in shards)
+    elif shard_splits:
         shards = batch.shard_indices(batch.split_costs(a_all, n_taxa, code), world)
         mine = shards[rank]
         per = max(len(s) for s in shards)
@@ -452,6 +459,14 @@ def main():
                 else:
                     _lib.check(lib.sp_score_plan_async(lane.ctx.handle, al_handles, n_al_rank, plan.handle, lane.sc_p[0],
                                                        lane.st_p[0]))
+            elif enum_on_device:
+                ctx0.sync_stream_with_torch()
+                n_got = C.c_int64()
+                for a, al in enumerate(aligns):
+                    _lib.check(lib.sp_score_all_splits_shard(al.handle, code, 0, 0, rank if shard_splits else 0,
+                                                             world if shard_splits else 1, C.byref(n_got), None,
+                                                             lane.sc_p[a], None, lane.st_p[a]))
+                    assert n_got.value == n_mine, (n_got.value, n_mine)
             else:
                 ctx0.sync_stream_with_torch()
                 for a, al in enumerate(aligns):
@@ -566,7 +581,10 @@ def main():
         roof = roofline_block(dom, dom_ms_alone, ph[dom][0] / ph[dom][1], ph[dom][0] / (elapsed * 1e3),
                               {k: round(v[0] / args.steps, 5) for k, v in ph.items()}, n_taxa, n_sites, a_arr,
                               items_rank / max(launches_per_step, 1e-9), n_patterns, n_lanes, status=status)
-        if shard_splits:
+        if shard_splits and enum_on_device:
+            par = (f"split-sharded x{world}: one alignment replicated, every rank enumerates and scores its share of every size "
+                   "class on the device (index mod P), all_gather of scores + status")
+        elif shard_splits:
             par = f"split-sharded x{world}: one alignment replicated, candidate splits dealt by cost class, all_gather of scores + status"
         elif world > 1:
             par = f"alignment-sharded x{world}, all_gather of scores + status"

@@ -21,6 +21,9 @@
 #ifndef SPK_ROW_MAX
 #define SPK_ROW_MAX 128     // ... and with more than this by the 64 lanes of a wave
 #endif
+#ifndef SPK_TOL_REL
+#define SPK_TOL_REL 1e-13    // relative tolerance on the top-4 Ritz sum (spk_converged)
+#endif
 #define SPK_MAXIT 40        // dense products of the small-side path (cheap)
 #define SPK_MAXHALF 40      // sparse half products of the general path; a block without a spectral gap behind it goes to
                             // the dense route long before (spk_converged)
@@ -268,7 +271,7 @@ __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double t
             // Tolerance on s: 1e-13 relative, tightened for tiny scores (d score = d s / (2 score trace): keep it
             // below 2e-11) down to the rounding floor of the Ritz sum (~2e-15 relative, so 4e-15 is the least asked).
             const double sx = sqrt(fmax(rest, 0.0) * trace);   // = score * trace
-            const double tol = fmax(fmin(1e-13 * s4, 4e-11 * sx), 4e-15 * s4);
+            const double tol = fmax(fmin(SPK_TOL_REL * s4, 4e-11 * sx), 4e-15 * s4);
             // Measured ratios can hide a slow component of small amplitude behind fast ones (a rank-5 flattening
             // stopped 3e-8 early in the randomised tests).  No component is slower than lambda_5 / lambda_4 <= rho_b =
             // rest / lam_lb per half product, and e_k <= rho (e_k + delta_k) makes delta rho_b / (1 - rho_b) a BOUND of
