@@ -365,8 +365,8 @@ __global__ __launch_bounds__(256) void k_scatter_i8(const SplitDev* __restrict__
     const int64_t plane = (int64_t)sp.rcap * sp.pitch;
     uint8_t* p = mats + sp.mat_off + (int64_t)rr[o] * sp.pitch + cc[o];
     u32 v = vals[i];
-    for (int l = 0; l < nl; ++l) {
-        p[l * plane] = (uint8_t)(v & 127u);
+    for (int l = 0; l < nl; ++l) {   // (the planes were zero-filled: a zero limb - the high limb of most patterns - needs no store)
+        if (v & 127u) p[l * plane] = (uint8_t)(v & 127u);
         v >>= 7;
     }
 }
