@@ -498,8 +498,8 @@ __device__ __forceinline__ bool update_convergence(double s4, int it, double& pr
 // the block weighs rest = trace - (sum of all 16 Ritz values) >= lambda_17, the 4th Ritz value theta_4 <= lambda_4, so no
 // component of the top-4 sum's error decays slower than q = (rest / theta_4)^2 per product (Ritz values are second order
 // in the angle) and what is still missing after a step of size delta is at most delta q / (1 - q).  Phylogenetic
-// flattenings have rest / theta_4 ~ 1e-3: the bound certifies the sum after the 3rd product, where the two-ratio rule of
-// update_convergence cannot speak before the 4th - one G V product and one Rayleigh-Ritz round less for every split.
+// flattenings have rest / theta_4 ~ 1e-4 ... 2e-2: the bound certifies the sum after the 3rd product, where the two-ratio
+// rule of update_convergence cannot speak before the 4th - one G V product and one Rayleigh-Ritz round less.
 __device__ __forceinline__ bool certified_stop(double s4, double delta, int it, double trace, const EigShared& sh) {
     if (it < 3) return false;
     const double rest = trace - sh.sum_all;
@@ -507,7 +507,14 @@ __device__ __forceinline__ bool certified_stop(double s4, double delta, int it, 
     const double rho = rest / sh.theta4;
     if (!(rho < 0.25)) return false;
     const double q = rho * rho;
-    return delta * q / (1.0 - q) <= 1e-15 * s4;
+    // Tolerance on the sum as in the sparse route (spk_converged): the score is sqrt(1 - s / trace), so an error e of the
+    // sum moves it by e / (2 score trace); 4e-11 score trace keeps that below 2e-11, capped at 1e-12 of the sum and never
+    // asked below the sum's rounding floor.  The bound is conservative - rest overestimates lambda_17 ~30x on real
+    // alignments: where it says 1e-12 the sum is typically good to 1e-15 - so a fixed 1e-15 certified only a quarter of
+    // config 2's splits after the 3rd product; this certifies all of them, and the 4th round of launches is empty.
+    const double sx = sqrt(fmax(trace - s4, 0.0) * trace);   // = score * trace
+    const double tol = fmax(fmin(1e-12 * s4, 4e-11 * sx), 4e-15 * s4);
+    return delta * q / (1.0 - q) <= tol;
 }
 
 // Final acceptance, shared by k_eig_rr and k_eig_finish (uniform).  `g2_conv`: the G^2 sums have settled this round.

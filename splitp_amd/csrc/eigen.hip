@@ -224,6 +224,12 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_rr(const SplitDev* __restri
     const double g2_sum = sh.top4;
     bool g2_conv = update_convergence(g2_sum, st.it, st.prev_sum, st.prev_delta, st.prev_ratio);
     g2_conv = g2_conv || certified_stop(g2_sum, st.prev_delta, st.it, st.trace, sh);
+#ifdef EIG_STAMPS
+    if (st.it == 3 && threadIdx.x == 0 && blockIdx.x < 128) {   // what the certified stop saw (diagnostic build)
+        g_eig_dump[blockIdx.x] = st.prev_delta / g2_sum;
+        g_eig_dump[128 + blockIdx.x] = (st.trace - sh.sum_all) / sh.theta4;
+    }
+#endif
     // (the score comes from the first-power Ritz values of the same subspace; sets st.top4)
     if (accept_first_power(g2_conv, g2_sum, st, sh)) {
         STAMP(5);

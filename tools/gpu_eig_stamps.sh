@@ -25,6 +25,16 @@ o = np.array(out[:], dtype=np.int64)
 d = lambda a, b: int(o[a] - o[b])
 print("round $round (cycles): load_Y=%d proj=%d gram=%d jacobi=%d T+rowmul=%d polish0=%d polish1=%d polish2=%d ritz_total=%d end(3)=%d accept(5)=%d" % (
     d(1,0), d(4,1), d(10,4), d(11,10), d(12,11), d(13,12), d(14,13), d(15,14), d(2,4), d(3,2), d(5,2)))
+if "$EIG_CERT":
+    lib.sp_debug_eig_dump.argtypes = [C.POINTER(C.c_double)]
+    dd = (C.c_double * 256)()
+    lib.sp_debug_eig_dump(dd)
+    v = np.array(dd[:])
+    dl, rho = v[:126], v[128:254]
+    bound = dl * rho**2 / (1 - rho**2)
+    np.set_printoptions(linewidth=200, precision=2)
+    print("   certified stop at product 3, first 126 workgroups (long sides): delta/s", np.sort(dl)[[0, 31, 63, 94, 125]], "rho", np.sort(rho)[[0, 31, 63, 94, 125]])
+    print("   bound delta q/(1-q) quantiles", np.sort(bound)[[0, 31, 63, 94, 125]], " passes (<= 1e-15):", int((bound <= 1e-15).sum()), " with q/30:", int((bound / 30 <= 1e-15).sum()), " with q/100:", int((bound / 100 <= 1e-15).sum()))
 if "$EIG_DUMP":
     lib.sp_debug_eig_dump.argtypes = [C.POINTER(C.c_double)]
     dd = (C.c_double * 256)()
