@@ -134,14 +134,14 @@ template <typename GT>
 struct G4 {};
 template <>
 struct G4<double> {
-    static __device__ __forceinline__ void load(const double* p, double (&a)[4]) {
+    static __device__ __forceinline__ void load(const double* p, double* a) {
         const double2 x = *reinterpret_cast<const double2*>(p), y = *reinterpret_cast<const double2*>(p + 2);
         a[0] = x.x; a[1] = x.y; a[2] = y.x; a[3] = y.y;
     }
 };
 template <>
 struct G4<int> {
-    static __device__ __forceinline__ void load(const int* p, double (&a)[4]) {
+    static __device__ __forceinline__ void load(const int* p, double* a) {
         const int4 x = *reinterpret_cast<const int4*>(p);
         a[0] = (double)x.x; a[1] = (double)x.y; a[2] = (double)x.z; a[3] = (double)x.w;
     }
@@ -166,8 +166,28 @@ __global__ __launch_bounds__(256) void k_eig_gv(const GramItem* __restrict__ ite
     const GT* __restrict__ g = grams + sp.g_off + (int64_t)(row0 + fr) * sp.g_pitch + 4 * fk;
     const double* __restrict__ v = vt_pool + sp.ev_off + (int64_t)fr * sp.rcap + 4 * fk;
     double4_t acc = {0, 0, 0, 0};
-#pragma unroll 8
-    for (int k0 = 0; k0 < Rp; k0 += 16) {
+    // 32 k's a step: a lane loads 8 consecutive entries of its G row (the 4 lanes of a row read one full 128-byte line of
+    // an int32 G, 256 bytes of an fp64 G) and 8 consecutive entries of its V column; MFMA j sums k in {k0 + 8 g + j}.
+    // (16 k's a step - 64-byte half lines of the int32 G - streamed at 3.3 TB/s.)  A 16-wide tail follows when needed.
+    int k0 = 0;
+#pragma unroll 4
+    for (; k0 + 32 <= Rp; k0 += 32) {
+        double a[8];
+        G4<GT>::load(g + k0 + 4 * fk, a);            // g already carries 4 fk: 8 fk in all
+        G4<GT>::load(g + k0 + 4 * fk + 4, a + 4);
+        const double* __restrict__ vb = v + k0 + 4 * fk;
+        const double2 b01 = *reinterpret_cast<const double2*>(vb), b23 = *reinterpret_cast<const double2*>(vb + 2);
+        const double2 b45 = *reinterpret_cast<const double2*>(vb + 4), b67 = *reinterpret_cast<const double2*>(vb + 6);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b01.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b01.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b23.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b23.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4], b45.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[5], b45.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[6], b67.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[7], b67.y, acc, 0, 0, 0);
+    }
+    for (; k0 < Rp; k0 += 16) {
         double a[4];
         G4<GT>::load(g + k0, a);
         const double2 b01 = *reinterpret_cast<const double2*>(v + k0);
