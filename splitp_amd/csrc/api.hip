@@ -188,7 +188,7 @@ extern "C" int sp_ctx_destroy(sp_ctx* c) {
     for (auto e : c->timer.pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->splits, &c->bitmaps, &c->coords, &c->dims, &c->mats,  &c->grams,  &c->eigws,
                       &c->scores, &c->status,  &c->misc,   &c->misc2, &c->gram_items, &c->aldescs, &c->slabs, &c->chain,
-                      &c->splits_launch};
+                      &c->splits_launch, &c->hist_bins, &c->hist_blk, &c->hist_off};
     if (c->cache && c->cache->sparse) (void)sp_plan_release(c->cache->sparse);
     delete c->cache;
     for (auto* b : bufs) b->release();

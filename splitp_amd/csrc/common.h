@@ -138,6 +138,10 @@ struct sp_ctx {
     // workgroups per CU) run as a pipeline of their own on this internal stream, next to the long sides on `stream`
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // direct-bins histogram (hist.hip), tables of up to 12 taxa: the 4^n-bin array is kept between calls and handed back
+    // ALL ZERO by the pass that reads it (no allocation, no memset per alignment); hist_clean = that invariant holds
+    DevBuf hist_bins, hist_blk, hist_off;
+    bool hist_clean = false;
 };
 
 struct sp_alignment {

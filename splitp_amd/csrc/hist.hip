@@ -137,26 +137,42 @@ __global__ __launch_bounds__(HIST_THREADS) void k_hist_lds(const KT* __restrict_
 
 #define SCAN_BLOCK_ELEMS 4096  // bins per block in the count / write passes
 
+// (also the largest count, into *max_count: it decides the limb count of the int8 Gram and used to cost a D x 4-byte
+// copy to the host per alignment)
 __global__ __launch_bounds__(256) void k_bins_count(const u32* __restrict__ bins, int64_t nbins,
-                                                    u32* __restrict__ block_nz) {
-    __shared__ u32 sh[4];
+                                                    u32* __restrict__ block_nz, u32* __restrict__ max_count) {
+    __shared__ u32 sh[4], shm[4];
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK_ELEMS;
-    u32 c = 0;
+    u32 c = 0, mx = 0;
     for (int j = 0; j < SCAN_BLOCK_ELEMS / 256 / 4; ++j) {
         const int64_t i = base + ((int64_t)j * 256 + threadIdx.x) * 4;
         if (i + 3 < nbins) {
             const uint4 v = *reinterpret_cast<const uint4*>(bins + i);
             c += (v.x != 0) + (v.y != 0) + (v.z != 0) + (v.w != 0);
+            mx = max(max(mx, v.x), max(max(v.y, v.z), v.w));
         } else {
             for (int e = 0; e < 4; ++e)
-                if (i + e < nbins) c += bins[i + e] != 0;
+                if (i + e < nbins) {
+                    c += bins[i + e] != 0;
+                    mx = max(mx, bins[i + e]);
+                }
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    for (int d = 32; d >= 1; d >>= 1) {
+        c += __shfl_xor(c, d, 64);
+        mx = max(mx, (u32)__shfl_xor((int)mx, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sh[threadIdx.x >> 6] = c;
+        shm[threadIdx.x >> 6] = mx;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) block_nz[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0) {
+        block_nz[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+        const u32 m = max(max(shm[0], shm[1]), max(shm[2], shm[3]));
+        if (m) atomicMax(max_count, m);
+    }
 }
 
 // exclusive scan of block_nz (one workgroup; nblocks up to a few million) -> offsets, total at [nblocks]
@@ -188,9 +204,13 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const u32* __restrict__ in
     if (threadIdx.x == 0) out[nblocks] = carry;
 }
 
-__global__ __launch_bounds__(256) void k_bins_write(const u32* __restrict__ bins, int64_t nbins,
+// Ordered compaction of the non-empty bins -> keys ascending, counts, weights = count / N (counts[k] / float(L):
+// simulation.py:54, fasta.py:66-70).  `rezero`: every non-empty bin is cleared after it was read (and the two meta words
+// behind the bins by block 0), so a pooled bin array goes back all zero.
+__global__ __launch_bounds__(256) void k_bins_write(u32* __restrict__ bins, int64_t nbins,
                                                     const u64* __restrict__ block_off, u64* __restrict__ keys,
-                                                    u32* __restrict__ counts) {
+                                                    u32* __restrict__ counts, double* __restrict__ weights, double N,
+                                                    int rezero) {
     __shared__ u32 sh[5];
     const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK_ELEMS;
     // each thread owns 16 consecutive bins -> ordered output
@@ -220,8 +240,11 @@ __global__ __launch_bounds__(256) void k_bins_write(const u32* __restrict__ bins
         if (v[e]) {
             keys[o] = (u64)(lo + e);
             counts[o] = v[e];
+            weights[o] = (double)v[e] / N;
+            if (rezero) bins[lo + e] = 0;
             ++o;
         }
+    if (rezero && blockIdx.x == 0 && threadIdx.x < 4) bins[nbins + threadIdx.x] = 0;   // n_valid, max count
 }
 
 __global__ void k_counts_to_weights(const u32* __restrict__ counts, int64_t D, double N, double* __restrict__ w) {
@@ -339,27 +362,40 @@ static int build_from_device_keys(sp_ctx* ctx, const void* dkeys, bool keys32, i
                           : build_sorted<u64>(ctx, (const u64*)dkeys, L, n_taxa, out);
     }
     const int64_t nbins = pow4(n_taxa);
-    DevBuf bins, blk, off;
     const int64_t nblocks = (nbins + SCAN_BLOCK_ELEMS - 1) / SCAN_BLOCK_ELEMS;
+    // Up to 12 taxa (64 MB of bins) the three work arrays belong to the context and the bins are handed back all zero by
+    // k_bins_write: no allocation and no memset per alignment (they were most of the call's wall time: 0.42 ms around
+    // 0.04 ms of kernels at config 2).  Larger bin arrays are allocated, cleared and freed per call as before.
+    const bool pooled = nbins * 4 <= ((int64_t)64 << 20);
+    DevBuf l_bins, l_blk, l_off;
+    DevBuf& bins = pooled ? ctx->hist_bins : l_bins;
+    DevBuf& blk = pooled ? ctx->hist_blk : l_blk;
+    DevBuf& off = pooled ? ctx->hist_off : l_off;
     int rc;
     auto cleanup = [&]() {
-        bins.release();
-        blk.release();
-        off.release();
+        l_bins.release();
+        l_blk.release();
+        l_off.release();
     };
+    const void* had = bins.p;
+    const size_t had_cap = bins.cap;
     if ((rc = bins.ensure((size_t)nbins * 4 + 16)) || (rc = blk.ensure((size_t)nblocks * 4)) ||
         (rc = off.ensure((size_t)(nblocks + 1) * 8))) {
         cleanup();
         return rc;
     }
-    u32* n_valid = bins.as<u32>() + nbins;  // the 4 bytes after the bins
+    if (pooled && (bins.p != had || bins.cap != had_cap)) ctx->hist_clean = false;   // a fresh (larger) array
+    u32* n_valid = bins.as<u32>() + nbins;      // the words after the bins: usable sites, largest count
+    u32* max_dev = n_valid + 1;
     {
         PhaseScope ps(ctx, SP_PHASE_HIST);
-        if (hipMemsetAsync(bins.p, 0, (size_t)nbins * 4 + 16, ctx->stream) != hipSuccess) {
+        if (!(pooled && ctx->hist_clean) &&
+            hipMemsetAsync(bins.p, 0, (size_t)nbins * 4 + 16, ctx->stream) != hipSuccess) {
             cleanup();
             sp_set_error("hipMemsetAsync of the bin array failed");
             return SP_EHIP;
         }
+        ctx->hist_clean = false;   // dirty from here until k_bins_write has run to completion
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((L + HIST_TILE - 1) / HIST_TILE, ctx->n_cu * 2));
         if (keys32)   // 32-bit site words (n <= 15): half the traffic of the pass (4 L bytes)
             hipLaunchKernelGGL(k_hist_lds<u32>, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, (const u32*)dkeys, L,
@@ -368,13 +404,13 @@ static int build_from_device_keys(sp_ctx* ctx, const void* dkeys, bool keys32, i
             hipLaunchKernelGGL(k_hist_lds<u64>, dim3(grid), dim3(HIST_THREADS), 0, ctx->stream, (const u64*)dkeys, L,
                                n_taxa, bins.as<u32>(), n_valid);
         hipLaunchKernelGGL(k_bins_count, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, bins.as<u32>(), nbins,
-                           blk.as<u32>());
+                           blk.as<u32>(), max_dev);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, blk.as<u32>(), nblocks, off.as<u64>());
     }
     u64 D64 = 0;
-    u32 N32 = 0;
+    u32 meta[2] = {0, 0};   // usable sites, largest count
     hipError_t e = hipMemcpyAsync(&D64, off.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&N32, n_valid, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(meta, n_valid, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) {
@@ -383,12 +419,14 @@ static int build_from_device_keys(sp_ctx* ctx, const void* dkeys, bool keys32, i
         return SP_EHIP;
     }
     const int64_t D = (int64_t)D64;
+    const u32 N32 = meta[0];
     sp_alignment* al = new sp_alignment();
     al->ctx = ctx;
     al->n_taxa = n_taxa;
     al->D = D;
     al->N = N32;
     al->exact = true;
+    al->max_count = meta[1];
     const size_t d1 = (size_t)std::max<int64_t>(D, 1);
     if ((rc = al->keys.ensure(d1 * 8)) || (rc = al->weights.ensure(d1 * 8)) || (rc = al->counts.ensure(d1 * 4))) {
         cleanup();
@@ -398,23 +436,20 @@ static int build_from_device_keys(sp_ctx* ctx, const void* dkeys, bool keys32, i
     if (D > 0) {
         PhaseScope ps(ctx, SP_PHASE_HIST);
         hipLaunchKernelGGL(k_bins_write, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, bins.as<u32>(), nbins,
-                           off.as<u64>(), al->keys.as<u64>(), al->counts.as<u32>());
-        hipLaunchKernelGGL(k_counts_to_weights, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream,
-                           al->counts.as<u32>(), D, (double)N32, al->weights.as<double>());
+                           off.as<u64>(), al->keys.as<u64>(), al->counts.as<u32>(), al->weights.as<double>(), (double)N32,
+                           pooled ? 1 : 0);
+    } else if (pooled) {
+        // no usable site: nothing was added to the bins; the meta words are cleared by the next call's memset
     }
     e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess && D > 0) {  // largest count -> limb count of the int8 Gram (D x 4 bytes, one-time)
-        std::vector<u32> hc((size_t)D);
-        e = hipMemcpy(hc.data(), al->counts.p, (size_t)D * 4, hipMemcpyDeviceToHost);
-        for (u32 c : hc) al->max_count = std::max(al->max_count, c);
-    }
     cleanup();
     if (e != hipSuccess) {
         sp_alignment_destroy(al);
         sp_set_error("histogram compaction failed: %s", hipGetErrorString(e));
         return SP_EHIP;
     }
+    if (pooled && D > 0) ctx->hist_clean = true;   // every bin that was touched has been cleared again
     *out = al;
     return SP_OK;
 }
