@@ -158,17 +158,17 @@ __device__ __forceinline__ void jacobi_cs(double app, double aqq, double apq, do
 // round trip, ~100 flops and one wave-level sync.  Convergence is judged relatively (|h_ij|^2 against
 // h_ii h_jj), which is what gives Jacobi its high relative accuracy on PSD matrices.  Ends with a barrier.
 template <int NB>
-__device__ __forceinline__ void jacobi_nb(EigShared& sh) {
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
+__device__ __forceinline__ void jacobi_core(double* H, double* Q, double* theta, bool diag) {
+    {
+        const int lane = threadIdx.x & 63;
         constexpr int NP = NB / 2;  // disjoint pairs per round; lanes 0 .. NP*NP-1 each own a 2 x 2 block
         const bool act = lane < NP * NP;
         const int pa = act ? lane / NP : 0, pb = act ? lane % NP : 0;
-        for (int e = lane; e < EIG_B * EIG_B; e += 64) sh.Q[(e >> 4) * EIG_VP + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+        for (int e = lane; e < EIG_B * EIG_B; e += 64) Q[(e >> 4) * EIG_VP + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
         wave_sync_lds();
 #pragma unroll 1
         for (int sweep = 0; sweep < 15; ++sweep) {
-            double dmx = lane < NB ? fabs(sh.H[lane * EIG_VP + lane]) : 0.0;
+            double dmx = lane < NB ? fabs(H[lane * EIG_VP + lane]) : 0.0;
 #pragma unroll
             for (int d = 8; d >= 1; d >>= 1) dmx = fmax(dmx, __shfl_xor(dmx, d, 64));
             dmx = __shfl(dmx, 0, 64);
@@ -176,8 +176,8 @@ __device__ __forceinline__ void jacobi_nb(EigShared& sh) {
             for (int e = lane; e < EIG_B * EIG_B; e += 64) {
                 const int i = e >> 4, j = e & 15;
                 if (i < j && j < NB) {
-                    const double v = sh.H[i * EIG_VP + j];
-                    const double dd = fabs(sh.H[i * EIG_VP + i] * sh.H[j * EIG_VP + j]);
+                    const double v = H[i * EIG_VP + j];
+                    const double dd = fabs(H[i * EIG_VP + i] * H[j * EIG_VP + j]);
                     // couplings below 1e-20 of the largest eigenvalue cannot matter (directions that small are
                     // noise or dead) and would otherwise keep the sweeps going on rounding residue
                     open = open || (v * v > 1e-40 * dmx * dmx && !(v * v <= 1e-22 * dd));
@@ -185,13 +185,13 @@ __device__ __forceinline__ void jacobi_nb(EigShared& sh) {
             }
             const double rel = __builtin_amdgcn_ballot_w64(open) != 0ull ? 1.0 : 0.0;
 #ifdef EIG_STAMPS
-            if (blockIdx.x == 0 && g_eig_stamp_on && g_eig_stamps[39] == 0 && sweep < 10) {
+            if (diag && blockIdx.x == 0 && g_eig_stamp_on && g_eig_stamps[39] == 0 && sweep < 10) {
                 double mx = 0; int nopen = 0;
                 for (int e = lane; e < EIG_B * EIG_B; e += 64) {
                     const int i = e >> 4, j = e & 15;
                     if (i < j && j < NB) {
-                        const double v = sh.H[i * EIG_VP + j];
-                        const double dd = fabs(sh.H[i * EIG_VP + i] * sh.H[j * EIG_VP + j]);
+                        const double v = H[i * EIG_VP + j];
+                        const double dd = fabs(H[i * EIG_VP + i] * H[j * EIG_VP + j]);
                         mx = fmax(mx, fabs(v) / dmx);
                         nopen += (v * v > 1e-40 * dmx * dmx && !(v * v <= 1e-22 * dd)) ? 1 : 0;
                     }
@@ -202,7 +202,7 @@ __device__ __forceinline__ void jacobi_nb(EigShared& sh) {
             }
 #endif
 #ifdef EIG_STAMPS
-            if (lane == 0 && blockIdx.x == 0 && g_eig_stamp_on) {
+            if (diag && lane == 0 && blockIdx.x == 0 && g_eig_stamp_on) {
                 const int slot = g_eig_stamps[39] < 8 ? (int)g_eig_stamps[39] : 7;   // [39] = Jacobi calls so far
                 g_eig_stamps[40 + slot] = sweep;
                 g_eig_stamps[48 + slot] = (long long)(rel * 1e30 < 9e18 ? rel * 1e30 : 9e18);
@@ -222,12 +222,12 @@ __device__ __forceinline__ void jacobi_nb(EigShared& sh) {
                 jp = pb == 0 ? NB - 1 : (b1 >= NB - 1 ? b1 - (NB - 1) : b1);
                 jq = pb == 0 ? round : (b2 >= NB - 1 ? b2 - (NB - 1) : b2);
                 if (jp > jq) { const int t = jp; jp = jq; jq = t; }
-                const double hpp = sh.H[ip * EIG_VP + jp], hpq = sh.H[ip * EIG_VP + jq];
-                const double hqp = sh.H[iq * EIG_VP + jp], hqq = sh.H[iq * EIG_VP + jq];
-                const double a_pp = sh.H[ip * EIG_VP + ip], a_qq = sh.H[iq * EIG_VP + iq], a_pq = sh.H[ip * EIG_VP + iq];
-                const double b_pp = sh.H[jp * EIG_VP + jp], b_qq = sh.H[jq * EIG_VP + jq], b_pq = sh.H[jp * EIG_VP + jq];
-                const double q0p = sh.Q[(2 * pa) * EIG_VP + jp], q0q = sh.Q[(2 * pa) * EIG_VP + jq];
-                const double q1p = sh.Q[(2 * pa + 1) * EIG_VP + jp], q1q = sh.Q[(2 * pa + 1) * EIG_VP + jq];
+                const double hpp = H[ip * EIG_VP + jp], hpq = H[ip * EIG_VP + jq];
+                const double hqp = H[iq * EIG_VP + jp], hqq = H[iq * EIG_VP + jq];
+                const double a_pp = H[ip * EIG_VP + ip], a_qq = H[iq * EIG_VP + iq], a_pq = H[ip * EIG_VP + iq];
+                const double b_pp = H[jp * EIG_VP + jp], b_qq = H[jq * EIG_VP + jq], b_pq = H[jp * EIG_VP + jq];
+                const double q0p = Q[(2 * pa) * EIG_VP + jp], q0q = Q[(2 * pa) * EIG_VP + jq];
+                const double q1p = Q[(2 * pa + 1) * EIG_VP + jp], q1q = Q[(2 * pa + 1) * EIG_VP + jq];
                 double ca, sa, cb, sb;
                 jacobi_cs(a_pp, a_qq, a_pq, ca, sa);
                 jacobi_cs(b_pp, b_qq, b_pq, cb, sb);
@@ -237,23 +237,60 @@ __device__ __forceinline__ void jacobi_nb(EigShared& sh) {
                 wave_sync_lds();  // every lane has read before anyone writes
                 // cols: [p' q'] = [p q] [c s; -s c]
                 if (act) {
-                sh.H[ip * EIG_VP + jp] = cb * rpp - sb * rpq;
-                sh.H[ip * EIG_VP + jq] = sb * rpp + cb * rpq;
-                sh.H[iq * EIG_VP + jp] = cb * rqp - sb * rqq;
-                sh.H[iq * EIG_VP + jq] = sb * rqp + cb * rqq;
+                H[ip * EIG_VP + jp] = cb * rpp - sb * rpq;
+                H[ip * EIG_VP + jq] = sb * rpp + cb * rpq;
+                H[iq * EIG_VP + jp] = cb * rqp - sb * rqq;
+                H[iq * EIG_VP + jq] = sb * rqp + cb * rqq;
                 // Q <- Q J: lane (a, b) updates rows {2a, 2a+1} of the column pair b
-                sh.Q[(2 * pa) * EIG_VP + jp] = cb * q0p - sb * q0q;
-                sh.Q[(2 * pa) * EIG_VP + jq] = sb * q0p + cb * q0q;
-                sh.Q[(2 * pa + 1) * EIG_VP + jp] = cb * q1p - sb * q1q;
-                sh.Q[(2 * pa + 1) * EIG_VP + jq] = sb * q1p + cb * q1q;
+                Q[(2 * pa) * EIG_VP + jp] = cb * q0p - sb * q0q;
+                Q[(2 * pa) * EIG_VP + jq] = sb * q0p + cb * q0q;
+                Q[(2 * pa + 1) * EIG_VP + jp] = cb * q1p - sb * q1q;
+                Q[(2 * pa + 1) * EIG_VP + jq] = sb * q1p + cb * q1q;
                 }
                 wave_sync_lds();
             }
         }
-        if (lane < EIG_B) sh.theta[lane] = lane < NB ? sh.H[lane * EIG_VP + lane] : 0.0;
+        if (lane < EIG_B) theta[lane] = lane < NB ? H[lane * EIG_VP + lane] : 0.0;
 #ifdef EIG_STAMPS
-        if (lane == 0 && blockIdx.x == 0 && g_eig_stamp_on) g_eig_stamps[39] += 1;
+        if (diag && lane == 0 && blockIdx.x == 0 && g_eig_stamp_on) g_eig_stamps[39] += 1;
 #endif
+    }
+}
+
+// Wave 0 runs the Jacobi on sh.H / sh.Q / sh.theta.  Ends with a barrier.
+template <int NB>
+__device__ __forceinline__ void jacobi_nb(EigShared& sh) {
+    if (threadIdx.x < 64) jacobi_core<NB>(sh.H, sh.Q, sh.theta, true);
+    __syncthreads();
+}
+
+// Second 16 x 16 problem solved NEXT TO the first one by wave 1 (eigen.hip: the first-power projection G1 of the dense
+// route, whose eigenvalues the acceptance test wants in the round that stops - one wave's Jacobi is 60 - 90 us of pure
+// latency and the other 7 waves of the workgroup are idle meanwhile).  top4 = sum of the four largest eigenvalues of H.
+struct EigSpec {
+    double H[EIG_B * EIG_VP];
+    double Q[EIG_B * EIG_VP];
+    double theta[EIG_B];
+    double top4;
+};
+template <int NB>
+__device__ __forceinline__ void jacobi_dual(EigShared& sh, EigSpec& sp2) {
+    const int w = threadIdx.x >> 6;
+    if (w == 0) jacobi_core<NB>(sh.H, sh.Q, sh.theta, true);
+    else if (w == 1) {
+        jacobi_core<EIG_B>(sp2.H, sp2.Q, sp2.theta, false);
+        const int lane = threadIdx.x & 63;
+        const double th = lane < EIG_B ? sp2.theta[lane] : -1e300;
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < EIG_B; ++j) {
+            const double o = __shfl(th, j, 64);
+            rank += (o > th || (o == th && j < lane)) ? 1 : 0;
+        }
+        double pick = (lane < EIG_B && rank < 4) ? fmax(th, 0.0) : 0.0;
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) pick += __shfl_xor(pick, d, 64);
+        if (lane == 0) sp2.top4 = pick;
     }
     __syncthreads();
 }
@@ -271,14 +308,15 @@ template <int NB, int VP>
 __device__ __forceinline__ void polish_nb(double* X, int Rp, EigShared& sh);
 
 template <int NB, int VP>
-__device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh) {
+__device__ __forceinline__ void ritz_orth_nb(double* X, int Rp, EigShared& sh, EigSpec* spec = nullptr) {
     gram_nb<NB, VP>(X, Rp, sh, sh.H);
     EIG_STAMP(10);
 #ifdef EIG_STAMPS
     if (blockIdx.x == 0 && g_eig_stamp_on && threadIdx.x < 256) g_eig_dump[threadIdx.x] = sh.H[(threadIdx.x >> 4) * EIG_VP + (threadIdx.x & 15)];
     __syncthreads();
 #endif
-    jacobi_nb<NB>(sh);
+    if (spec) jacobi_dual<NB>(sh, *spec);   // (uniform)
+    else jacobi_nb<NB>(sh);
     EIG_STAMP(11);
     bool weak;
     // top-4 sum + T = P D^-1/2 (256 threads)
@@ -522,12 +560,17 @@ __device__ __forceinline__ bool certified_stop(double s4, double delta, int it, 
 // iteration resolved all four values and f is final.  If not, the 4th value is below what G^2 can see (a matrix of
 // numerical rank < 4: lambda_4 inside the cluster of its noise eigenvalues) and the G^2 sums are blind to its
 // convergence: from then on f is evaluated every round and judged by the two-ratio rule itself.
-__device__ __forceinline__ bool accept_first_power(bool g2_conv, double g2_sum, EigState& st, EigShared& sh) {
+__device__ __forceinline__ bool accept_first_power(bool g2_conv, double g2_sum, EigState& st, EigShared& sh,
+                                                   const EigSpec* spec = nullptr) {
     // (also from the 6th product on: G^2 sums of a moderately ill-conditioned spectrum sit on their rounding floor, above
     // the tolerance, and would never settle)
     if (!g2_conv && st.fp_it == 0 && st.it < 6) return false;
-    first_power_top4(sh);
-    const double f = sh.top4;
+    double f;
+    if (spec) f = spec->top4;          // solved by wave 1 next to this round's G^2 Jacobi (jacobi_dual)
+    else {
+        first_power_top4(sh);
+        f = sh.top4;
+    }
     if (st.fp_it == 0 && g2_conv && fabs(f - g2_sum) <= 1e-13 * g2_sum) {
         st.top4 = f;
         return true;

@@ -42,6 +42,8 @@ __device__ double g_eig_dump[256];   // projected matrix of workgroup 0 in the s
 
 #define gram16 gram_nb<16, EIG_VP>
 #define rowmul16 rowmul_nb<16, EIG_VP>
+// LDS head of the per-split kernels: EigShared, then EigSpec (k_eig_rr's second Jacobi problem), then the R x 16 block
+#define EIG_HEAD_BYTES ((((sizeof(EigShared) + 15) & ~(size_t)15)) + ((sizeof(EigSpec) + 15) & ~(size_t)15))
 #define ritz_orth16 ritz_orth_nb<16, EIG_VP>
 #define orth_near16 orth_near_nb<16, EIG_VP>
 
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_init(const SplitDev* __rest
                                                           const int* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     EigShared& sh = *reinterpret_cast<EigShared*>(smem_raw);
-    double* V = reinterpret_cast<double*>(smem_raw + ((sizeof(EigShared) + 15) & ~(size_t)15));
+    double* V = reinterpret_cast<double*>(smem_raw + EIG_HEAD_BYTES);
     const int sid = order[blockIdx.x];  // heaviest splits first
     const SplitDev& sp = splits[sid];
     const int R = min(dims[sid].x, sp.rcap);
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_rr(const SplitDev* __restri
                                                         const int* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     EigShared& sh = *reinterpret_cast<EigShared*>(smem_raw);
-    double* V = reinterpret_cast<double*>(smem_raw + ((sizeof(EigShared) + 15) & ~(size_t)15));
+    double* V = reinterpret_cast<double*>(smem_raw + EIG_HEAD_BYTES);
     const int sid = order[blockIdx.x];
     EigState st = states[sid];
     if (st.done) return;
@@ -237,7 +239,14 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_rr(const SplitDev* __restri
     STAMP(1);
     proj_first_power<EIG_VP>(V, Rp, Vt, vp, sh);  // G1 = V^T G V on the block that produced Y (kept for the final score)
     STAMP(4);
-    ritz_orth16(V, Rp, sh);  // Ritz values (sh.top4) + next orthonormal block in one pass
+    // the (symmetrised) first-power projection goes to wave 1's Jacobi, which runs next to the G^2 Jacobi of wave 0
+    EigSpec& spec = *reinterpret_cast<EigSpec*>(smem_raw + ((sizeof(EigShared) + 15) & ~(size_t)15));
+    if (threadIdx.x < 256) {
+        const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+        spec.H[i * EIG_VP + j] = 0.5 * (sh.G1[i * EIG_VP + j] + sh.G1[j * EIG_VP + i]);
+    }
+    __syncthreads();
+    ritz_orth_nb<16, EIG_VP>(V, Rp, sh, &spec);  // Ritz values (sh.top4) + next orthonormal block in one pass
     STAMP(2);
     st.it += 1;
     st.top4 = sh.top4;
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_rr(const SplitDev* __restri
     }
 #endif
     // (the score comes from the first-power Ritz values of the same subspace; sets st.top4)
-    if (accept_first_power(g2_conv, g2_sum, st, sh)) {
+    if (accept_first_power(g2_conv, g2_sum, st, sh, &spec)) {
         STAMP(5);
         if (threadIdx.x == 0) {
             st.done = 1;
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_finish(const SplitDev* __re
                                                             const int* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     EigShared& sh = *reinterpret_cast<EigShared*>(smem_raw);
-    double* V = reinterpret_cast<double*>(smem_raw + ((sizeof(EigShared) + 15) & ~(size_t)15));
+    double* V = reinterpret_cast<double*>(smem_raw + EIG_HEAD_BYTES);
     const int sid = order[blockIdx.x];
     EigState st = states[sid];
     if (st.done) return;
@@ -373,7 +382,7 @@ static int launch_eigen_t(sp_ctx* ctx, const SplitDev* splits_dev, const std::ve
     double* vt = reinterpret_cast<double*>(ctx->eigws.as<unsigned char>() + st_bytes);
     double* yp = vt + ev_elems;
     PhaseScope ps(ctx, SP_PHASE_EIGEN);
-    const size_t lds_head = (sizeof(EigShared) + 15) & ~(size_t)15;
+    const size_t lds_head = EIG_HEAD_BYTES;
     const size_t lds = lds_head + (size_t)maxr * EIG_VP * sizeof(double);
     static size_t attr = 0;
     if (lds > attr) {

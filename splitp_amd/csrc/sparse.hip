@@ -1153,7 +1153,15 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             const int p0 = desc_r[idx], p1 = desc_r[idx + 1];
             for (int e = p0 + (int)threadIdx.x; e < p1; e += SPK_THREADS) {
                 const u32 v = csr_ent[e];
-                Wb[(v & 0xFFFFu) * w_rs + k * w_cs] = (double)(v >> 16);
+                const u32 mn = v & 0xFFFFu;
+                // A count >= 2^16 enters the table as several consecutive rows (pieces <= 65535) of one cell: they sit next
+                // to each other in the list (stable sort) and their SUM belongs here.  Rounds 1 - 2 let every piece store
+                // its own value - whichever thread came last won, the start block differed from process to process and
+                // with it the last bits of such tables' scores (randomised sweep: up to 3.6e-10 apart on tiny scores).
+                if (e > p0 && (csr_ent[e - 1] & 0xFFFFu) == mn) continue;   // a further piece: summed by the first one's thread
+                double c = (double)(v >> 16);
+                for (int f = e + 1; f < p1 && (csr_ent[f] & 0xFFFFu) == mn; ++f) c += (double)(csr_ent[f] >> 16);
+                Wb[mn * w_rs + k * w_cs] = c;
             }
         }
         __syncthreads();
@@ -1188,7 +1196,9 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             for (int ww = 0; ww < SPK_WAVES; ++ww) top4 += sh.red[ww];
             __syncthreads();   // spk_gram reuses sh.red: nobody may still be summing it (a rare race, caught after 36 rounds)
             spk_gram(V, R, v_rs, v_cs, sh);                  // Y^T Y = V^T G^2 V: its eigenvalues are the squared Ritz values
-            spk_chol_factor(sh, it >= 4);
+            // (S holds SQUARED Ritz values here: the cheap bound suffices when rest^2 <= 0.09 of it, i.e. rest <= 0.3 sqrt)
+            const double rest_s = trace - top4;
+            spk_chol_factor(sh, it >= 4, rest_s > 0 ? rest_s * rest_s * (1.0 / 0.3) : 0.0);
             if (spk_converged(top4, sqrt(sh.L[11]), trace, it, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
                 break;

@@ -1680,3 +1680,38 @@ def test_score_all_splits_shards(sp, golden):
     assert np.abs(batch.score_all_splits_shard(dev, _lib.SP_METHOD_FLATTENING, False, None, 0, 1)[0] - g["scores"]).max() <= SCORE_TOL
     one_class, _ = batch.score_all_splits_shard(dev, _lib.SP_METHOD_FLATTENING, False, 4, 1, 3)
     assert np.array_equal(one_class, sp.score_all_splits(dev, size=4)[1::3])
+
+
+def test_regress_stalled_block_is_not_accepted(sp):
+    """Randomised sweep, seed 9100 (round 2): 8 taxa, 8 patterns, the 4|4 split below flattens to a 5 x 7 matrix with
+    squared singular values 585.0, 433, 2, 1, 0.985.  The 4-wide block stalls on {1, 2, 3, 5} (the 4th direction is an
+    isolated cell the start block barely sees, and 0.985 / 1 per half product never catches up); the stop rule's estimate of
+    the block's smallest Ritz value came from inverse iteration started at (1, 1, 1, 1), which the smallest eigenvector had
+    turned orthogonal to - the next eigenvalue came back, the gap guard passed and a score 2.4e-4 off was accepted as
+    converged.  The estimate is certified now (S - 0.9 mu I positive definite): the split goes down the chain instead."""
+    n = 8
+    names = taxa_names(n)
+    pats = ['0000000000000000', '0000000001000000', '0000000001000001', '0000010100000100', '0000010101000100',
+            '0101000001010001', '0101010100010101', '0101010101010101']
+    keys = np.array([int(p, 2) for p in pats], dtype=np.uint64)
+    counts = np.array([24, 3, 1, 1, 1, 1, 12, 17], dtype=np.int64)
+    a, b = [2, 5, 6, 7], [0, 1, 3, 4]
+    split = (tuple(names[t] for t in a), tuple(names[t] for t in b))
+    M = O.reduced_flattening_packed(keys, counts.astype(np.float64), n, a, b)[0]
+    assert M.shape == (5, 7)
+    want = O.dense_split_score(M)
+    assert abs(want - 0.031038601176007503) < 1e-15
+    dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=int(counts.sum()), taxa=names)
+    for route in ("auto", "dense"):
+        got, st = sp.score_splits(dev, [split], route=route, return_status=True)
+        assert abs(got[0] - want) <= SCORE_TOL and (st[0] & 3) == 0, (route, got[0], want, hex(int(st[0])))
+    # every split of the table, and the same table with counts beyond 16 bits (pieces of one cell in the lists)
+    splits = list(sp.all_splits(names))
+    for scale in (1, 70_000):
+        d2 = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts * scale, n_sites=int(counts.sum()) * scale, taxa=names)
+        got = sp.score_splits(d2, splits)
+        for i, (x, y) in enumerate(splits):
+            Mi = O.reduced_flattening_packed(keys, (counts * scale).astype(np.float64), n, [names.index(t) for t in x],
+                                             [names.index(t) for t in y])[0]
+            w = 0.0 if min(Mi.shape) <= 4 else O.dense_split_score(Mi)
+            assert abs(got[i] - w) <= SCORE_TOL or abs(got[i] ** 2 - w ** 2) <= 4e-15, (scale, i, got[i], w)
