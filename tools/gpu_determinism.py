@@ -14,6 +14,7 @@ bad = 0; t0 = time.time()
 for trial in range(ntr):
     n = int(rng.integers(4, nmax + 1)); length = int(rng.choice([10, 60, 400, 2500, 20000])); letters = int(rng.choice([2, 3, 4, 4]))
     keys, counts = _copy_mutate_table(rng, n, length, letters)
+    if trial % 3 == 0: counts = counts * int(rng.choice([300, 70_000]))   # counts beyond 16 bits: pieces of one cell in the lists
     names = taxa_names(n)
     splits = list(sp.all_splits(names))
     if len(splits) > 200:
