@@ -1147,21 +1147,37 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
                 if (m == top_row[k]) sh.bucket[k] = (u32)idx;
         }
         __syncthreads();
+        // A count >= 2^16 enters the table as several rows (pieces <= 65535) of ONE cell, and the SUM of the pieces belongs
+        // into W.  Rounds 1 - 2 let every piece store its own value - whichever thread came last won, the start block
+        // differed from run to run and with it the last bits of such tables' scores (randomised sweep: up to 3.6e-10
+        // apart on scores of 1e-5).  Tables with pieces therefore clear the cells first and ADD: the values are integers,
+        // so the fp64 atomic sum is exact in any order (the pieces need not even sit next to each other in the list).
+        if ((u32)Di != sh.ntab) {   // (uniform)
 #pragma unroll
-        for (int k = 0; k < SPK_NB; ++k) {
-            const int idx = (int)sh.bucket[k];
-            const int p0 = desc_r[idx], p1 = desc_r[idx + 1];
-            for (int e = p0 + (int)threadIdx.x; e < p1; e += SPK_THREADS) {
-                const u32 v = csr_ent[e];
-                const u32 mn = v & 0xFFFFu;
-                // A count >= 2^16 enters the table as several consecutive rows (pieces <= 65535) of one cell: they sit next
-                // to each other in the list (stable sort) and their SUM belongs here.  Rounds 1 - 2 let every piece store
-                // its own value - whichever thread came last won, the start block differed from process to process and
-                // with it the last bits of such tables' scores (randomised sweep: up to 3.6e-10 apart on tiny scores).
-                if (e > p0 && (csr_ent[e - 1] & 0xFFFFu) == mn) continue;   // a further piece: summed by the first one's thread
-                double c = (double)(v >> 16);
-                for (int f = e + 1; f < p1 && (csr_ent[f] & 0xFFFFu) == mn; ++f) c += (double)(csr_ent[f] >> 16);
-                Wb[mn * w_rs + k * w_cs] = c;
+            for (int k = 0; k < SPK_NB; ++k) {
+                const int idx = (int)sh.bucket[k];
+                const int p0 = desc_r[idx], p1 = desc_r[idx + 1];
+                for (int e = p0 + (int)threadIdx.x; e < p1; e += SPK_THREADS) Wb[(csr_ent[e] & 0xFFFFu) * w_rs + k * w_cs] = 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < SPK_NB; ++k) {
+                const int idx = (int)sh.bucket[k];
+                const int p0 = desc_r[idx], p1 = desc_r[idx + 1];
+                for (int e = p0 + (int)threadIdx.x; e < p1; e += SPK_THREADS) {
+                    const u32 v = csr_ent[e];
+                    atomicAdd(&Wb[(v & 0xFFFFu) * w_rs + k * w_cs], (double)(v >> 16));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SPK_NB; ++k) {
+                const int idx = (int)sh.bucket[k];
+                const int p0 = desc_r[idx], p1 = desc_r[idx + 1];
+                for (int e = p0 + (int)threadIdx.x; e < p1; e += SPK_THREADS) {
+                    const u32 v = csr_ent[e];
+                    Wb[(v & 0xFFFFu) * w_rs + k * w_cs] = (double)(v >> 16);
+                }
             }
         }
         __syncthreads();
