@@ -374,7 +374,7 @@ __device__ __forceinline__ void spk_wide_apply(double* X, int rows, int cs, cons
 
 // Rayleigh-Ritz + orthonormalisation of the fresh block X = op(X_in), X_in orthonormal: eigenvalues of X^T X are the
 // Ritz values of the operator's Gram form on span(X_in).  Out: sum of the 4 largest (top4), the 4th largest (th4), the
-// sum of all 8 (sum8).  X becomes orthonormal (dead directions - eigenvalue <= 1e-24 of the largest - become zero columns).
+// sum of all 8 (sum8).  X becomes orthonormal (dead directions - eigenvalue <= 1e-14 of the largest - become zero columns).
 __device__ __forceinline__ void spk_wide_ritz_orth(double* X, int rows, int cs, EigShared& esh, double& top4, double& th4,
                                                    double& sum8, double* th5_out = nullptr) {
     spk_wide_gram(X, rows, cs, esh);
@@ -403,7 +403,11 @@ __device__ __forceinline__ void spk_wide_ritz_orth(double* X, int rows, int cs, 
     if (th5_out) *th5_out = th5;
     if (threadIdx.x < SPK_WB * SPK_WB) {
         const int i = threadIdx.x / SPK_WB, j = threadIdx.x % SPK_WB;
-        const double rj = (esh.theta[j] > 1e-24 * tmax && esh.theta[j] > 0) ? 1.0 / sqrt(esh.theta[j]) : 0.0;
+        // dead direction = eigenvalue inside the rounding noise of X^T X (eps |X|^2 ~ 1e-16 tmax): zero column.  (The
+        // threshold was 1e-24 tmax until a randomised sweep of round 2: an 8-wide block in a 7-row space has a direction
+        // of eigenvalue 0 that came out of the Jacobi as +8e-18 tmax, its column was scaled by 1e9, the polish diverged
+        // to inf, every Ritz value became 0 and a score of 1.0 left as "converged".)
+        const double rj = (esh.theta[j] > 1e-14 * tmax && esh.theta[j] > 0) ? 1.0 / sqrt(esh.theta[j]) : 0.0;
         esh.T[i * EIG_VP + j] = esh.Q[i * EIG_VP + j] * rj;
     }
     __syncthreads();
@@ -461,7 +465,12 @@ __device__ __forceinline__ bool spk_wide_converged(double s4, double th4, double
                 conv = k >= 6 && (delta <= 0.1 * tol || tail <= 0.1 * tol);
             }
             const bool fifth_out_of_reach = d5 <= tol || th5 + 4.0 * d5 < th4;
-            conv = conv && fifth_out_of_reach;
+            conv = conv && fifth_out_of_reach && s4 > 0 && th4 > 0;   // (a block that collapsed to zeros / nan is never a result)
+#ifdef SPK_DEBUG_CONV
+            if (threadIdx.x == 0)
+                printf("wide k %d s4/trace %.12f th4/s %.4e th5/s %.4e sum8/trace %.12f delta/s %.3e rho_b %.4f conv %d\n", k, s4 / trace,
+                       th4 / s4, th5 / s4, sum8 / trace, delta / s4, rho_b, (int)conv);
+#endif
         }
     }
     prev_ratio = ratio;

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(SUB_WAVES * 64) void k_subscore(const void* __restr
     }
     const int half = re / 2;
     int sweep = 0;
+    double prev_off = 1e300;
     for (; sweep < 30; ++sweep) {
         double off = 0, dg = 0;
         for (int e = lane; e < re * re; e += 64) {
@@ -271,7 +272,13 @@ __global__ __launch_bounds__(SUB_WAVES * 64) void k_subscore(const void* __restr
             off += __shfl_xor(off, d, 64);
             dg += __shfl_xor(dg, d, 64);
         }
-        if (!(off > 1e-30 * dg)) break;
+        // converged: the off-diagonal mass is below 1e-15 of the diagonal's - or it has reached its rounding floor: the
+        // entries of a 22 x 22 ... 49 x 49 block carry ~eps |G| each, their squares sum to more than 1e-30 of the diagonal,
+        // and the sweeps ran to the cap of 30 with a spurious "not converged" flag on every split of such a table
+        // (randomised sweep of round 2, forced onto this kernel at 14 - 20 taxa; the values were right to 1e-12).  Jacobi
+        // converges quadratically, so a sweep that no longer shrinks a small off-diagonal mass tenfold has hit that floor.
+        if (!(off > 1e-30 * dg) || (off <= 1e-24 * dg && off > 0.1 * prev_off)) break;
+        prev_off = off;
         for (int round = 0; round < re - 1; ++round) {
             // rotation parameters for all pairs first (they read the pre-round matrix)
             // pair pi: (re-1, round) for pi = 0, else ((round+pi) % (re-1), (round-pi) mod (re-1))
