@@ -267,6 +267,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
         spk_chol_factor(sh, false);
         spk_orth(V, R, 4, 1, sh);
         double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0, prev_th5 = 0, prev_d5 = 0;
+        int wide_settled = 0;
         int it = 0, conv = 0;
         for (it = 1; it <= SPKB_MAXHALF; ++it) {
             const bool odd = it & 1;   // odd: W = C^T V (column order)   even: V = C W (row order)
@@ -310,9 +311,9 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
                     else
                         spkb_product<CT, false>(keyr, minr, cntr, D, W8 + (size_t)cb * Wp, Wp, V8 + (size_t)cb * Vp, Vp, R, pt);
                 }
-                double th5;
-                spk_wide_ritz_orth(X, rows, xcs, esh, top4, th4, sum8, &th5);
-                if (spk_wide_converged(top4, th4, sum8, trace, wit, prev_sum, prev_delta, prev_ratio, th5, prev_th5, prev_d5)) {
+                double th5, thmin;
+                spk_wide_ritz_orth(X, rows, xcs, esh, top4, th4, sum8, &th5, &thmin);
+                if (spk_wide_converged(top4, th4, sum8, trace, wit, prev_sum, prev_delta, prev_ratio, th5, prev_th5, prev_d5, thmin, wide_settled)) {
                     conv = 1;
                     break;
                 }
