@@ -1735,3 +1735,33 @@ def test_split_counts_are_reproducible(sp):
             dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=int(counts.sum()), taxa=names)
             runs.append(sp.score_splits(dev, splits))
         assert np.array_equal(runs[0], runs[1], equal_nan=True) and np.array_equal(runs[0], runs[2], equal_nan=True), (trial, n, len(keys))
+
+
+def test_regress_wide_block_close_pair(sp):
+    """Two 7-taxon tables from the randomised sweeps of round 2 (seeds 37000 / 51000) whose flattenings have
+    lambda_4 / lambda_5 = 1.0001 ... 1.0003 behind three dominant values.  Forced onto the big-table form, its 8-wide
+    fallback block accepted sums whose 4th value sat on lambda_5 (the direction of lambda_4 still creeping up in 5th
+    place) or that missed one direction of the pair altogether (amplitude 1e-8 in the guard columns: nothing moves for
+    dozens of half products, every test passes, error bound included): scores 3e-6 off, status "converged".  The 5th
+    value's reach is now the geometric tail of its own steps and the verdict has to last as long as such a direction needs
+    to grow into view."""
+    import os
+
+    from tests.conftest import GOLDEN
+
+    d = np.load(os.path.join(GOLDEN, "regress_wide_close_pair.npz"))
+    for tag in ("a", "b"):
+        n = int(d[tag + "_n"])
+        names = taxa_names(n)
+        keys, counts = d[tag + "_keys"], d[tag + "_counts"]
+        splits = list(sp.all_splits(names))
+        pick = [splits[int(i)] for i in d[tag + "_splits"]]
+        dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=int(counts.sum()), taxa=names)
+        got0 = sp.score_splits(dev, pick)                       # default chain
+        dev.ctx.set_option("force_big", 1)
+        try:
+            got1, st1 = sp.score_splits(dev, pick, return_status=True)
+        finally:
+            dev.ctx.set_option("force_big", 0)
+        assert np.abs(got0 - d[tag + "_want"]).max() <= SCORE_TOL, (tag, got0, d[tag + "_want"])
+        assert np.abs(got1 - d[tag + "_want"]).max() <= SCORE_TOL and not np.any(st1 & 3), (tag, got1, d[tag + "_want"], st1)
