@@ -298,6 +298,8 @@ def main():
     ap.add_argument("--no-hipri", action="store_true", help="RCCL stream at normal priority (diagnostic)")
     ap.add_argument("--route", default="auto", choices=["auto", "dense", "sparse"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline-block", action="store_true",
+                    help="skip the north_star_pipeline block (30 steps of the dense route after the timed region of the default run)")
     ap.add_argument("--cpu-budget", type=float, default=170.0, help="seconds per CPU leg (all 501 splits take ~60-120 s)")
     args = ap.parse_args()
 
@@ -607,7 +609,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if (shard_splits or (wl_aligns > 1 and args.alignments == 0)) else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl_text, "route": args.route, "alignments_per_rank_per_step": n_al_rank,
+            "config": {"workload": wl_text, "workload_key": args.workload, "route": args.route, "alignments_per_rank_per_step": n_al_rank,
                        "lanes": n_lanes, "splits_per_alignment": n_splits_total, "splits_this_rank": n_mine,
                        "patterns": n_patterns, "parallelism": par, "unconverged_splits_in_timed_region": unresolved[0]},
             "roofline": roof,

@@ -40,6 +40,25 @@ SYMBOLS = (
 )
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources the shared library is built from (csrc/*.hip, csrc/*.h and the
+    ABI header, in name order).  tools/pmc_summarise.py stamps every PMC record under profiles/ with it and bench.py
+    prints a counter-based roofline fraction only when the stamp equals the hash of the sources in the tree - a counter
+    profile of an older kernel must not describe a newer one."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "splitp_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 class SplitPDeviceError(RuntimeError):
     """The HIP library is missing / failed, or no GPU is visible."""
 

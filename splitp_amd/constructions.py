@@ -55,28 +55,46 @@ def flattening(split, pattern_probabilities, flattening_format=FlatFormat.sparse
 
 
 class Flattening(np.ndarray):
-    """The reduced flattening as the reference returns it - a float64 ndarray - that also remembers where it came from:
-    (device-resident alignment, split).  `split_score(F)` then scores the split on the device from the resident table
-    instead of uploading F again ("API impedance"): the unchanged README loop
-    `split_score(flattening(split, table, FlatFormat.reduced))` keeps its semantics and loses the second PCIe trip.
+    """The reduced flattening as the reference returns it - a fresh, WRITABLE float64 ndarray (constructions.py:51-55) -
+    that also remembers where it came from: (device-resident alignment, split).  `split_score(F)` then scores the split on
+    the device from the resident table instead of uploading F again ("API impedance"): the unchanged
+    README loop `split_score(flattening(split, table, FlatFormat.reduced))` keeps its semantics and loses the second PCIe
+    trip.
 
-    The array is handed out READ-ONLY so that the remembered origin cannot go stale (the reference's array is writable:
-    `F.copy()` / `np.array(F)` give an ordinary writable ndarray, without the origin).  Anything derived from it - slices,
-    arithmetic, copies - is a plain result with no origin."""
+    The remembered origin cannot go stale: it carries a checksum of the contents (a dot product with a fixed vector of
+    pseudo-random weights, ~0.3 ms for a 690 x 690 matrix), recomputed when the origin is asked for - an array edited in
+    place (`F /= F.sum()`, `F[i, j] = 0`) no longer matches and is scored as the generic matrix it now is.  Anything
+    derived from it - slices, arithmetic, copies, pickles - is a plain result with no origin."""
 
     _sp_origin = None
+    _sp_check = None
 
     def __array_finalize__(self, obj):
         self._sp_origin = None
+        self._sp_check = None
 
     def __reduce__(self):      # pickling / copy.deepcopy: a plain array
         return np.asarray(self).__reduce__()
 
 
+_CHECK_WEIGHTS = np.zeros(0)
+
+
+def _content_check(arr):
+    """Order-sensitive checksum of a C-contiguous float64 array: dot product with fixed pseudo-random weights in [1, 2)."""
+    global _CHECK_WEIGHTS
+    flat = np.asarray(arr).reshape(-1)
+    if flat.size > _CHECK_WEIGHTS.size:
+        _CHECK_WEIGHTS = 1.0 + np.random.default_rng(0x5EED).random(max(flat.size, 1 << 20))
+    return float(np.dot(flat, _CHECK_WEIGHTS[:flat.size])), flat.size
+
+
 def flattening_origin(matrix):
     """(DeviceAlignment, order_a, order_b) if `matrix` is an untouched result of flattening(..., FlatFormat.reduced)."""
-    if type(matrix) is Flattening and matrix._sp_origin is not None and not matrix.flags.writeable:
-        return matrix._sp_origin
+    if type(matrix) is Flattening and matrix._sp_origin is not None and matrix.flags.c_contiguous:
+        if _content_check(matrix) == matrix._sp_check:
+            return matrix._sp_origin
+        matrix._sp_origin = None        # edited in place: from now on an ordinary matrix
     return None
 
 
@@ -90,7 +108,7 @@ def _reduced(al, oa, ob):
     _lib.check(lib.sp_flatten_reduced_fetch(al.handle, _lib._ptr(out, C.c_double), None, None))
     out = out.view(Flattening)
     out._sp_origin = (al, np.array(oa, dtype=np.int32), np.array(ob, dtype=np.int32))
-    out.flags.writeable = False
+    out._sp_check = _content_check(out)
     return out
 
 

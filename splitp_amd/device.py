@@ -267,8 +267,10 @@ _TABLE_CACHE_SLOTS = 4
 
 
 def _fingerprint(table):
-    vals = table.values()
-    return (len(table), hash(tuple(table)), float(sum(vals)), getattr(table, "taxa", None) and tuple(table.taxa))
+    # keys AND every value, position by position: a sum of the values would miss an in-place edit that moves mass between
+    # patterns (two probabilities swapped, a bootstrap refill of the same dict with the same number of sites) and the
+    # stale device table would answer for the old data - the reference reads the dict on every call (constructions.py:37-45)
+    return (len(table), hash(tuple(table)), hash(tuple(table.values())), getattr(table, "taxa", None) and tuple(table.taxa))
 
 
 def clear_table_cache():

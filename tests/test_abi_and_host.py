@@ -206,3 +206,39 @@ def test_simulation_host_logic():
         sim.tree_arrays(syn.balanced_tree(4), None, 0.1)          # nested tuples carry no matrices
     with pytest.raises(ValueError):
         sim.tree_arrays(syn.balanced_tree(4), jc)                 # ... and no branch lengths
+
+
+def test_table_fingerprint_sees_every_value():
+    """the drop-in path's table cache must miss on ANY in-place edit, also one that keeps the keys
+    and the total mass (values swapped, counts moved between patterns of a fixed-length dict)."""
+    from splitp_amd import device
+
+    table = {"ACGT": 0.25, "AAAA": 0.30, "CCCC": 0.20, "GGTT": 0.25}
+    fp = device._fingerprint(table)
+    assert device._fingerprint(table) == fp
+    table["ACGT"], table["AAAA"] = table["AAAA"], table["ACGT"]            # same keys, same sum
+    assert device._fingerprint(table) != fp
+    counts = {"ACGT": 5 / 20, "AAAA": 10 / 20, "CCCC": 5 / 20}
+    fp = device._fingerprint(counts)
+    counts["ACGT"], counts["CCCC"] = 3 / 20, 7 / 20                        # a bootstrap refill: 2 counts moved
+    assert device._fingerprint(counts) != fp
+
+
+def test_flattening_content_check_detects_edits():
+    """flattening(..., reduced) hands out a writable array (reference constructions.py:51); the remembered origin is
+    dropped as soon as the contents differ from what the device produced."""
+    from splitp_amd.constructions import Flattening, _content_check, flattening_origin
+
+    base = np.arange(12, dtype=np.float64).reshape(3, 4) / 7.0
+    F = base.copy().view(Flattening)
+    F._sp_origin = ("al", np.array([0, 1]), np.array([2, 3]))
+    F._sp_check = _content_check(F)
+    assert F.flags.writeable and flattening_origin(F) is F._sp_origin
+    assert flattening_origin(F.copy()) is None and flattening_origin(F * 1.0) is None and flattening_origin(F[:, 1:]) is None
+    F[1, 2], F[2, 1] = F[2, 1], F[1, 2]                                     # a swap keeps the plain sum
+    assert flattening_origin(F) is None and F._sp_origin is None
+    G = base.copy().view(Flattening)
+    G._sp_origin = ("al", None, None)
+    G._sp_check = _content_check(G)
+    G /= G.sum()
+    assert flattening_origin(G) is None

@@ -940,7 +940,7 @@ def test_dropin_loop_stays_on_the_device(sp, golden):
     scores = []
     for i in range(0, 501, 25):
         F = sp.flattening(splits[i], table, sp.FlatFormat.reduced)
-        assert type(F) is Flattening and isinstance(F, np.ndarray) and F.dtype == np.float64 and not F.flags.writeable
+        assert type(F) is Flattening and isinstance(F, np.ndarray) and F.dtype == np.float64 and F.flags.writeable
         assert flattening_origin(F) is not None and flattening_origin(F)[0] is al1
         s = sp.split_score(F)
         assert isinstance(s, np.float64) and abs(s - g["scores"][i]) <= SCORE_TOL
@@ -952,8 +952,16 @@ def test_dropin_loop_stays_on_the_device(sp, golden):
             assert plain.flags.writeable and abs(sp.split_score(plain) - s) <= SCORE_TOL
             assert flattening_origin(F * 1.0) is None and flattening_origin(F[:, :]) is None
             assert flattening_origin(pickle.loads(pickle.dumps(F))) is None
-            with pytest.raises(ValueError):
-                F[0, 0] = 1.0
+            # the reference's array is writable (constructions.py:51): an in-place edit is allowed, and the edited array
+            # is scored as the matrix it now is (generic route), not as the split it came from
+            keep = F[0, 0]
+            F[0, 0] = keep + 0.5
+            assert flattening_origin(F) is None
+            edited = sp.split_score(F)
+            assert abs(edited - O.dense_split_score(np.asarray(F))) <= SCORE_TOL and abs(edited - s) > 1e-6
+            G = sp.flattening(splits[i], table, sp.FlatFormat.reduced)
+            G /= G.sum()                                        # the usual normalisation: scale-invariant score
+            assert flattening_origin(G) is None and abs(sp.split_score(G) - s) <= SCORE_TOL
     for fid in g["full_ids"]:
         F = sp.flattening(splits[int(fid)], table, sp.FlatFormat.reduced)
         assert np.array_equal(np.asarray(F), g[f"reduced_{int(fid)}"])
@@ -966,6 +974,20 @@ def test_dropin_loop_stays_on_the_device(sp, golden):
     assert al2 is not al1
     table[some] = table[some] / 2.0
     assert device.as_device_alignment(table) is al1 or len(device._TABLE_CACHE) <= device._TABLE_CACHE_SLOTS
+    # ... also when the edit keeps the keys AND the total mass (two values swapped / mass moved between two
+    # patterns - a bootstrap refill of the same dict): the fingerprint covers every value, so this is a miss as well
+    al_before = device.as_device_alignment(table)
+    ks = list(table)
+    k1 = ks[0]
+    k2 = next(k for k in ks[1:] if table[k] != table[k1])
+    before = sp.score_splits(table, splits[0:501:50])
+    table[k1], table[k2] = table[k2], table[k1]
+    al_swapped = device.as_device_alignment(table)
+    assert al_swapped is not al_before
+    swapped = dict(table)
+    ref = np.array([O.dense_split_score(O.flattening(s_, swapped, "reduced")) for s_ in splits[0:501:250]])
+    got = sp.score_splits(table, splits[0:501:50])
+    assert np.max(np.abs(got[::5] - ref)) <= SCORE_TOL and not np.array_equal(got, before)
 
 
 def test_config5_shape_12_taxa(sp):
