@@ -782,7 +782,9 @@ extern "C" int sp_plan_create(sp_ctx* ctx, int n_taxa, const int32_t* split_taxa
     pl->splits = hp.splits;
     pl->taxa.assign(split_taxa, split_taxa + (size_t)n_splits * n_taxa);
     pl->a.assign(split_a, split_a + n_splits);
-    // heaviest first: the larger the smaller side, the longer the workgroup runs (stable: ties keep the list order)
+    // heaviest first: the larger the smaller side, the longer the workgroup runs (stable: ties keep the list order).
+    // (Round 3 tried the measured per-class cost instead - 4|6 before 5|5 on 10 taxa, 56 against 51 us - and the pipelined
+    // benchmark got 0.5 % slower, 0.1011 against 0.1006 ms per step: kept as it was.)
     std::vector<int> order((size_t)n_splits);
     for (int64_t i = 0; i < n_splits; ++i) order[i] = (int)i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return pl->splits[x].nr > pl->splits[y].nr; });

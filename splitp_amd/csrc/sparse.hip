@@ -469,6 +469,145 @@ __device__ __forceinline__ void spk_build_pair(const u32* pc, const CT* cnt, int
     __syncthreads();
 }
 
+// Gram path (short row side): group the entries by column with ONE shared set of packed 16-bit counters - no stable sort,
+// no wave-private rows, all 16 waves at work.  The exact Gram matrix G = C C^T is then accumulated with INTEGER atomics over
+// the pairs of entries inside every column, and an integer sum does not depend on the order of the entries inside a column
+// nor on the order of the columns: whatever order the atomics below resolve in, G comes out the same bit for bit.  (The
+// general path's lists feed floating-point sums and therefore need the stable counting sort above.)
+//   entry word  = row | count << 16
+//   position word = index of the entry inside its column | (column size - 1) << 8      (column size <= R <= 256)
+//   ENT64 (lists in global memory): both in ONE 8-byte word per list position, ent64[pos] = entry | position word << 32 -
+//   one scattered 8-byte store per entry instead of a 4-byte and a 2-byte one; otherwise ent[pos] and pinfo[pos].
+//   csz / ccur: (nmajor + 2) / 2 words of packed counters each (sizes / fill cursors, zeroed here), gstart: nmajor + 2
+//   start offsets (all three build-time only)
+// Columns are laid out by SIZE CLASS, largest first (> 64, 17 .. 64, 5 .. 16, <= 4 entries; index order inside a class): the
+// pair loop gives every list position its column's size / 2 steps, so the 64 consecutive positions of a wave should belong
+// to columns of one size (a wave that mixes a 60-entry column with singletons runs 31 steps for a few lanes' sake).
+// *used = number of non-empty columns.  All-global form: the counters may live in global memory (atomics are read back with
+// agent-scope loads).
+template <typename CT, bool ENT64>
+__device__ __forceinline__ void spk_group_cols(const u32* pc, const CT* cnt, int D, int nmajor, u32* csz, u32* ccur,
+                                               unsigned short* gstart, u32* ent, unsigned short* pinfo, u64* ent64,
+                                               int* used, SpkShared& sh) {
+    constexpr bool CNT_GLOBAL = !std::is_same<CT, unsigned short>::value;
+    const int words = (nmajor + 2) >> 1;
+    // lane-contiguous sub-chunks of the table (consecutive entries often share their column: see spk_build_list), odd
+    // length so that the lanes of a load spread over the LDS banks
+    const int q = ((D + SPK_THREADS - 1) / SPK_THREADS) | 1;
+    const int lo = min(D, (int)threadIdx.x * q), hi = min(D, lo + q);
+    for (int i = threadIdx.x; i < words; i += SPK_THREADS) {
+        csz[i] = 0;
+        ccur[i] = 0;
+    }
+    __syncthreads();
+    SSTAMP(55);
+    for (int i = lo; i < hi; ++i) {                        // pass A: column sizes
+        const int col = (int)(pc[i] & 0xFFFF);
+        atomicAdd(&csz[col >> 1], 1u << (16 * (col & 1)));
+    }
+    u32 cpre[SPK_MAXQ];
+    if (CNT_GLOBAL) {   // counts of this thread's first entries for pass B: issued now, used after the scans
+#pragma unroll
+        for (int t = 0; t < SPK_MAXQ; ++t) cpre[t] = (t < q && lo + t < hi) ? (u32)cnt[lo + t] : 0u;
+    }
+    __syncthreads();
+    SSTAMP(50);
+    {   // start offsets of all four classes from ONE block scan: the class sums travel as four 16-bit fields of a 64-bit
+        // word (every class total is <= D <= 65535: no field carries into the next), the count of non-empty columns as a
+        // 32-bit word next to it (four scans, one per class, cost 14 - 40 k cycles; this one 4 - 10 k)
+        const int pw = (words + SPK_THREADS - 1) / SPK_THREADS;
+        const int w0 = min(words, (int)threadIdx.x * pw), w1 = min(words, w0 + pw);
+        auto cls_sh = [](u32 n) { return n > 64u ? 0 : (n > 16u ? 16 : (n > 4u ? 32 : 48)); };
+        u64 sum = 0;
+        u32 nz = 0;
+        for (int wi = w0; wi < w1; ++wi) {
+            const u32 v = spk_aload(csz + wi);
+            const u32 a = v & 0xFFFFu, b = v >> 16;
+            sum += ((u64)a << cls_sh(a)) + ((u64)b << cls_sh(b));
+            nz += (a != 0) + (b != 0);
+        }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        u64 x = sum;
+        u32 xn = nz;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u64 y = __shfl_up(x, d, 64);
+            const u32 yn = __shfl_up(xn, d, 64);
+            if (lane >= d) {
+                x += y;
+                xn += yn;
+            }
+        }
+        u64* const wsum = reinterpret_cast<u64*>(sh.red);   // (16 + 16 words of the reduction scratch)
+        u32* const wnz = reinterpret_cast<u32*>(sh.red + SPK_WAVES);
+        __syncthreads();
+        if (lane == 63) {
+            wsum[w] = x;
+            wnz[w] = xn;
+        }
+        __syncthreads();
+        u64 before = 0, total = 0;
+        u32 tot_nz = 0;
+#pragma unroll
+        for (int i = 0; i < SPK_WAVES; ++i) {
+            const u64 sv = wsum[i];
+            if (i < w) before += sv;
+            total += sv;
+            tot_nz += wnz[i];
+        }
+        const u64 excl = before + x - sum;   // exclusive prefix of this thread, per class field
+        // class bases: class 0 starts at 0, class c after the totals of the classes before it
+        const u32 t0 = (u32)(total & 0xFFFFu), t1 = (u32)((total >> 16) & 0xFFFFu), t2 = (u32)((total >> 32) & 0xFFFFu);
+        u32 run0 = (u32)(excl & 0xFFFFu), run1 = t0 + (u32)((excl >> 16) & 0xFFFFu), run2 = t0 + t1 + (u32)((excl >> 32) & 0xFFFFu),
+            run3 = t0 + t1 + t2 + (u32)(excl >> 48);
+        auto start_of = [&](u32 n) {
+            u32 st;
+            if (n > 64u) { st = run0; run0 += n; }
+            else if (n > 16u) { st = run1; run1 += n; }
+            else if (n > 4u) { st = run2; run2 += n; }
+            else { st = run3; run3 += n; }
+            return st;
+        };
+        for (int wi = w0; wi < w1; ++wi) {
+            const u32 v = spk_aload(csz + wi);
+            gstart[2 * wi] = (unsigned short)start_of(v & 0xFFFFu);
+            gstart[2 * wi + 1] = (unsigned short)start_of(v >> 16);
+        }
+        if (threadIdx.x == 0 && used) *used = (int)tot_nz;
+        __syncthreads();
+    }
+    SSTAMP(51);
+    auto place = [&](int i, u32 c) {                       // pass B: placement
+        const u32 v = pc[i];
+        const int col = (int)(v & 0xFFFF);
+        const u32 old = atomicAdd(&ccur[col >> 1], 1u << (16 * (col & 1)));
+        const u32 idx = (old >> (16 * (col & 1))) & 0xFFFFu;
+        const u32 n = (spk_aload(csz + (col >> 1)) >> (16 * (col & 1))) & 0xFFFFu;
+        const int pos = (int)gstart[col] + (int)idx;
+        const u32 e = (v >> 16) | (c << 16), pi = idx | ((n - 1u) << 8);
+        if (ENT64) {
+            ent64[pos] = (u64)e | ((u64)pi << 32);
+        } else {
+            ent[pos] = e;
+            pinfo[pos] = (unsigned short)pi;
+        }
+    };
+    if (CNT_GLOBAL) {
+        for (int t0 = 0; t0 < q; t0 += SPK_MAXQ) {
+            if (t0 > 0) {
+#pragma unroll
+                for (int t = 0; t < SPK_MAXQ; ++t) cpre[t] = (t0 + t < q && lo + t0 + t < hi) ? (u32)cnt[lo + t0 + t] : 0u;
+            }
+#pragma unroll
+            for (int t = 0; t < SPK_MAXQ; ++t)
+                if (t0 + t < q && lo + t0 + t < hi) place(lo + t0 + t, cpre[t]);
+        }
+    } else {
+        for (int i = lo; i < hi; ++i) place(i, (u32)cnt[i]);
+    }
+    __syncthreads();
+}
+
 // out[m][0..3] = sum over the entries e of major group m of count_e * in[minor_e][0..3].
 // One LANE handles an entry for all four columns: one entry word, one address, one count conversion and four gathers
 // (two ds_read2_b64) per entry - a quarter of the VALU work of a lane-per-column layout, same LDS traffic.  Groups are
@@ -683,25 +822,54 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
 #define SPK_RAW_MAX 5
 #endif
     const bool raw_r = nr <= SPK_RAW_MAX, raw_c = nc <= SPK_RAW_MAX;
-    const int rwl = raw_r ? 0 : rw, cwl = raw_c ? 0 : cw;   // bitmap words in use
-    const int W = rwl + cwl;
+    const int rwl = raw_r ? 0 : rw;   // bitmap words in use on the row side
     const int Di = (int)D;
     // a-priori bounds on the matrix sizes (the actual sizes of compacted sides are known only after ranking)
     const int kc_cap = raw_c ? (1 << (2 * nc)) : (int)min((long long)D, nc >= 8 ? (long long)D : (1ll << (2 * nc)));
     const int r_cap = raw_r ? (1 << (2 * nr)) : (int)min((long long)D, nr >= 8 ? (long long)D : (1ll << (2 * nr)));
-    // (a table with split counts - several rows per pattern - can have more than R entries in a column, which the 8-bit
-    // sort counters of the small path do not hold: such tables take the general path)
-    const bool small_sure = r_cap <= SPK_SMALL_R && (u32)Di == sh.ntab && !wide_on;   // then no CSR list is needed
-    // plain LDS form: no copy of the counts in LDS - pass B of the list builds fetches them from the table in global
-    // memory (all of a lane's loads issued up front), which frees 2 D bytes for a second set of sort counters
+    // Gram path: the row side is short enough for the exact Gram matrix G = C C^T to sit in LDS and for the iteration to run
+    // on it densely; then no CSR list is needed and the CSC grouping needs no order (spk_group_cols).
+    //   small: up to SPK_SMALL_R (64) row ids, G as fp64 (integer accumulation in 32 or 64 bits)
+    //   mid:   up to SPK_MID_R (256) row ids, lists-in-global form only: G as the packed upper triangle of 32-bit integers,
+    //          131.6 KB at 256 rows (needs trace < 2^32) - the 4|8 splits of a 12-taxon table, whose column-side block W
+    //          (5000 ids x 4 x 8 bytes) does not fit the LDS
+    // (a table with split counts - several rows per pattern - pairs the pieces of one cell: such tables take the general path)
+    const bool g32 = sh.trace < (1ull << 32);
+    const bool small_sure = r_cap <= SPK_SMALL_R && (u32)Di == sh.ntab && !wide_on;
+    // (mid: exactly the raw 4-taxon row side, R = SPK_MID_R - its product runs without bounds checks)
+    const bool mid_sure = LISTS_GLOBAL && !W_GLOBAL && !small_sure && raw_r && r_cap == SPK_MID_R && (u32)Di == sh.ntab && g32 && !wide_on;
+    const bool gpath = small_sure || mid_sure;
+    // A column side of 10 and more taxa has too many possible ids for presence bitmaps in LDS (4^10 bits + rank prefixes =
+    // 196 KB: the 2|10 splits of a 12-taxon table used to fall through to the all-global form for them alone).  The Gram
+    // path needs no ORDER on the column ids, only equal ids for equal columns: an open-addressing hash table over the
+    // column keys hands out its slot numbers instead (H >= 1.125 D slots of 4 bytes; unused slots are empty columns).
+    // Plain LDS form (the fast kernel): its Gram path keeps round 2's STABLE list build (wave-private 8-bit counter rows,
+    // column pointers + column of every position) and leaves the order-free grouping, the hash relabelling and the packed
+    // G to the slow kernel's forms.  Measured on config 2: the new grouping makes the 2|8 and 3|7 splits 6.5 % faster when a
+    // launch holds one size class only, but the whole mixed launch 2.3 % slower (0.1025 against 0.1002 ms per step, three
+    // A/B rounds on one box) - the fast kernel grew from 240 to 292 KB of code and its general path, which decides the
+    // makespan of a launch, pays for that in instruction fetch.
+    constexpr bool GP_STABLE = !HBM && !LISTS_GLOBAL;
+    const bool hash_c = !HBM && !GP_STABLE && gpath && !raw_c && (size_t)cw * 12 > 49152;
+    int H = 1024;
+    while (H < Di + (Di >> 3) + 16) H <<= 1;
+    const int cwl = (raw_c || hash_c) ? 0 : cw;   // bitmap words in use on the column side
+    const int W = rwl + cwl;
+    // LDS forms keep no copy of the counts in LDS: pass B of the list builds fetches them from the table in global memory
+    // (all of a lane's loads issued up front), which frees 2 D bytes for a second set of sort counters
     constexpr bool PLAIN = !HBM && !LISTS_GLOBAL;
-    const size_t need_build = off + (LISTS_GLOBAL ? 0 : (size_t)(D + 8) * (small_sure ? 4 : 8)) + (size_t)D * (PLAIN ? 4 : 6) +
-                              (size_t)W * 12 + 4096 + 256;
+    // (general path with the lists in global memory: one list after the other with the counts staged next to the table,
+    // 8 + 16 counter rows, measured 89 k cycles for both lists of a 13.5 k-pattern table; counts fetched from global memory
+    // with 12 + 16 rows: 100 - 108 k; both lists side by side: 105 - 112 k)
+    const bool stage_cnt = HBM || (LISTS_GLOBAL && !gpath);
+    const size_t need_build = off + (LISTS_GLOBAL ? 0 : (size_t)(D + 8) * (gpath ? 4 : 8)) + (size_t)(D + 8) * (stage_cnt ? 6 : 4) +
+                              (size_t)W * 12 + (hash_c ? (size_t)H * 4 : 0) + 4096 + 256;
     if (D > 65535 || n > 16 || need_build + 2048 > cap) {
         if (threadIdx.x == 0) {
             scores[sid] = 0.0;
             status[sid] = 2;
         }
+        SFORM(1);
         return 2;
     }
     (void)kc_cap;
@@ -718,19 +886,22 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             scores[sid] = 0.0;
             status[sid] = 2;
         }
+        SFORM(2);
         return 2;
     }
+    // (Gram path with the lists in global memory: ONE list of 8-byte words - entry + position word - over both list slots)
     u32* csc_ent = LISTS_GLOBAL ? reinterpret_cast<u32*>(lslab) : reinterpret_cast<u32*>(carve((size_t)(D + 8) * 4));
-    u32* csr_ent = small_sure ? nullptr
+    u64* const ent64 = LISTS_GLOBAL ? reinterpret_cast<u64*>(lslab) : nullptr;
+    u32* csr_ent = gpath ? nullptr
                               : (LISTS_GLOBAL ? reinterpret_cast<u32*>(lslab + list_bytes)
                                               : reinterpret_cast<u32*>(carve((size_t)(D + 8) * 4)));
-    if (threadIdx.x < 8) {
+    if (threadIdx.x < 8 && !gpath) {   // (the products' unpredicated tail reads)
         csc_ent[D + threadIdx.x] = 0;
         if (csr_ent) csr_ent[D + threadIdx.x] = 0;
     }
     const size_t off_after_lists = off;
-    u32* pc = reinterpret_cast<u32*>(carve((size_t)D * 4));
-    unsigned short* cnt = PLAIN ? nullptr : reinterpret_cast<unsigned short*>(carve((size_t)D * 2));
+    u32* pc = reinterpret_cast<u32*>(carve((size_t)(D + 8) * 4));
+    unsigned short* cnt = stage_cnt ? reinterpret_cast<unsigned short*>(carve((size_t)D * 2)) : nullptr;
     u64* bm = reinterpret_cast<u64*>(carve((size_t)W * 8));
     u32* pf = reinterpret_cast<u32*>(carve((size_t)W * 4));
     const int* shifts = sh.shifts;
@@ -739,21 +910,22 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     // tables (4 taxa each) built here - 3 look-ups + 2 ORs per pattern instead of 4 instructions per taxon (the
     // staging loop is instruction-bound: 16 waves share 4 SIMDs)
     u32* lut = reinterpret_cast<u32*>(carve(4 * 256 * 4));
+    u32* htab = hash_c ? reinterpret_cast<u32*>(carve((size_t)H * 4)) : nullptr;
     // The table's keys (and counts) come from global memory, SPK_SU loads in flight per thread; the plain LDS form issues
     // its first - for every table it can hold, only - batch HERE, before the look-up tables are built, and consumes it
     // after the barrier: under load a batch waits 4 - 5 k cycles for the L2, and the old 8-load batches took two of them
     // for a 8.2 k-pattern table (34 patterns in the second).
-    constexpr int SPK_SU = PLAIN ? 10 : 8;
+    constexpr int SPK_SU = PLAIN ? 10 : (HBM ? 8 : 14);   // (lists-in-global forms: one batch for a 14 k-pattern table)
     u32 key[SPK_SU], cv[SPK_SU];
     auto load_batch = [&](int base0) {
 #pragma unroll
         for (int u = 0; u < SPK_SU; ++u) {
             const int i = base0 + u * SPK_THREADS + (int)threadIdx.x;
             key[u] = i < Di ? keys[i] : 0u;
-            if (!PLAIN) cv[u] = i < Di ? counts[i] : 0u;
+            if (!PLAIN) cv[u] = (stage_cnt && i < Di) ? counts[i] : 0u;
         }
     };
-    if (PLAIN) load_batch(0);
+    if (!HBM) load_batch(0);
     {
         for (int e = threadIdx.x; e < 1024; e += SPK_THREADS) {
             const int ch = e >> 8, v = e & 255;
@@ -771,7 +943,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     const bool wide_key = n > 12;   // bits 24..31 in use
     __syncthreads();   // bitmaps are zero
     for (int base0 = 0; base0 < Di; base0 += SPK_THREADS * SPK_SU) {
-        if (!PLAIN || base0 > 0) load_batch(base0);
+        if (HBM || base0 > 0) load_batch(base0);
 #pragma unroll
         for (int u = 0; u < SPK_SU; ++u) {
             const int i = base0 + u * SPK_THREADS + (int)threadIdx.x;
@@ -780,21 +952,23 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             if (wide_key) cell |= lut[768 + (key[u] >> 24)];
             const u32 r = cell >> (2 * nc), c = cell & cmask;
             pc[i] = both_raw ? ((r << 16) | c) : cell;
-            if (!PLAIN) cnt[i] = (unsigned short)cv[u];
+            if (!PLAIN && stage_cnt) cnt[i] = (unsigned short)cv[u];
             if (!raw_r) {   // presence bits (a plain read first saves most of the atomics)
                 const u64 rb = 1ull << (r & 63);
                 if (!(*(volatile u64*)(bm + (r >> 6)) & rb)) atomicOr(bm + (r >> 6), rb);
             }
-            if (!raw_c) {
+            if (!raw_c && !hash_c) {
                 const u64 cb = 1ull << (c & 63);
                 if (!(*(volatile u64*)(bm + rwl + (c >> 6)) & cb)) atomicOr(bm + rwl + (c >> 6), cb);
             }
         }
     }
     __syncthreads();
-    int dimsRC[2] = {1 << (2 * (raw_r ? nr : 0)), 1 << (2 * (raw_c ? nc : 0))};
+    if (hash_c)
+        for (int i = threadIdx.x; i < H; i += SPK_THREADS) htab[i] = 0;
+    int dimsRC[2] = {1 << (2 * (raw_r ? nr : 0)), hash_c ? H : 1 << (2 * (raw_c ? nc : 0))};
     for (int which = 0; which < 2; ++which) {
-        if (which ? raw_c : raw_r) continue;
+        if (which ? (raw_c || hash_c) : raw_r) continue;
         const int wbase = which ? rwl : 0, cntw = which ? cwl : rwl;
         const int per = (cntw + SPK_THREADS - 1) / SPK_THREADS;
         const int lo = min(cntw, (int)threadIdx.x * per), hi = min(cntw, lo + per);
@@ -822,8 +996,22 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
         }
         return true;
     };
-    if (degenerate(raw_r ? 5 : R, raw_c ? 5 : Kc)) return 0;
-    if (!both_raw) {   // compact coordinates in place: pc[i] = rr << 16 | cc (8 look-ups in flight per thread)
+    if (degenerate(raw_r ? 5 : R, (raw_c || hash_c) ? 5 : Kc)) return 0;
+    if (hash_c) {   // column id = slot of the column key in the hash table (empty = 0, key c stored as c + 1; nc <= 15)
+        for (int i = threadIdx.x; i < Di; i += SPK_THREADS) {
+            const u32 cell = pc[i];
+            const u32 r = cell >> (2 * nc), c = cell & cmask;
+            u32 slot = (c * 0x9E3779B1u) >> 7;
+            slot = (slot ^ (slot >> 11)) & (u32)(H - 1);
+            for (;;) {   // (H > D: an empty slot always turns up)
+                const u32 old = atomicCAS(&htab[slot], 0u, c + 1u);
+                if (old == 0u || old == c + 1u) break;
+                slot = (slot + 1u) & (u32)(H - 1);
+            }
+            pc[i] = ((raw_r ? r : bm_rank(bm, pf, r)) << 16) | slot;
+        }
+        __syncthreads();
+    } else if (!both_raw) {   // compact coordinates in place: pc[i] = rr << 16 | cc (8 look-ups in flight per thread)
         for (int base = 0; base < Di; base += SPK_THREADS * 8) {
             u32 cell[8], rr[8], cc[8];
 #pragma unroll
@@ -845,7 +1033,8 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
         }
         __syncthreads();
     }
-    const bool small = small_sure;   // (R <= 64 with a larger bound simply takes the general path)
+    const bool small = gpath;        // Gram path (either form of G); everything else is the general path
+    const bool mid = mid_sure;       // ... with G as a packed triangle of 32-bit integers
     const int Rp = (R + 3) & ~3;
     // group descriptors + permutations (now that R and Kc are known) are carved top-down from the end of LDS; the key
     // bitmaps are dead: the counting-sort counters start where they were
@@ -862,10 +1051,6 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     unsigned short* desc_r = small ? nullptr : carve_desc(1, (size_t)(R + 1) * 2);
     unsigned short* perm_c = small ? nullptr : carve_desc(2, (size_t)Kc * 2);
     unsigned short* perm_r = small ? nullptr : carve_desc(3, (size_t)R * 2);
-    // (small path: the column pointers and - below - the column of every list position; with the lists in global memory
-    // they go there as well, into two of the four descriptor slots: what stays in LDS then is the staged table, the sort
-    // counters and G, which is what lets the 3|9 splits of a 12-taxon table - 9 k columns - stay out of the all-global form)
-    unsigned short* csc_ptr = small ? carve_desc(0, (size_t)(Kc + 1) * 2) : nullptr;
     const size_t build_end = reinterpret_cast<unsigned char*>(bm) - base;
     // V and W are column-major: four arrays of Rp / Kcp doubles.  A lane's four gathers then go to four arrays -
     // measured 9 % faster than four consecutive doubles of one row (fewer LDS bank conflicts), and no row padding.
@@ -877,28 +1062,39 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     const int v_rs = 1, v_cs = Vp, w_rs = 1, w_cs = Kcp;
     const size_t base_iter = off_after_lists + (size_t)Vp * NBC * 8 + 16;
     const int Gp = R | 1;   // odd row pitch of the dense G: a pitch of 64 doubles puts every row on the same LDS bank
-    const size_t need_iter = base_iter + (small ? (size_t)R * Gp * 8 : ((W_GLOBAL ? 0 : (size_t)Kcp * NBC * 8)));
-    // small path: column of every CSC position (for the entry-parallel Gram below), carved from the top as well
-    unsigned short* colof = small ? carve_desc(2, (size_t)Di * 2) : nullptr;
-    // counters: rows of 16-bit (8-bit when a group cannot exceed 255 entries) fields
-    const bool bits8 = small;   // a column has at most R <= 64 entries
-    // every wave gets its own row when that fits (shorter chunks per lane), else the first SPK_SORT_WAVES waves sort
-    const size_t cw_c1 = (size_t)((Kc + (bits8 ? 3 : 1)) / (bits8 ? 4 : 2)) * 4, cw_r1 = (size_t)((R + 1) / 2) * 4;
+    const size_t gtri_bytes = ((size_t)R * (R + 1) / 2) * 4;   // mid: packed upper triangle, 32-bit cells
+    const size_t need_iter = base_iter + (small ? (mid ? gtri_bytes : (size_t)R * Gp * 8) : ((W_GLOBAL ? 0 : (size_t)Kcp * NBC * 8)));
+    // Gram path: index inside its column / column size of every list position (for the entry-parallel pair loop below);
+    // with the lists in global memory it goes there as well, into one of the four descriptor slots - what stays in LDS is
+    // the staged table, the counters and G
+    unsigned short* pinfo = (small && !LISTS_GLOBAL && !GP_STABLE) ? carve_desc(2, (size_t)Di * 2) : nullptr;
+    // (plain LDS form: column pointers and the column of every list position, see GP_STABLE)
+    unsigned short* csc_ptr = (small && GP_STABLE) ? carve_desc(0, (size_t)(Kc + 1) * 2) : nullptr;
+    unsigned short* colof = (small && GP_STABLE) ? carve_desc(2, (size_t)Di * 2) : nullptr;
+    // general path: wave-private counter rows of 16-bit fields; every wave gets its own row when that fits (shorter
+    // chunks per lane), else fewer waves sort.  Gram path: one shared row + the start offsets (spk_group_cols).
+    const size_t cw_c1 = small ? (GP_STABLE ? (size_t)((Kc + 3) / 4) * 4   // (8-bit fields: a column has at most R <= 64 entries)
+                                            : 2 * (size_t)((Kc + 2) / 2) * 4 + (((size_t)Kc + 2) * 2 + 15 & ~(size_t)15))
+                               : (size_t)((Kc + 1) / 2) * 4;
+    const size_t cw_r1 = (size_t)((R + 1) / 2) * 4;
     const size_t grp_r_probe = small ? 0 : (((size_t)R + 1) * 2 + 15) & ~(size_t)15;
     // All-global form: the sort counters - the only words of the build that take an atomic per entry - go to the
     // otherwise idle LDS when at least 4 wave rows fit (global atomics made the two list builds 78 % of a 4|8 split of
     // the 12-taxon table).
     const size_t lds_used = ((sizeof(SpkShared) + 15) & ~(size_t)15) + sizeof(EigShared) + 32;
     const size_t lds_free = HBM ? (size_t)SPK_LDS_BYTES - lds_used : 0;
-    const int ns_c_lds = HBM ? (int)min((size_t)SPK_WAVES, lds_free / max(cw_c1, (size_t)4)) : 0;
+    const int ns_c_lds = HBM ? (small ? (cw_c1 + 16 <= lds_free ? 4 : 0) : (int)min((size_t)SPK_WAVES, lds_free / max(cw_c1, (size_t)4))) : 0;
     const int ns_r_lds = (HBM && !small) ? (int)min((size_t)SPK_WAVES, lds_free / max(cw_r1, (size_t)4)) : 0;
     const bool cwc_lds = ns_c_lds >= 4, cwr_lds = ns_r_lds >= 4;
-    auto rows_that_fit = [&](size_t row_bytes, size_t extra) {   // 16, 8, 4, 2 or 1 wave-private counter rows
+    auto rows_that_fit = [&](size_t row_bytes, size_t extra) {   // wave-private counter rows: as many of the 16 as fit
         int ns = SPK_WAVES;
-        while (ns > 1 && build_end + (size_t)ns * row_bytes + extra + 16 > top) ns >>= 1;
+        while (ns > 1 && build_end + (size_t)ns * row_bytes + extra + 16 > top) --ns;
         return ns;
     };
-    const int ns_c = cwc_lds ? ns_c_lds : rows_that_fit(cw_c1, 0);
+    // (the group starts of the sequential CSC build sit behind its counter rows - general path, lists in global memory -
+    // and have to fit as well: without the allowance a side whose 16 rows just fitted was refused, hand-back to the all-global form)
+    const size_t grp_c_room = (small || (!LISTS_GLOBAL && ((size_t)Kc + 1) * 2 <= ((size_t)D + 8) * 4)) ? 0 : ((((size_t)Kc + 1) * 2 + 15) & ~(size_t)15) + 16;
+    const int ns_c = (small && !GP_STABLE) ? 1 : (cwc_lds ? ns_c_lds : rows_that_fit(cw_c1, grp_c_room));
     const int ns_r = cwr_lds ? ns_r_lds
                              : (build_end + SPK_WAVES * cw_r1 + grp_r_probe + 16 <= top ? SPK_WAVES : SPK_SORT_WAVES);
     const size_t cw_c = cwc_lds ? 0 : (size_t)ns_c * cw_c1;                  // bytes taken behind the staging arrays
@@ -915,6 +1111,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             scores[sid] = 0.0;
             status[sid] = 2;
         }
+        SFORM(3);
         return 2;
     }
     u32* const cw_lds = reinterpret_cast<u32*>(smem + lds_used);
@@ -923,16 +1120,34 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     unsigned short* grp_c = grp_c_in_csr ? reinterpret_cast<unsigned short*>(csr_ent)
                                          : reinterpret_cast<unsigned short*>(base + ((build_end + cw_c + 15) & ~(size_t)15));
     unsigned short* grp_r = reinterpret_cast<unsigned short*>(base + ((build_end + cw_r + 15) & ~(size_t)15));
-    if (PLAIN) {
-        // both lists side by side (waves 0..7 / 8..15) when two sets of 8 counter rows + both group-start arrays fit
+    if (small) {   // Gram path: order-free grouping by column (one shared counter row + start offsets behind the staging arrays)
+        if (GP_STABLE) {
+            spk_build_list<true, 8, false, u32>(pc, counts, Di, Kc, csc_ptr, nullptr, csc_ent, nullptr, nullptr, nullptr, nullptr,
+                                                &sh.used_c, cwbuf, ns_c, sh, colof);
+        }
+        const size_t gwords = (size_t)((Kc + 2) / 2);
+        u32* const csz = cwbuf;
+        u32* const ccur = cwbuf + gwords;
+        unsigned short* const gstart = reinterpret_cast<unsigned short*>(cwbuf + 2 * gwords);
+        if (HBM)
+            spk_group_cols<unsigned short, false>(pc, cnt, Di, Kc, csz, ccur, gstart, csc_ent, pinfo, nullptr, &sh.used_c, sh);
+        else if (!GP_STABLE)
+            spk_group_cols<u32, LISTS_GLOBAL>(pc, counts, Di, Kc, csz, ccur, gstart, csc_ent, pinfo, ent64, &sh.used_c, sh);
+        SSTAMP(2);
+    } else if (!HBM) {
+        // both lists side by side (waves 0..7 / 8..15) when two sets of 8 counter rows + both group-start arrays fit - plain
+        // LDS form only: with the lists in global memory (13.5 k patterns: 27 entries per lane and pass) the two halves do
+        // not overlap, 105 - 112 k cycles against 89 k for one list after the other (8 + 16 counter rows)
         const size_t pair_c = (size_t)SPK_HALF_WAVES * cw_c1, pair_r = (size_t)SPK_HALF_WAVES * cw_r1;
         const size_t pair_gc = (((size_t)Kc + 1) * 2 + 15) & ~(size_t)15, pair_gr = (((size_t)R + 1) * 2 + 15) & ~(size_t)15;
         const size_t pair_at = (build_end + 15) & ~(size_t)15;
-        const bool pair = !small && pair_at + pair_c + pair_r + pair_gc + pair_gr + 16 <= top;
-        if (small) {
-            spk_build_list<true, 8, false, u32>(pc, counts, Di, Kc, csc_ptr, nullptr, csc_ent, nullptr, nullptr, nullptr, nullptr,
-                                                &sh.used_c, cwbuf, ns_c, sh, colof);
+        const bool pair = !LISTS_GLOBAL && pair_at + pair_c + pair_r + pair_gc + pair_gr + 16 <= top;
+        if (LISTS_GLOBAL) {
+            spk_build_list<true, 16, true>(pc, cnt, Di, Kc, grp_c, desc_c, csc_ent, perm_c, &sh.nw_c, &sh.nr_c, &sh.nq_c, &sh.used_c,
+                                           cwbuf, ns_c, sh, nullptr, 50);
             SSTAMP(2);
+            spk_build_list<false, 16, true>(pc, cnt, Di, R, grp_r, desc_r, csr_ent, perm_r, &sh.nw_r, &sh.nr_r, &sh.nq_r, &sh.used_r,
+                                            cwbuf_r, ns_r, sh);
         } else if (pair) {
             unsigned char* at = base + pair_at;
             SpkListOut Lc{Kc, reinterpret_cast<unsigned short*>(at + pair_c + pair_r), desc_c, perm_c, csc_ent,
@@ -949,16 +1164,11 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
                                                  &sh.used_r, cwbuf_r, ns_r, sh);
         }
     } else {
-        if (small)
-            spk_build_list<true, 8, false>(pc, cnt, Di, Kc, csc_ptr, nullptr, csc_ent, nullptr, nullptr, nullptr, nullptr, &sh.used_c,
-                                           cwbuf, ns_c, sh, colof);
-        else
-            spk_build_list<true, 16, true>(pc, cnt, Di, Kc, grp_c, desc_c, csc_ent, perm_c, &sh.nw_c, &sh.nr_c, &sh.nq_c, &sh.used_c,
-                                           cwbuf, ns_c, sh, nullptr, 50);
+        spk_build_list<true, 16, true>(pc, cnt, Di, Kc, grp_c, desc_c, csc_ent, perm_c, &sh.nw_c, &sh.nr_c, &sh.nq_c, &sh.used_c,
+                                       cwbuf, ns_c, sh, nullptr, 50);
         SSTAMP(2);
-        if (!small)
-            spk_build_list<false, 16, true>(pc, cnt, Di, R, grp_r, desc_r, csr_ent, perm_r, &sh.nw_r, &sh.nr_r, &sh.nq_r, &sh.used_r,
-                                            cwbuf_r, ns_r, sh);
+        spk_build_list<false, 16, true>(pc, cnt, Di, R, grp_r, desc_r, csr_ent, perm_r, &sh.nw_r, &sh.nr_r, &sh.nq_r, &sh.used_r,
+                                        cwbuf_r, ns_r, sh);
     }
     SSTAMP(3);
     // ids in use on raw sides (small path: the used rows are the non-zero diagonal entries of G, checked below)
@@ -978,7 +1188,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             int myrow = -1, mycnt = 1;
             if (lane < ntop) {
                 myrow = (int)(pc[sh.top[lane]] >> 16);
-                mycnt = PLAIN ? (int)counts[sh.top[lane]] : (int)cnt[sh.top[lane]];
+                mycnt = (!PLAIN && stage_cnt) ? (int)cnt[sh.top[lane]] : (int)counts[sh.top[lane]];
             }
             u64 active = __ballot(myrow >= 0);
             // (fully unrolled, constant indices: a runtime-indexed local array would live in scratch = global memory)
@@ -1025,80 +1235,127 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     double* V = reinterpret_cast<double*>(carve((size_t)Vp * NBC * 8));
     double* Wb = (W_GLOBAL && !small) ? reinterpret_cast<double*>(lslab + wslab_off)
                                       : reinterpret_cast<double*>(base + off);   // large: W (Kc x 4);  small: G (R x R)
+    // mid path: cell (lo, hi), lo <= hi, of the packed upper triangle (R rows: lo (2R + 1 - lo) is even)
+    auto tri = [&](int lo, int hi) { return (int)(__umul24((u32)lo, (u32)(2 * R + 1 - lo)) >> 1) + (hi - lo); };
     if (small) {
         // exact Gram G = C C^T: all pairs of entries inside every column, accumulated with integer LDS atomics (exact,
-        // order independent).  One thread per CSC position i of a column of n entries takes the pairs (i, i + d mod n),
+        // order independent).  One thread per list position i of a column of n entries takes the pairs (i, i + d mod n),
         // d = 0 .. n/2 - every unordered pair once, every thread of a column the same number of steps (walking the
         // rest of the column instead leaves half of the lanes of a long column idle).  32-bit atomics when every entry
-        // fits (G[r][r'] <= trace), 64-bit otherwise.
-        const bool g32 = sh.trace < (1ull << 32);
+        // fits (G[r][r'] <= trace), 64-bit otherwise (small form only).
         u32* G32 = reinterpret_cast<u32*>(Wb);
         unsigned long long* G64 = reinterpret_cast<unsigned long long*>(Wb);
-        const int gwords = g32 ? R * Gp : 2 * R * Gp;   // (integer G with the same odd pitch: cells spread over the banks)
+        const int gwords = mid ? (int)(gtri_bytes / 4) : (g32 ? R * Gp : 2 * R * Gp);   // (small: integer G with the same odd pitch as the fp64 one)
         for (int i = threadIdx.x; i < gwords; i += SPK_THREADS) G32[i] = 0;
         __syncthreads();
         SSTAMP(44);
         // (instruction count is what this loop costs - 16 waves share 4 SIMDs, so every instruction of the body is 16
-        // cycles of the block: the partner index walks and wraps by compare-select, the cell is min * Gp + max, and the
-        // rare table with split counts - pieces of one large count on one row pair twice - has its own copy of the loop)
-        const bool has_pieces = Di != (int)sh.ntab;
-        auto pair_loop = [&](auto add_cell, bool pieces) {
+        // cycles of the block: position and size of the entry in its column come in one 16-bit word (spk_group_cols), the
+        // partner index walks and wraps by compare-select, the cell is min * Gp + max)
+        // (lists in global memory: entry and position word come in one 8-byte word, partners are the low halves; eight
+        // partner entries are fetched before the first of their atomics - a dependent L2 round trip per step otherwise)
+        auto entry_at = [&](int q) -> u32 { return LISTS_GLOBAL ? (u32)ent64[q] : csc_ent[q]; };
+        auto pair_loop = [&](auto add_cell) {
             for (int a = threadIdx.x; a < Di; a += SPK_THREADS) {
-                const int col = colof[a];
-                const int p0 = csc_ptr[col], pend = csc_ptr[col + 1], n = pend - p0, i = a - p0, half = n >> 1;
-                const u32 va = csc_ent[a];
+                u32 va;
+                int info;
+                int i, n, p0, pend;
+                if (GP_STABLE) {
+                    const int col = colof[a];
+                    p0 = csc_ptr[col];
+                    pend = csc_ptr[col + 1];
+                    n = pend - p0;
+                    i = a - p0;
+                    va = csc_ent[a];
+                } else {
+                    if (LISTS_GLOBAL) {
+                        const u64 w = ent64[a];
+                        va = (u32)w;
+                        info = (int)(w >> 32);
+                    } else {
+                        va = csc_ent[a];
+                        info = pinfo[a];
+                    }
+                    i = info & 255;
+                    n = (info >> 8) + 1;
+                    p0 = a - i;
+                    pend = p0 + n;
+                }
+                const int half = n >> 1;
                 const u32 ca = va >> 16;
                 const int ra = va & 0xFFFF;
                 const int steps = ((n & 1) == 0 && i >= half) ? half : half + 1;   // even n: the pair (i, i + n/2) belongs to i < n/2
                 int q = a;
-                for (int d = 0; d < steps; ++d) {
-                    const u32 vb = csc_ent[q];
-                    q = q + 1 == pend ? p0 : q + 1;
-                    const int rb = vb & 0xFFFF;
-                    u32 val = ca * (vb >> 16);
-                    if (pieces && ra == rb && d > 0) val *= 2u;   // (c1 + c2)^2 has 2 c1 c2
-                    add_cell(min(ra, rb) * Gp + max(ra, rb), val, ca, vb >> 16, pieces && ra == rb && d > 0);
+                if (LISTS_GLOBAL) {
+                    for (int d = 0; d < steps; d += 8) {
+                        u32 vb[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            vb[u] = entry_at(q);      // (d + u >= steps: a valid position of the column, not used)
+                            q = q + 1 == pend ? p0 : q + 1;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (d + u >= steps) break;
+                            const int rb = vb[u] & 0xFFFF;
+                            add_cell(min(ra, rb), max(ra, rb), ca, vb[u] >> 16);
+                        }
+                    }
+                } else {
+                    for (int d = 0; d < steps; ++d) {
+                        const u32 vb = entry_at(q);
+                        q = q + 1 == pend ? p0 : q + 1;
+                        const int rb = vb & 0xFFFF;
+                        add_cell(min(ra, rb), max(ra, rb), ca, vb >> 16);
+                    }
                 }
             }
         };
-        auto add32 = [&](int cell, u32 val, u32, u32, bool) { atomicAdd(&G32[cell], val); };
-        auto add64 = [&](int cell, u32, u32 c1, u32 c2, bool twice) {
-            atomicAdd(&G64[cell], (unsigned long long)c1 * (unsigned long long)c2 * (twice ? 2ull : 1ull));
-        };
-        if (g32 && !has_pieces)   // (the common case gets the lean copy, everything else the general one)
-            pair_loop(add32, false);
+        if (mid)
+            pair_loop([&](int lo, int hi, u32 c1, u32 c2) { atomicAdd(&G32[tri(lo, hi)], c1 * c2); });
+        else if (g32)
+            pair_loop([&](int lo, int hi, u32 c1, u32 c2) { atomicAdd(&G32[lo * Gp + hi], c1 * c2); });
         else
-            pair_loop([&](int cell, u32 val, u32 c1, u32 c2, bool twice) {
-                if (g32) add32(cell, val, c1, c2, twice); else add64(cell, val, c1, c2, twice);
-            }, has_pieces);
+            pair_loop([&](int lo, int hi, u32 c1, u32 c2) {
+                atomicAdd(&G64[lo * Gp + hi], (unsigned long long)c1 * (unsigned long long)c2);
+            });
         __syncthreads();
         SSTAMP(45);
-        {   // exact integer -> fp64 in place (same R x Gp layout), through registers: 4- / 8-byte cells overlap
-            constexpr int NG = (SPK_SMALL_R * (SPK_SMALL_R + 1) + SPK_THREADS - 1) / SPK_THREADS;
-            double gv[NG];
+        if (mid) {   // rows in use = non-zero diagonal cells; G stays packed integers (converted on the fly by the product)
+            if (threadIdx.x == 0) sh.used_r = 0;
+            __syncthreads();
+            const int dr = (int)threadIdx.x < R ? (int)threadIdx.x : 0;
+            const u64 nzd = __ballot((int)threadIdx.x < R && G32[tri(dr, dr)] != 0u);
+            if ((threadIdx.x & 63) == 0 && nzd) atomicAdd(&sh.used_r, (int)__popcll(nzd));
+            __syncthreads();
+        } else {
+            {   // exact integer -> fp64 in place (same R x Gp layout), through registers: 4- / 8-byte cells overlap
+                constexpr int NG = (SPK_SMALL_R * (SPK_SMALL_R + 1) + SPK_THREADS - 1) / SPK_THREADS;
+                double gv[NG];
 #pragma unroll
-            for (int k = 0; k < NG; ++k) {
-                const int i = k * SPK_THREADS + (int)threadIdx.x;
-                gv[k] = i < R * Gp ? (g32 ? (double)spk_aload(G32 + i) : (double)spk_aload(G64 + i)) : 0.0;
+                for (int k = 0; k < NG; ++k) {
+                    const int i = k * SPK_THREADS + (int)threadIdx.x;
+                    gv[k] = i < R * Gp ? (g32 ? (double)spk_aload(G32 + i) : (double)spk_aload(G64 + i)) : 0.0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < NG; ++k) {
+                    const int i = k * SPK_THREADS + (int)threadIdx.x;
+                    if (i < R * Gp) Wb[i] = gv[k];
+                }
             }
             __syncthreads();
-#pragma unroll
-            for (int k = 0; k < NG; ++k) {
-                const int i = k * SPK_THREADS + (int)threadIdx.x;
-                if (i < R * Gp) Wb[i] = gv[k];
+            const float pinv = 1.0f / (float)Gp;   // i / Gp for i < 4160, Gp <= 65: (i + 0.5) / Gp is >= 1/130 away from an integer
+            for (int i = threadIdx.x; i < R * Gp; i += SPK_THREADS) {
+                const int r = (int)(((float)i + 0.5f) * pinv), c = i - r * Gp;
+                if (c < R && r > c) Wb[r * Gp + c] = Wb[c * Gp + r];
             }
+            if (threadIdx.x < 64) {   // rows in use = non-zero diagonal entries (R <= 64)
+                const u64 nzd = __ballot((int)threadIdx.x < R && Wb[threadIdx.x * Gp + threadIdx.x] != 0.0);
+                if (threadIdx.x == 0) sh.used_r = (int)__popcll(nzd);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        const float pinv = 1.0f / (float)Gp;   // i / Gp for i < 4160, Gp <= 65: (i + 0.5) / Gp is >= 1/130 away from an integer
-        for (int i = threadIdx.x; i < R * Gp; i += SPK_THREADS) {
-            const int r = (int)(((float)i + 0.5f) * pinv), c = i - r * Gp;
-            if (c < R && r > c) Wb[r * Gp + c] = Wb[c * Gp + r];
-        }
-        if (threadIdx.x < 64) {   // rows in use = non-zero diagonal entries (R <= 64)
-            const u64 nzd = __ballot((int)threadIdx.x < R && Wb[threadIdx.x * Gp + threadIdx.x] != 0.0);
-            if (threadIdx.x == 0) sh.used_r = (int)__popcll(nzd);
-        }
-        __syncthreads();
         if (degenerate(sh.used_r, 5)) return 0;
     }
     // ---- iteration: alternate half products, one Ritz sum per half product -------------------------------------
@@ -1194,11 +1451,52 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     SSTAMP(5);
     SSTAMP(6);
     if (small) {
+        const u32* const Gt = reinterpret_cast<const u32*>(Wb);
         for (it = 1; it <= SPK_MAXIT; ++it) {
-            // Y = G V densely (R <= 64): thread (row, j); Ritz sum = trace(V^T Y); Y staged in registers, written over V
-            const int row = threadIdx.x >> 2, j = threadIdx.x & 3;
+            // Y = G V densely; Ritz sum = trace(V^T Y); Y staged in registers, written over V
+            int row = threadIdx.x >> 2, j = threadIdx.x & 3;
             double acc = 0, part = 0;
-            if (row < R) {
+            if (mid) {
+                // R <= 256, G packed.  One v_mfma_f64_4x4x4 = 4 independent 4 x 4 x 4 blocks; lane l supplies A[i][kk] of
+                // block b at l = i + 4 b + 16 kk and B[kk][j] at l = j + 4 b + 16 kk, D[i][j] of block b comes back in lane
+                // j + 4 b + 16 i (layout: spk_gram).  Here the four blocks are four K-PARTS of the same 4 rows: step t of a
+                // row group takes k = 16 t + 4 b + kk, i.e. 4 rows x 16 consecutive k per instruction, and the blocks are
+                // added up at the end (two shuffles).  With that assignment a lane's B operands are V[16 t + 4 b + kk][j],
+                // t = 0 .. R/16 - 1: 16 doubles that do not depend on the row group - they are loaded into registers ONCE
+                // per product, and the LDS is left with one 4-byte read per G cell (with V read per instruction as well
+                // the product was LDS-instruction bound: 2048 wave-instructions, 26 k cycles).
+                const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+                const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
+                constexpr int NT = SPK_MID_R / 16;
+                double bv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bv[t] = V[(16 * t + 4 * lb + lk) * v_rs + li * v_cs];   // (R == SPK_MID_R: no bounds)
+                // row groups of 4: SPK_MID_R / 4 = 64 of them, 4 per wave (wave w: rows 16 w .. 16 w + 15); lane (li, lb, lk)
+                // reports D[i = lk][j = li] of group lb.  (The group loop is NOT unrolled: unrolled, the 64 cell addresses
+                // of a wave's four groups were all kept live and the function spilled to scratch in every loop it has.)
+#pragma unroll 1
+                for (int g = 0; g < 4; ++g) {
+                    const int arow = 16 * w + 4 * g + li;
+                    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NT; t += 2) {
+                        const int k0 = 16 * t + 4 * lb + lk, k1 = k0 + 16;
+                        // (unconditional reads: a predicated read became a branch with its own s_waitcnt - 64 LDS round trips
+                        // in a row per wave and product, 24 k cycles)
+                        const double a0 = (double)Gt[tri(min(arow, k0), max(arow, k0))];
+                        const double a1 = (double)Gt[tri(min(arow, k1), max(arow, k1))];
+                        d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, bv[t], d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, bv[t + 1], d1, 0, 0, 0);
+                    }
+                    double d = d0 + d1;
+                    d += __shfl_xor(d, 4, 64);               // sum of the four K-parts: every block now holds D[i][j]
+                    d += __shfl_xor(d, 8, 64);
+                    acc = lb == g ? d : acc;
+                }
+                row = 16 * w + 4 * lb + lk;
+                j = li;
+                if (row < R) part = acc * V[row * v_rs + j * v_cs]; else row = R;
+            } else if (row < R) {
                 for (int k = 0; k < R; ++k) acc = fma(Wb[row * Gp + k], V[k * v_rs + j * v_cs], acc);
                 part = acc * V[row * v_rs + j * v_cs];
             }
@@ -1215,8 +1513,8 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             spk_gram(V, R, v_rs, v_cs, sh);                  // Y^T Y = V^T G^2 V: its eigenvalues are the squared Ritz values
             // (S holds SQUARED Ritz values here: the cheap bound suffices when rest^2 <= 0.09 of it, i.e. rest <= 0.3 sqrt)
             const double rest_s = trace - top4;
-            spk_chol_factor(sh, it >= 4, rest_s > 0 ? rest_s * rest_s * (1.0 / 0.3) : 0.0);
-            if (spk_converged(top4, sqrt(sh.L[11]), trace, it, prev_sum, prev_delta, prev_ratio)) {
+            spk_chol_factor(sh, it >= 3, rest_s > 0 ? rest_s * rest_s * (1.0 / 0.3) : 0.0);
+            if (spk_converged(top4, sqrt(sh.L[11]), trace, it, prev_sum, prev_delta, prev_ratio, true)) {
                 conv = 1;
                 break;
             }
@@ -1266,6 +1564,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     // score written is an upper estimate; status bit 1 hands the split on (wide block / dense route), the wide block
     // - the last resort - flags it with bit 0 instead.
     const int code = conv ? (it << 8) : ((wide_on ? 1 : 2) | (it << 8));
+    SFORM(0);
     if (threadIdx.x == 0) {
         const double op = 1.0 - top4 / trace;
         scores[sid] = sqrt(op > 0 ? op : 0.0);

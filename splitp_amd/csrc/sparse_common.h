@@ -28,7 +28,8 @@
 #define SPK_MAXHALF 40      // sparse half products of the general path; a block without a spectral gap behind it goes to
                             // the dense route long before (spk_converged)
 #define SPK_LDS_BYTES 163840
-#define SPK_SMALL_R 64
+#define SPK_SMALL_R 64      // Gram path, fp64 G: row ids
+#define SPK_MID_R 256       // Gram path, packed integer triangle (lists-in-global form): row ids
 
 #if defined(SPK_STAMPS) && defined(SPK_MAIN_TU)
 __device__ long long g_spk_stamps[64];
@@ -38,6 +39,18 @@ __device__ int g_spk_stamp_block = 0;
         __syncthreads();                                                                       \
         if (threadIdx.x == 0 && (int)blockIdx.x == g_spk_stamp_block) g_spk_stamps[i] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+// which form finished / refused how many items (diagnostic build only): [form * 4 + reason], form = HBM | WIDE << 1 |
+// LISTS_GLOBAL << 2 | W_GLOBAL << 3, reason 0 = scored, 1..3 = the three "does not fit" exits of spk_score_one
+__device__ unsigned int g_spk_forms[64];
+#define SFORM(reason) do { if (threadIdx.x == 0) atomicAdd(&g_spk_forms[((HBM ? 1 : 0) | (WIDE ? 2 : 0) | (LISTS_GLOBAL ? 4 : 0) | (W_GLOBAL ? 8 : 0)) * 4 + (reason)], 1u); } while (0)
+extern "C" int sp_debug_spk_forms(unsigned int* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spk_forms), sizeof(unsigned int) * 64) != hipSuccess) return 2;
+    if (reset) {
+        unsigned int z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_spk_forms), z, sizeof(z)) != hipSuccess) return 2;
+    }
+    return 0;
+}
 extern "C" int sp_debug_spk_stamp_block(int b) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_spk_stamp_block), &b, sizeof(int)) == hipSuccess ? 0 : 2;
 }
@@ -46,6 +59,7 @@ extern "C" int sp_debug_spk_stamps(long long* out) {
 }
 #else
 #define SSTAMP(i)
+#define SFORM(reason)
 #endif
 
 struct SpkShared {
@@ -281,18 +295,24 @@ __device__ __forceinline__ void spk_orth(double* X, int rows, int rs, int cs, Sp
 // possible and the measured ratios are real - or if trace - s is itself below the tolerance.  A block that never
 // passes the guard runs out of half products and is handed to the dense route (16-wide block), where clusters are at home.
 // Tolerance: the score is sqrt(1 - s / trace); 1e-13 relative in s is < 1e-11 in any score >= 0.005.
+// dense_g (Gram path): one step is a product with the exact G = C C^T, i.e. TWO half products - the error ratio per step is
+// (lambda_5 / lambda_4)^2 ~ 4e-6 on real alignments, the 3rd sum is already converged far below the tolerance, and waiting
+// for a second measured ratio costs a whole product (a quarter of the iteration).  There the rule may fire at the 3rd sum
+// on ONE measured ratio, provided the tail it predicts is a hundred times below the tolerance (early ratios are optimistic:
+// components of smaller eigenvalues die first - but not a hundredfold at ratios of 1e-5) and the same gap guard and rigorous
+// bound hold as for every other stop.
 __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double trace, int k, double& prev_sum,
-                                              double& prev_delta, double& prev_ratio) {
+                                              double& prev_delta, double& prev_ratio, bool dense_g = false) {
     bool conv = false;
     const double delta = fabs(s4 - prev_sum);
     double ratio = 1.0;
     if (k >= 3) {   // delta_2 is the first real difference, so ratios exist from k = 3 on
         ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
         ratio = fmin(fmax(ratio, 0.0), 0.9999);
-        if (k >= 4) {
+        if (k >= 4 || dense_g) {
             const double rest = trace - s4;                    // >= lambda_5 + lambda_6 + ...
-            const double r = fmax(ratio, prev_ratio);
-            const double tail = delta * r / (1.0 - r);
+            const double r = k >= 4 ? fmax(ratio, prev_ratio) : ratio;
+            const double tail = (k >= 4 ? 1.0 : 100.0) * delta * r / (1.0 - r);
             const bool gap = rest <= 0.6 * lam_lb || rest <= 1e-13 * trace;
             // Tolerance on s: 1e-13 relative, tightened for tiny scores (d score = d s / (2 score trace): keep it
             // below 2e-11) down to the rounding floor of the Ritz sum (~2e-15 relative, so 4e-15 is the least asked).
@@ -306,7 +326,7 @@ __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double t
             // (d s <= 1e-10 score trace), which the estimate-based stop already implies unless rho_b >> r.
             const double rho_b = lam_lb > 0 ? fmin(rest / lam_lb, 0.9999) : 0.9999;
             const bool bounded = delta * rho_b / (1.0 - rho_b) <= fmax(1e-10 * sx, 4e-15 * s4);
-            if (gap && bounded && (delta <= 0.2 * tol || tail <= tol)) conv = true;
+            if (gap && bounded && ((k >= 4 && delta <= 0.2 * tol) || tail <= tol)) conv = true;
         }
     }
 #ifdef SPK_DEBUG_CONV

@@ -960,8 +960,12 @@ def test_dropin_loop_stays_on_the_device(sp, golden):
             edited = sp.split_score(F)
             assert abs(edited - O.dense_split_score(np.asarray(F))) <= SCORE_TOL and abs(edited - s) > 1e-6
             G = sp.flattening(splits[i], table, sp.FlatFormat.reduced)
-            G /= G.sum()                                        # the usual normalisation: scale-invariant score
-            assert flattening_origin(G) is None and abs(sp.split_score(G) - s) <= SCORE_TOL
+            G *= 3.0                                            # an in-place rescale: same score (scale invariant), but
+            assert flattening_origin(G) is None                 # a different matrix: generic route
+            assert abs(sp.split_score(G) - s) <= SCORE_TOL
+            G2 = sp.flattening(splits[i], table, sp.FlatFormat.reduced)
+            G2 /= 1.0                                           # an in-place operation that changes nothing keeps the origin
+            assert flattening_origin(G2) is not None
     for fid in g["full_ids"]:
         F = sp.flattening(splits[int(fid)], table, sp.FlatFormat.reduced)
         assert np.array_equal(np.asarray(F), g[f"reduced_{int(fid)}"])

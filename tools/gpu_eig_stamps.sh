@@ -1,11 +1,9 @@
 # cycle stamps of k_eig_rr's workgroup 0 (the heaviest split) in the dense route (GPU box): bash tools/gpu_eig_stamps.sh
 set -e
-cd $GRAFT_REPO_ROOT/splitp_amd/csrc
-cp ../libsplitp_hip.so /tmp/lib_keep.so
+cd $GRAFT_REPO_ROOT
 for round in ${EIG_ROUNDS:-0 1 3}; do
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DEIG_STAMPS $EIG_EXTRA -DEIG_STAMP_ROUND=$round -c eigen.hip -o /tmp/eigen_st.o 2>/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsplitp_hip.so api.o flatten.o gram.o gram_i8.o /tmp/eigen_st.o sparse.o sparse_big.o subflat.o hist.o divergence.o
-(cd ../.. && python - <<PY
+bash tools/variant_lib.sh eigen.hip /tmp/lib_eig_st.so -DEIG_STAMPS $EIG_EXTRA -DEIG_STAMP_ROUND=$round 2>/dev/null
+(SPLITP_LIB=/tmp/lib_eig_st.so python - <<PY
 import sys, ctypes as C, numpy as np
 sys.path.insert(0,'.')
 import splitp_amd as sp
@@ -48,4 +46,3 @@ print("   jacobi calls %d: last sweep index reached %s, rel*1e30 at that check %
 PY
 )
 done
-cp /tmp/lib_keep.so ../libsplitp_hip.so

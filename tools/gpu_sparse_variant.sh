@@ -1,10 +1,10 @@
 # A/B of k_sparse_score builds on the GPU box: bash tools/gpu_sparse_variant.sh "<flags A>" "<flags B>" ...
 # each build: half-product histogram (tools/gpu_iters.py), max |score - golden|, bench (3 lanes, 1500 steps)
 cd $GRAFT_REPO_ROOT
-cp splitp_amd/libsplitp_hip.so /tmp/lib_keep.so
 for fl in "$@"; do
   echo "=== flags: $fl"
-  (cd splitp_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $fl -c sparse.hip -o /tmp/sparse_v.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsplitp_hip.so api.o flatten.o gram.o gram_i8.o eigen.o /tmp/sparse_v.o sparse_big.o subflat.o hist.o divergence.o) || continue
+  bash tools/variant_lib.sh sparse.hip /tmp/lib_v.so $fl || continue
+  export SPLITP_LIB=/tmp/lib_v.so
   python tools/gpu_iters.py 2>&1 | grep -v amdgpu.ids
   python - <<'PY' 2>&1 | grep -v amdgpu.ids
 import sys, numpy as np
@@ -21,6 +21,5 @@ for name in ("n10_L100k", "n10_L10k"):
     s = sp.score_splits(dev, splits)
     print(name, "max |score - reference| = %.2e" % np.abs(s - g["scores"]).max())
 PY
-  python bench.py --steps 1500 --warmup 50 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step %.5f  launch_ms %.5f' % (d['ms_per_step'], d['roofline']['launch_ms']))"
+  python bench.py --steps 1500 --warmup 50 --no-cpu-baseline --no-pipeline-block 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step %.5f  launch_ms %.5f' % (d['ms_per_step'], d['roofline']['launch_ms']))"
 done
-cp /tmp/lib_keep.so splitp_amd/libsplitp_hip.so

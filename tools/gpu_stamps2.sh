@@ -1,10 +1,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
-cd splitp_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $SPK_EXTRA -DSPK_STAMPS -c sparse.hip -o /tmp/sparse_st.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libsplitp_hip.so api.o flatten.o gram.o gram_i8.o eigen.o /tmp/sparse_st.o sparse_big.o subflat.o hist.o divergence.o
-cd ../..
-python - <<'PY'
+bash tools/variant_lib.sh sparse.hip /tmp/lib_stamps.so $SPK_EXTRA -DSPK_STAMPS
+SPLITP_LIB=/tmp/lib_stamps.so python - <<'PY'
 import sys, ctypes as C, numpy as np
 sys.path.insert(0,'.')
 import splitp_amd as sp
@@ -34,7 +31,7 @@ for k in (5, 4, 3, 2):
         o = np.array(out[:], dtype=np.int64)
         print(f"k={k} block {blk}: stage={o[1]-o[0]} CSC={o[2]-o[1]} CSR={o[3]-o[2]} start={o[4]-o[3]} G/Vinit+W1+orth={o[7]-o[4]} "
               f"spmm_it2={o[9]-o[7]} gram2={o[40]-o[9]} orth2={o[41]-o[40]} spmm_it3={o[8]-o[41]} rest={o[11]-o[8]} total={o[11]-o[0]}")
-        print(f"     CSC build: pre={o[55]-o[1]} passA={o[50]-o[55]} prefix={o[51]-o[50]} class+perm={o[52]-o[51]} scan+ptr={o[53]-o[52]} passB={o[2]-o[53]} "
+        print(f"     CSC build: pre={o[55]-o[1]} passA={o[50]-o[55]} prefix={o[51]-o[50]} class+perm={o[52]-o[51]} scan+ptr={o[53]-o[52]} passB={o[2]-o[53]} (Gram path: scans={o[51]-o[50]} passB={o[2]-o[51]}) "
               f"| spmm_it3: wave={o[30]-o[41]} row={o[32]-o[30]} quad={o[20]-o[32]} lane={o[8]-o[20]} | G: zero={o[44]-o[4]} pairs={o[45]-o[44]} conv={o[5]-o[45]}")
         print(f"     atomic form (k >= 4): stage={o[1]-o[0]} top+init+orth={o[5]-o[1]} | it2: zero+product={o[9]-o[5]} convert+gram={o[40]-o[9]} chol+orth={o[41]-o[40]} "
               f"| it3: zero={o[20]-o[41]} product={o[30]-o[20]} convert={o[8]-o[30]} | rest={o[11]-o[8]} total={o[11]-o[0]}")
