@@ -48,7 +48,7 @@ extern "C" {
 #define SP_ELIMIT 4   /* size outside what this build supports (see message) */
 #define SP_ENOCONV 5  /* eigen iteration did not converge (score still written, flagged) */
 
-#define SP_ABI_VERSION 2
+#define SP_ABI_VERSION 3   /* 3: sp_score_plan_steps */
 
 typedef struct sp_ctx sp_ctx;             /* device + stream + workspace arena */
 typedef struct sp_alignment sp_alignment; /* device-resident pattern table */
@@ -261,6 +261,15 @@ int sp_plan_info(const sp_plan* plan, int* n_taxa, int64_t* n_splits);
  * alignment-major.  The first call for an alignment prepares its split-independent metadata (synchronously, once). */
 int sp_score_plan_async(sp_ctx* lane, sp_alignment* const* als, int n_al, sp_plan* plan, void* scores_dev,
                         void* status_dev);
+
+/* n_steps passes of sp_score_plan_async from ONE host call (ABI 3): pass s - the whole flattening + score + hand-back
+ * chain over every (alignment, split) item, nothing cached between passes - writes its n_al * n_splits scores to
+ * (char*)scores_dev + s * scores_step_bytes and its status words to (char*)status_dev + s * status_step_bytes.  This is
+ * the host loop `for s in range(n_steps): sp_score_plan_async(...)` (the repeated scoring of one table: bootstrap
+ * replicates of the reference's README loop, README.md:36-41, or a benchmark's steps) without a Python / ctypes round
+ * trip per pass: two kernel launches of host time per pass.  Same argument checks and errors as sp_score_plan_async. */
+int sp_score_plan_steps(sp_ctx* lane, sp_alignment* const* als, int n_al, sp_plan* plan, int n_steps, void* scores_dev,
+                        int64_t scores_step_bytes, void* status_dev, int64_t status_step_bytes);
 
 #ifdef __cplusplus
 }

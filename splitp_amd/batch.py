@@ -179,6 +179,16 @@ def score_plan_async(lane_ctx, als, plan, scores_dev_ptr, status_dev_ptr, _handl
                                                  C.c_void_p(scores_dev_ptr), C.c_void_p(status_dev_ptr)))
 
 
+def score_plan_steps(lane_ctx, als, plan, n_steps, scores_dev_ptr, scores_step_bytes, status_dev_ptr, status_step_bytes,
+                     _handles=None):
+    """sp_score_plan_steps: `n_steps` complete passes of score_plan_async from one host call; pass s writes its scores /
+    status words `s * step_bytes` behind the given device pointers."""
+    arr = _handles if _handles is not None else (C.c_void_p * len(als))(*[a.handle.value for a in als])
+    _lib.check(lane_ctx._lib.sp_score_plan_steps(lane_ctx.handle, arr, len(als), plan.handle, int(n_steps),
+                                                 C.c_void_p(scores_dev_ptr), int(scores_step_bytes),
+                                                 C.c_void_p(status_dev_ptr), int(status_step_bytes)))
+
+
 def score_encoded_async(al, split_taxa, split_a, method_code, scores_dev_ptr, status_dev_ptr):
     """Enqueue only (no host synchronisation): scores and status land in the given device buffers.  On the sparse
     route the hand-back chain runs on the device, so the results are final once the stream has run."""
@@ -210,6 +220,19 @@ def finish_async(al, split_taxa, split_a, scores_host, status_host):
         scores_host[redo] = sc
         status_host[redo] = st
     return len(redo)
+
+
+def _send_buffer(width):
+    """Zeroed device buffer for a collective's send side, COMPLETE before it is returned.  The library's kernels run on the
+    context's stream; when torch's current stream is the legacy default stream the context owns a private one, so neither
+    torch's fill kernel nor the collective is ordered with them by the stream alone: the fill is waited for here, the
+    kernels by a context synchronise before the collective (found by the world-size-1 nccl test of round 3: the 0.7 ms
+    subflattening pass of a 16-taxon table had its results overwritten by the late fill - all scores 0)."""
+    import torch
+
+    send = torch.zeros(width, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    torch.cuda.current_stream().synchronize()
+    return send
 
 
 def packed_width(per):
@@ -302,10 +325,10 @@ def score_all_splits(pattern_probabilities, method=Method.flattening, route="aut
         per = max(len(s) for s in shards)
         nccl = dist.get_backend(group) == "nccl"
         if nccl:
-            send = torch.zeros(packed_width(per), dtype=torch.float64,
-                               device=torch.device("cuda", torch.cuda.current_device()))
+            send = _send_buffer(packed_width(per))
             score_all_splits_shard(al, code, trivial, size, rank, world, scores_dev_ptr=send.data_ptr(),
                                    status_dev_ptr=send.data_ptr() + per * 8)
+            al.ctx.synchronize()      # the collective runs on torch's stream, the kernels on the context's (see _send_buffer)
             out, status = gather_scores(None, shards, total, group=group, device_tensor=send, return_status=True)
         else:
             loc, loc_st = score_all_splits_shard(al, code, trivial, size, rank, world)
@@ -376,10 +399,10 @@ def score_splits(pattern_probabilities, splits, method=Method.flattening, distri
     per = max(len(s) for s in shards)
     if dist.get_backend(group) == "nccl":
         # scores and status of this rank's shard are written by the kernels straight into the packed exchange buffer
-        send = torch.zeros(packed_width(per), dtype=torch.float64,
-                           device=torch.device("cuda", torch.cuda.current_device()))
+        send = _send_buffer(packed_width(per))
         if len(mine):
             score_encoded_async(al, taxa_arr[mine], a_arr[mine], code, send.data_ptr(), send.data_ptr() + per * 8)
+        al.ctx.synchronize()          # the collective runs on torch's stream, the kernels on the context's (see _send_buffer)
         out, status = gather_scores(None, shards, len(splits), group=group, device_tensor=send, return_status=True)
     else:
         if len(mine):

@@ -788,7 +788,10 @@ extern "C" int sp_plan_create(sp_ctx* ctx, int n_taxa, const int32_t* split_taxa
     std::vector<int> order((size_t)n_splits);
     for (int64_t i = 0; i < n_splits; ++i) order[i] = (int)i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return pl->splits[x].nr > pl->splits[y].nr; });
-    for (const SplitDev& sd : pl->splits) pl->bm_words_max = std::max<int64_t>(pl->bm_words_max, (int64_t)sd.rw + sd.cw);
+    for (const SplitDev& sd : pl->splits) {
+        pl->bm_words_max = std::max<int64_t>(pl->bm_words_max, (int64_t)sd.rw + sd.cw);
+        pl->fit.add_split(sd.nr, sd.nc, sd.rw, sd.cw);
+    }
     int rc = SP_OK;
     const size_t s1 = (size_t)std::max<int64_t>(n_splits, 1);
     if ((rc = pl->splits_dev.ensure(s1 * sizeof(SplitDev))) || (rc = pl->launch_dev.ensure(s1 * sizeof(SplitDev)))) {
@@ -848,7 +851,7 @@ extern "C" int sp_plan_info(const sp_plan* plan, int* n_taxa, int64_t* n_splits)
 // the alignments are prepared).
 static int enqueue_sparse_plan(sp_ctx* ctx, sp_alignment* const* als, int n_al, const sp_plan* plan, double* scores,
                                int* status, bool wide_all) {
-    int64_t dmax = 0;
+    int64_t dmax = 0, dmin = INT64_MAX;
     for (int i = 0; i < n_al; ++i) {
         sp_alignment* al = als[i];
         SP_REQUIRE(al && al->ctx->device == ctx->device && al->n_taxa == plan->n, SP_EINVAL,
@@ -860,11 +863,34 @@ static int enqueue_sparse_plan(sp_ctx* ctx, sp_alignment* const* als, int n_al, 
                    "taxa (alignment %d: %lld rows, %d taxa, %s)", i, (long long)srows, al->n_taxa,
                    al->exact ? "counts" : "float weights");
         dmax = std::max(dmax, srows);
+        dmin = std::min(dmin, srows);
     }
     const AlDesc* descs = nullptr;
     SP_CHECK(aldescs_for(ctx, als, n_al, &descs));
+    SparseFitHint hint = plan->fit;
+    hint.d_min = n_al > 0 ? dmin : 0;
     return launch_sparse_chain(ctx, descs, host_aldesc(als[0]), n_al, plan->n, plan->splits_dev.as<SplitDev>(),
-                               plan->launch_dev.as<SplitDev>(), plan->S, scores, status, dmax, plan->bm_words_max, wide_all);
+                               plan->launch_dev.as<SplitDev>(), plan->S, scores, status, dmax, plan->bm_words_max, wide_all, hint);
+}
+
+extern "C" int sp_score_plan_steps(sp_ctx* lane, sp_alignment* const* als, int n_al, sp_plan* plan, int n_steps,
+                                   void* scores_dev, int64_t scores_step_bytes, void* status_dev, int64_t status_step_bytes) {
+    return sp_guard("sp_score_plan_steps", [&]() -> int {
+    SP_REQUIRE(lane && als && n_al >= 1 && plan && scores_dev && status_dev && n_steps >= 0, SP_EINVAL,
+               "sp_score_plan_steps: NULL argument or negative step count");
+    SP_REQUIRE(plan->device == lane->device, SP_EINVAL, "plan and lane are on different devices");
+    const int64_t items = (int64_t)n_al * plan->S;
+    SP_REQUIRE(n_steps <= 1 || (scores_step_bytes >= items * 8 && status_step_bytes >= items * 4 && scores_step_bytes % 8 == 0 &&
+                                status_step_bytes % 4 == 0),
+               SP_EINVAL, "sp_score_plan_steps: step strides of %lld / %lld bytes for %lld items per pass", (long long)scores_step_bytes,
+               (long long)status_step_bytes, (long long)items);
+    SP_HIP(hipSetDevice(lane->device));
+    if (plan->S == 0) return SP_OK;
+    for (int s = 0; s < n_steps; ++s)
+        SP_CHECK(enqueue_sparse_plan(lane, als, n_al, plan, (double*)((char*)scores_dev + (int64_t)s * scores_step_bytes),
+                                     (int*)((char*)status_dev + (int64_t)s * status_step_bytes), true));
+    return SP_OK;
+    });
 }
 
 extern "C" int sp_score_plan_async(sp_ctx* lane, sp_alignment* const* als, int n_al, sp_plan* plan, void* scores_dev,

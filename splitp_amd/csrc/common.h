@@ -218,6 +218,19 @@ struct PlanCache {
     Plan plan;
 };
 
+// What the host knows about whether any (alignment, split) item can run in the sparse kernel's in-LDS form: the smallest
+// table of the call and, over the split list, the smallest bitmap footprint (12 bytes per word in use) of a Gram-path
+// split (row side <= 3 taxa) and of a general-path split; -1 = no such split, d_min <= 0 = unknown (never skip).
+struct SparseFitHint {
+    int64_t d_min = 0;
+    int64_t w12_gpath = -1, w12_general = -1;
+    void add_split(int nr, int nc, int64_t rw, int64_t cw) {   // SPK_RAW_MAX = 5: shorter sides keep their raw ids, no bitmap
+        const int64_t w12 = 12 * ((nr > 5 ? rw : 0) + (nc > 5 ? cw : 0));
+        int64_t& slot = nr <= 3 ? w12_gpath : w12_general;
+        slot = slot < 0 ? w12 : (w12 < slot ? w12 : slot);
+    }
+};
+
 // An immutable, reference-counted candidate-split list on the device (sp_plan_create): split descriptors + the
 // heaviest-first launch order.  Uploaded synchronously at creation and never written again, so any number of contexts
 // (lanes) of the same device may score with it concurrently.
@@ -229,6 +242,7 @@ struct sp_plan {
     std::vector<SplitDev> splits;   // host copy
     std::vector<int32_t> taxa, a;   // the list as given (content key of the internal plan cache)
     int64_t bm_words_max = 0;       // largest rw + cw among the splits (slab sizing)
+    SparseFitHint fit;              // cheapest split of the list for the in-LDS form (d_min is filled in per call)
     DevBuf splits_dev;   // SplitDev[S], list order (the slow kernel and the dense route index it by split)
     DevBuf launch_dev;   // SplitDev[S], launch order (heaviest first), each with its split index in `cls`
 };
@@ -277,7 +291,7 @@ int launch_sparse_big(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, const u3
                       const double* weights, const int2* dims, int dev_cus, double* scores, int* status);
 int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, const AlDesc& al0, int n_al, int n_taxa,
                         const SplitDev* splits_dev, const SplitDev* launch_dev, int64_t S, double* scores, int* status,
-                        int64_t d_max, int64_t bm_words_max, bool wide_all);
+                        int64_t d_max, int64_t bm_words_max, bool wide_all, const SparseFitHint& hint = SparseFitHint());
 int launch_sparse_meta(sp_ctx* ctx, const u64* keys, const u32* counts, int64_t D, u32* keys32, SpkMeta* meta,
                        unsigned long long trace_override, int64_t orig_rows);
 template <typename T>

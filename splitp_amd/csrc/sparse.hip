@@ -1779,9 +1779,18 @@ size_t sparse_slab_bytes(int64_t D, int64_t bm_words, bool wide) {
 // kernel, and queued behind it the slow kernel that finishes - on the device - whatever the first one handed back.
 // d_max / bm_words_max: largest table / bitmap size among the items (slab sizing).  wide_all: see k_sparse_slow.
 // Afterwards a status word has bit 1 set only for splits left to the dense route (wide_all = false).
+// Every item "does not fit the in-LDS form" without running it: status 2, score 0, and the slow kernel's queue head reset.
+__global__ void k_sparse_refuse_all(int n_items, double* __restrict__ scores, int* __restrict__ status, int* __restrict__ queue_head) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *queue_head = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
+        scores[i] = 0.0;
+        status[i] = 2;
+    }
+}
+
 int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, const AlDesc& al0, int n_al, int n_taxa,
                         const SplitDev* splits_dev, const SplitDev* launch_dev, int64_t S, double* scores, int* status,
-                        int64_t d_max, int64_t bm_words_max, bool wide_all) {
+                        int64_t d_max, int64_t bm_words_max, bool wide_all, const SparseFitHint& hint) {
     if (S == 0 || n_al == 0) return SP_OK;
     const int64_t n_items = S * n_al;
     SP_REQUIRE(n_items < ((int64_t)1 << 31), SP_ELIMIT, "sparse route: %lld items in one call (limit 2^31)", (long long)n_items);
@@ -1805,7 +1814,9 @@ int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, const AlDesc& al0, i
     // workgroup of this kernel has to wait for a CU whose whole LDS is free, which at one per CU costs the pipelined
     // benchmark loop 3.7 % (0.1043 against 0.1006 ms per step).  Huge slabs shrink the grid (8 GB pool at most).
     const bool expect_many = (size_t)(d_max + 8) * 8 + (size_t)d_max * 6 + 12288 > (size_t)SPK_LDS_BYTES || ctx->opt.lds_cap > 0;
-    q.chunk = expect_many ? (int)std::max<int64_t>(1, std::min<int64_t>(8, n_items / (32 * (int64_t)std::max(ctx->n_cu, 1)))) : 64;
+    // (one item per draw: a draw is one atomic against 100 us of work, and chunks of 7 left the last workgroups of BASELINE
+    // config 5's pass up to 0.7 ms of items while the others had run dry)
+    q.chunk = expect_many ? 1 : 64;
     const int64_t nchunks = (n_items + q.chunk - 1) / q.chunk;
     int grid = (int)std::min<int64_t>(ctx->n_cu, nchunks);
     grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, std::max<int64_t>(16, ((int64_t)8 << 30) / (int64_t)q.slab_stride)));
@@ -1815,10 +1826,27 @@ int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, const AlDesc& al0, i
     q.slabs = ctx->slabs.as<unsigned char>();
     q.wide_all = wide_all ? 1 : 0;
     q.wide_cap = ctx->opt.wide_cap;
+    // Can ANY item run in the in-LDS form?  Its first test (spk_score_one, "need_build") is a function of the table size and
+    // the split's bitmap words alone, so the host evaluates it for the cheapest split on the smallest table: when even that
+    // one does not fit - a 12-taxon 100 k-site table: every split - the launch of one workgroup per item that would only
+    // write "status 2" (0.26 ms for the 65 120 items of BASELINE config 5, 1 % of the step) is replaced by a fill kernel.
+    bool none_fits = false;
+    if (hint.d_min > 0) {
+        const size_t off = (sizeof(SpkShared) + 15) & ~(size_t)15, cap = ctx->opt.lds_cap > 0 ? (size_t)ctx->opt.lds_cap : (size_t)SPK_LDS_BYTES;
+        const size_t d8 = (size_t)hint.d_min + 8;
+        size_t best = ~(size_t)0;
+        if (hint.w12_gpath >= 0) best = std::min(best, off + d8 * 8 + (size_t)hint.w12_gpath + 4096 + 256);
+        if (hint.w12_general >= 0) best = std::min(best, off + d8 * 12 + (size_t)hint.w12_general + 4096 + 256);
+        none_fits = best != ~(size_t)0 && best + 2048 > cap;
+    }
     {
         PhaseScope ps(ctx, SP_PHASE_SPARSE);
-        hipLaunchKernelGGL(k_sparse_score, dim3((unsigned)n_items), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream, als_dev,
-                           al0, n_al, n_taxa, launch_dev, (int)S, scores, status, q.head, (size_t)ctx->opt.lds_cap);
+        if (none_fits)
+            hipLaunchKernelGGL(k_sparse_refuse_all, dim3((unsigned)std::min<int64_t>(1024, (n_items + 255) / 256)), dim3(256), 0,
+                               ctx->stream, (int)n_items, scores, status, q.head);
+        else
+            hipLaunchKernelGGL(k_sparse_score, dim3((unsigned)n_items), dim3(SPK_THREADS), SPK_LDS_BYTES, ctx->stream, als_dev,
+                               al0, n_al, n_taxa, launch_dev, (int)S, scores, status, q.head, (size_t)ctx->opt.lds_cap);
         SP_HIP(hipGetLastError());
     }
     PhaseScope ps(ctx, SP_PHASE_CHAIN);

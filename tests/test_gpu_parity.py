@@ -677,16 +677,30 @@ def test_config3_size_subflattening(sp):
     keys, counts = syn.pattern_table(sites)
     names = syn.taxa_names(n)
     dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=length, taxa=names)
-    splits = list(sp.all_splits(names, size=2))[:40] + list(sp.all_splits(names, size=8))[:2000:50]
-    got = sp.score_splits(dev, splits, method=sp.Method.subflattening)
+    # ALL 32 751 splits (BASELINE config 3 says "all splits"), enumerated on the device, against the oracle on at least
+    # four splits of every size class - first, last and two inside - and against the list-based call on a sample
+    got, st = sp.score_all_splits(dev, method=sp.Method.subflattening, return_status=True)
+    assert len(got) == 32751 and not np.any(st & 3) and np.all(np.isfinite(got))
+    taxa_arr, a_arr = sp.encode_all_splits(n)
     M = O.moment_matrix(keys, counts, n)
-    for i in (0, 17, 39, 41, 60, 79):
-        oa = [names.index(t) for t in splits[i][0]]
-        ob = [names.index(t) for t in splits[i][1]]
-        S = M[np.ix_(O.subflattening_index(oa, n), O.subflattening_index(ob, n))] / float(length)
-        m_gpu = sp.subflattening(splits[i], dev)
-        assert np.array_equal(np.rint(m_gpu * length), np.rint(S * length))
-        assert abs(O.dense_split_score(S) - got[i]) <= SCORE_TOL
+    checked = 0
+    for k in range(2, 9):
+        idx = np.nonzero(np.minimum(a_arr, n - a_arr) == k)[0]          # (the side holding taxon 0 comes first: a = k or n - k)
+        for i in {int(idx[0]), int(idx[len(idx) // 3]), int(idx[2 * len(idx) // 3]), int(idx[-1])}:
+            oa, ob = taxa_arr[i][:a_arr[i]].tolist(), taxa_arr[i][a_arr[i]:].tolist()
+            S = M[np.ix_(O.subflattening_index(oa, n), O.subflattening_index(ob, n))] / float(length)
+            assert abs(O.dense_split_score(S) - got[i]) <= SCORE_TOL, (k, i)
+            checked += 1
+            if i == int(idx[0]):
+                split = (tuple(names[t] for t in oa), tuple(names[t] for t in ob))
+                m_gpu = sp.subflattening(split, dev)
+                assert np.array_equal(np.rint(m_gpu * length), np.rint(S * length))
+    assert checked >= 28
+    some = list(sp.all_splits(names, size=2))[:40] + list(sp.all_splits(names, size=8))[:2000:50]
+    by_list = sp.score_splits(dev, some, method=sp.Method.subflattening)
+    assert np.array_equal(by_list[:40], got[:40])          # all_splits order: the size-2 class comes first
+    pos8 = np.nonzero(np.minimum(a_arr, n - a_arr) == 8)[0][:2000:50]
+    assert np.array_equal(by_list[40:], got[pos8])
 
 
 def test_erickson_svd_matches_reference(sp, golden):
@@ -1632,11 +1646,27 @@ def test_bench_line_contract(sp):
     assert d["n_gpus"] == 1 and d["steps"] == 60 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and d["config"]["unconverged_splits_in_timed_region"] == 0
     assert abs(d["value"] - 501 * 60 / (d["ms_per_step"] * 60 * 1e-3)) <= 1e-6 * d["value"]
+    assert d["host_us_per_step"] > 0 and d["config"]["steps_per_host_call"] >= 1
     roof = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "survey_8d"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "survey_8d", "pmc_record"):
         assert key in roof, key
-    assert roof["bound"] == "lds" and 0.05 < roof["frac"] < 1.0 and roof["traffic"] > 0
-    assert 0.2 < roof["binding"]["bank_conflict_share"] < 0.8 and roof["binding"]["real_work"]["fma"] > 1e7
+    assert roof["bound"] == "lds"
+    if roof["pmc_record"]:
+        # a counter record whose source hash and workload shape match this tree: work- and busy-based fractions
+        assert 0.05 < roof["frac"] < 1.0 and roof["traffic"] > 0
+        assert 0.1 < roof["binding"]["bank_conflict_share"] < 0.8 and roof["binding"]["real_work"]["fma"] > 1e7
+        useful = roof["binding"]["useful"]
+        assert 0 < useful["conflict_free_lds_frac"] < roof["frac"] and 0 < useful["fp64_frac_of_peak"] < 0.2
+        assert 0 < useful["lds_gather_frac_of_read_peak"] < 0.5
+    else:
+        # no record of THIS kernel build: the fraction is withheld, with the reason (VERDICT r2 / ADVICE r2: a constant
+        # read from a file must not describe another kernel)
+        assert roof["frac"] is None and roof["achieved"] is None and roof["pmc_record_reason"]
+    # BASELINE's "dense flattening" pipeline, timed per phase in the same (default) invocation
+    ns = d["north_star_pipeline"]
+    assert ns["steps"] == 30 and ns["ms_per_step"] > 0 and ns["max_abs_score_diff_vs_sparse_route"] <= 1e-10
+    assert all(ns["phase_ms_per_step"][k] > 0 for k in ("reindex", "scatter", "gram", "eigen"))
+    assert abs(sum(ns["phase_ms_per_step"][k] for k in ("reindex", "scatter", "gram", "eigen")) - ns["ms_per_step"]) < 0.5 * ns["ms_per_step"]
 
 
 def test_score_all_splits_flattening_planned_on_device(sp, golden):
@@ -1791,3 +1821,143 @@ def test_regress_wide_block_close_pair(sp):
             dev.ctx.set_option("force_big", 0)
         assert np.abs(got0 - d[tag + "_want"]).max() <= SCORE_TOL, (tag, got0, d[tag + "_want"])
         assert np.abs(got1 - d[tag + "_want"]).max() <= SCORE_TOL and not np.any(st1 & 3), (tag, got1, d[tag + "_want"], st1)
+
+
+def test_plan_steps_entry(sp, golden):
+    """sp_score_plan_steps (ABI 3): n_steps complete passes from one host call, each into its own output slot - every slot
+    bit-identical to a single sp_score_plan_async pass (scores AND status words), strides checked."""
+    import ctypes as C
+    import torch
+    from splitp_amd import batch
+
+    g = golden("n10_L100k")
+    names = taxa_names(10)
+    dev = sp.DeviceAlignment.from_table(O.unpack_table(g["keys"], g["probs"], 10), taxa=names)
+    taxa_arr, a_arr = sp.encode_all_splits(10)
+    plan = batch.SplitPlan(dev.ctx, taxa_arr, a_arr, 10)
+    s_count, steps = len(a_arr), 3
+    width = batch.packed_width(s_count)
+    one = torch.zeros(width, dtype=torch.float64, device="cuda")
+    many = torch.zeros(steps * width, dtype=torch.float64, device="cuda")
+    dev.ctx.sync_stream_with_torch()
+    batch.score_plan_async(dev.ctx, [dev], plan, one.data_ptr(), one.data_ptr() + s_count * 8)
+    batch.score_plan_steps(dev.ctx, [dev], plan, steps, many.data_ptr(), width * 8, many.data_ptr() + s_count * 8, width * 8)
+    dev.ctx.synchronize()
+    torch.cuda.synchronize()
+    ref = one.cpu().numpy()
+    got = many.cpu().numpy().reshape(steps, width)
+    assert np.abs(ref[:s_count] - g["scores"]).max() <= SCORE_TOL
+    for s_ in range(steps):
+        assert np.array_equal(got[s_], ref)                                  # scores and packed status words, bit for bit
+    st = ref[s_count:].view(np.int32)[:s_count]
+    assert not np.any(st & 3) and np.all((st >> 8) >= 3)
+    lib = dev.ctx._lib
+    h = (C.c_void_p * 1)(dev.handle.value)
+    bad = lib.sp_score_plan_steps(dev.ctx.handle, h, 1, plan.handle, 2, C.c_void_p(many.data_ptr()), 8, C.c_void_p(many.data_ptr()), 8)
+    assert bad == 1 and b"step strides" in lib.sp_last_error()                # SP_EINVAL: slots would overlap
+    assert lib.sp_score_plan_steps(dev.ctx.handle, h, 1, plan.handle, 0, C.c_void_p(many.data_ptr()), 0, C.c_void_p(many.data_ptr()), 0) == 0
+
+
+def test_distributed_nccl_world_size_one(sp, golden):
+    """The RCCL code path with the real kernels: `nccl` initialised in-process at world size 1 on this
+    box's one GPU; score_splits(distributed=True) and score_all_splits(distributed=True) - kernels writing scores and
+    status straight into the all-gather's send buffer (batch.py nccl branches) - equal the undistributed calls bit for
+    bit, status words included.  Ordering contract: reference splits.py:39-59."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        assert dist.get_backend() == "nccl"
+        g = golden("n10_L100k")
+        names = taxa_names(10)
+        dev = sp.DeviceAlignment.from_table(O.unpack_table(g["keys"], g["probs"], 10), taxa=names)
+        splits = list(sp.all_splits(names))
+        plain, plain_st = sp.score_splits(dev, splits, return_status=True)
+        dsc, dst = sp.score_splits(dev, splits, distributed=True, return_status=True)
+        assert np.array_equal(dsc, plain) and np.array_equal(dst & 3, plain_st & 3) and np.array_equal(dst >> 8, plain_st >> 8)
+        assert np.abs(dsc - g["scores"]).max() <= SCORE_TOL
+        asc, ast = sp.score_all_splits(dev, distributed=True, return_status=True)
+        assert np.array_equal(asc, plain) and np.array_equal(ast, plain_st)
+        # subflattening route, 16 taxa (the partition of BASELINE configs 3 / 4: shards enumerated on the device)
+        g16 = golden("n16_L4k")
+        names16 = taxa_names(16)
+        dev16 = sp.DeviceAlignment.from_table(O.unpack_table(g16["keys"], g16["probs"], 16), taxa=names16)
+        want, want_st = sp.score_all_splits(dev16, method=sp.Method.subflattening, return_status=True)
+        got, got_st = sp.score_all_splits(dev16, method=sp.Method.subflattening, distributed=True, return_status=True)
+        assert len(got) == 32751 and np.array_equal(got, want) and np.array_equal(got_st, want_st)
+        some = splits[::7]
+        a = sp.score_splits(dev, some, method=sp.Method.subflattening, distributed=True)
+        assert np.array_equal(a, sp.score_splits(dev, some, method=sp.Method.subflattening))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_randomised_sweep_slice(sp):
+    """A bounded slice of the randomised sweeps of tools/gpu_fuzz_long.py inside the suite (the six defects of
+    round 2 were all found by those tools, none by pytest): fixed seeds - among them the families that exposed the false
+    acceptance (9100), the wide-block verdicts (37000, 51000) -, tables unlike anything a tree produces (4 - 12 taxa,
+    2 - 4 letters, counts up to 70 000 x), every split against the oracle on the default chain, on the hand-back chain
+    with the LDS capped at 30 KB and 12 KB (lists-in-global / all-global forms) and on the forced big-table form.
+    Gate as in the tools: score within 1e-10, or 1 - top4/trace within 8e-15 (the fp64 floor, decides scores < 2e-5)."""
+    import time
+    from splitp_amd.device import Context, current_device
+
+    def close(a, b):
+        return abs(a - b) <= 1e-10 or abs(a * a - b * b) <= 8e-15
+
+    t0 = time.time()
+    checked = 0
+    variants = []
+    for vname, opts in (("default", {}), ("lds_cap 30 KB", {"lds_cap": 30000}), ("lds_cap 12 KB", {"lds_cap": 12000}),
+                        ("big-table form", {"force_big": 1})):
+        ctx = Context(current_device())          # one context per variant: options are per context
+        for key, val in opts.items():
+            ctx.set_option(key, val)
+        variants.append((vname, ctx))
+    for seed0, ntr in ((9100, 16), (37000, 12), (51000, 12), (2026, 16)):
+        rng = np.random.default_rng(seed0)
+        for trial in range(ntr):
+            n = int(rng.integers(4, 13))
+            length = int(rng.choice([10, 60, 400, 2500, 20000]))
+            letters = int(rng.choice([2, 3, 4, 4]))
+            keys, counts = _copy_mutate_table(rng, n, length, letters)
+            if trial % 7 == 0:
+                counts = counts * int(rng.choice([300, 70_000]))
+            names = taxa_names(n)
+            if n <= 6:
+                splits = list(sp.all_splits(names))
+            else:
+                splits = []
+                for _ in range(10):
+                    k = int(rng.integers(2, n - 1))
+                    left = sorted(rng.choice(n, size=k, replace=False).tolist())
+                    splits.append((tuple(names[t] for t in left), tuple(names[t] for t in range(n) if t not in left)))
+            want = []
+            for spl in splits:
+                M = O.reduced_flattening_packed(keys, counts.astype(np.float64), n, [names.index(t) for t in spl[0]],
+                                                [names.index(t) for t in spl[1]])[0]
+                w = None if min(M.shape) > 400 else (0.0 if min(M.shape) <= 4 else O.dense_split_score(M))
+                want.append(0.0 if (w is not None and np.isnan(w)) else w)
+            which = variants if trial % 2 == 0 else variants[:1]
+            for vname, ctx in which:
+                dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=int(counts.sum()), taxa=names, ctx=ctx)
+                got, st = sp.score_splits(dev, splits, return_status=True)
+                for i, w in enumerate(want):
+                    if w is None:
+                        continue
+                    checked += 1
+                    assert close(w, got[i]) or (st[i] & 1), (vname, seed0, trial, n, length, letters, i, w, got[i], hex(int(st[i])))
+    assert checked >= 1000, checked
+    assert time.time() - t0 < 120, "the sweep slice is meant to stay within a minute or two"
