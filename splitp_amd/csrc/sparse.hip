@@ -1454,56 +1454,95 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
         const u32* const Gt = reinterpret_cast<const u32*>(Wb);
         for (it = 1; it <= SPK_MAXIT; ++it) {
             // Y = G V densely; Ritz sum = trace(V^T Y); Y staged in registers, written over V
+            if (it == 2) SSTAMP(56);
             int row = threadIdx.x >> 2, j = threadIdx.x & 3;
             double acc = 0, part = 0;
             if (mid) {
-                // R <= 256, G packed.  One v_mfma_f64_4x4x4 = 4 independent 4 x 4 x 4 blocks; lane l supplies A[i][kk] of
-                // block b at l = i + 4 b + 16 kk and B[kk][j] at l = j + 4 b + 16 kk, D[i][j] of block b comes back in lane
-                // j + 4 b + 16 i (layout: spk_gram).  Here the four blocks are four K-PARTS of the same 4 rows: step t of a
-                // row group takes k = 16 t + 4 b + kk, i.e. 4 rows x 16 consecutive k per instruction, and the blocks are
-                // added up at the end (two shuffles).  With that assignment a lane's B operands are V[16 t + 4 b + kk][j],
-                // t = 0 .. R/16 - 1: 16 doubles that do not depend on the row group - they are loaded into registers ONCE
-                // per product, and the LDS is left with one 4-byte read per G cell (with V read per instruction as well
-                // the product was LDS-instruction bound: 2048 wave-instructions, 26 k cycles).
+                // R = 256, G packed integers.  Plain fp64 FMAs, not the matrix cores: with only 4 right-hand columns a
+                // v_mfma_f64_4x4x4 (256 FMA) occupies the matrix pipe as long as a 16 x 16 x 4 (1024 FMA) - measured
+                // 22 k cycles per product, against 4 k cycles for the same 262 k FMA at the vector rate.  Thread = 4 rows x
+                // every 16th k: lane (s16 = lane & 15, row group = lane >> 4) of wave w takes rows 16 w + 4 (lane >> 4) .. + 3
+                // and k = s16, 16 + s16, ...: the 16 lanes of a group read 16 consecutive cells of a G row and 16 consecutive
+                // rows of V per instruction (no bank conflicts), a V row is fetched once per 4 rows of G, and the 16 partial
+                // sums of a (row, column) meet in the DPP row reduction of spk_spmm.
                 const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-                const int li = lane & 3, lb = (lane >> 2) & 3, lk = lane >> 4;
-                constexpr int NT = SPK_MID_R / 16;
-                double bv[NT];
+                const int s16 = lane & 15, r0 = 16 * w + 4 * (lane >> 4);
+                double a4[4][4];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) bv[t] = V[(16 * t + 4 * lb + lk) * v_rs + li * v_cs];   // (R == SPK_MID_R: no bounds)
-                // row groups of 4: SPK_MID_R / 4 = 64 of them, 4 per wave (wave w: rows 16 w .. 16 w + 15); lane (li, lb, lk)
-                // reports D[i = lk][j = li] of group lb.  (The group loop is NOT unrolled: unrolled, the 64 cell addresses
-                // of a wave's four groups were all kept live and the function spilled to scratch in every loop it has.)
-#pragma unroll 1
-                for (int g = 0; g < 4; ++g) {
-                    const int arow = 16 * w + 4 * g + li;
-                    double d0 = 0.0, d1 = 0.0;
+                for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                    for (int t = 0; t < NT; t += 2) {
-                        const int k0 = 16 * t + 4 * lb + lk, k1 = k0 + 16;
-                        // (unconditional reads: a predicated read became a branch with its own s_waitcnt - 64 LDS round trips
-                        // in a row per wave and product, 24 k cycles)
-                        const double a0 = (double)Gt[tri(min(arow, k0), max(arow, k0))];
-                        const double a1 = (double)Gt[tri(min(arow, k1), max(arow, k1))];
-                        d0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, bv[t], d0, 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, bv[t + 1], d1, 0, 0, 0);
+                    for (int c = 0; c < 4; ++c) a4[rr][c] = 0.0;
+                // cell (r, k) of the packed triangle: rowb[r] + k for k >= r, colb(k) + r for k < r.  A wave's rows are
+                // 16 w .. 16 w + 15 and step kk covers k = 16 kk .. 16 kk + 15, so the case is uniform except at kk == w: one
+                // add per cell instead of the eight integer operations of tri() (the loop is VALU-issue bound: every
+                // instruction costs the block 16 cycles).
+                int rowb[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) rowb[rr] = tri(r0 + rr, r0 + rr) - (r0 + rr);
+                auto step = [&](int kk, auto which) {
+                    const int k = 16 * kk + s16;
+                    double v[4], gcell[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = V[k * v_rs + c * v_cs];
+                    const int colb = tri(k, k) - k;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        int cell;
+                        if (decltype(which)::value == 0) cell = colb + r0 + rr;            // k < r
+                        else if (decltype(which)::value == 2) cell = rowb[rr] + k;         // k > r
+                        else cell = k >= r0 + rr ? rowb[rr] + k : colb + r0 + rr;
+                        gcell[rr] = (double)Gt[cell];
                     }
-                    double d = d0 + d1;
-                    d += __shfl_xor(d, 4, 64);               // sum of the four K-parts: every block now holds D[i][j]
-                    d += __shfl_xor(d, 8, 64);
-                    acc = lb == g ? d : acc;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a4[rr][c] = fma(gcell[rr], v[c], a4[rr][c]);
+                };
+#pragma unroll 2
+                for (int kk = 0; kk < w; ++kk) step(kk, std::integral_constant<int, 0>{});
+                step(w, std::integral_constant<int, 1>{});
+#pragma unroll 2
+                for (int kk = w + 1; kk < SPK_MID_R / 16; ++kk) step(kk, std::integral_constant<int, 2>{});
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        double x = a4[rr][c];
+                        x += spk_dpp<SPK_DPP_QUAD_XOR1>(x);
+                        x += spk_dpp<SPK_DPP_QUAD_XOR2>(x);
+                        x += spk_dpp<SPK_DPP_ROW_SHR4>(x);
+                        x += spk_dpp<SPK_DPP_ROW_SHR8>(x);     // lane 15 of every 16-lane row: the whole sum
+                        a4[rr][c] = x;
+                    }
+                part = 0.0;
+                if (s16 == 15) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) part = fma(a4[rr][c], V[(r0 + rr) * v_rs + c * v_cs], part);
                 }
-                row = 16 * w + 4 * lb + lk;
-                j = li;
-                if (row < R) part = acc * V[row * v_rs + j * v_cs]; else row = R;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+                if (it == 2) SSTAMP(57);
+                __syncthreads();
+                if (s16 == 15) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) V[(r0 + rr) * v_rs + c * v_cs] = a4[rr][c];
+                }
+                row = R;   // (the common tail below writes nothing more)
             } else if (row < R) {
                 for (int k = 0; k < R; ++k) acc = fma(Wb[row * Gp + k], V[k * v_rs + j * v_cs], acc);
                 part = acc * V[row * v_rs + j * v_cs];
             }
+            if (!mid) {
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-            __syncthreads();
-            if (row < R) V[row * v_rs + j * v_cs] = acc;
+                for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+                if (it == 2) SSTAMP(57);
+                __syncthreads();
+                if (row < R) V[row * v_rs + j * v_cs] = acc;
+            }
             if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = part;
             __syncthreads();
             top4 = 0;
@@ -1511,6 +1550,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             for (int ww = 0; ww < SPK_WAVES; ++ww) top4 += sh.red[ww];
             __syncthreads();   // spk_gram reuses sh.red: nobody may still be summing it (a rare race, caught after 36 rounds)
             spk_gram(V, R, v_rs, v_cs, sh);                  // Y^T Y = V^T G^2 V: its eigenvalues are the squared Ritz values
+            if (it == 2) SSTAMP(58);
             // (S holds SQUARED Ritz values here: the cheap bound suffices when rest^2 <= 0.09 of it, i.e. rest <= 0.3 sqrt)
             const double rest_s = trace - top4;
             spk_chol_factor(sh, it >= 3, rest_s > 0 ? rest_s * rest_s * (1.0 / 0.3) : 0.0);
@@ -1518,7 +1558,9 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
                 conv = 1;
                 break;
             }
+            if (it == 2) SSTAMP(59);
             spk_orth(V, R, v_rs, v_cs, sh);
+            if (it == 2) SSTAMP(60);
         }
     } else {
         SSTAMP(7);
