@@ -23,7 +23,7 @@
 
 #include "common.h"
 
-#include <rocprim/rocprim.hpp>   // radix sort + run-length encode for the sort-based histogram
+#include "radix_sort.h"   // hand-written LSD radix sort + run-length encode for the sort-based histogram
 
 #define HIST_THREADS 256
 #define HIST_PER_THREAD 8
@@ -266,33 +266,26 @@ __global__ void k_widen_keys(const KT* __restrict__ in, int64_t D, u64* __restri
 template <typename KT>
 static int build_sorted(sp_ctx* ctx, const KT* dkeys, int64_t L, int n_taxa, sp_alignment** out) {
     SP_REQUIRE(L < ((int64_t)1 << 32), SP_ELIMIT, "sort-based histogram: at most 2^32 - 1 sites per call (got %lld)", (long long)L);
-    DevBuf sorted, uniq, cnts, nruns, tmp;
-    auto cleanup = [&]() { sorted.release(); uniq.release(); cnts.release(); nruns.release(); tmp.release(); };
+    DevBuf sorted, sorted2, uniq, cnts, nruns, tmp;
+    auto cleanup = [&]() { sorted.release(); sorted2.release(); uniq.release(); cnts.release(); nruns.release(); tmp.release(); };
     auto fail = [&](int code) { cleanup(); return code; };
     const size_t l1 = (size_t)std::max<int64_t>(L, 1);
     int rc;
-    if ((rc = sorted.ensure(l1 * sizeof(KT))) || (rc = uniq.ensure(l1 * sizeof(KT))) || (rc = cnts.ensure(l1 * 4)) ||
-        (rc = nruns.ensure(16)))
+    if ((rc = sorted.ensure(l1 * sizeof(KT))) || (rc = sorted2.ensure(l1 * sizeof(KT))) || (rc = uniq.ensure(l1 * sizeof(KT))) ||
+        (rc = cnts.ensure(l1 * 4)) || (rc = nruns.ensure(16)))
         return fail(rc);
     const unsigned end_bit = (unsigned)std::min<int>(2 * n_taxa + 1, 8 * (int)sizeof(KT));   // + 1: the marker's bit
     u32 nr = 0;
     if (L > 0) {
         PhaseScope ps(ctx, SP_PHASE_HIST);
-        size_t t1 = 0, t2 = 0;
-        hipError_t e = rocprim::radix_sort_keys(nullptr, t1, dkeys, sorted.as<KT>(), (size_t)L, 0u, end_bit, ctx->stream);
-        if (e == hipSuccess)
-            e = rocprim::run_length_encode(nullptr, t2, sorted.as<KT>(), (unsigned int)L, uniq.as<KT>(), cnts.as<u32>(),
-                                           nruns.as<u32>(), ctx->stream);
-        if (e != hipSuccess) {
-            sp_set_error("rocPRIM size query failed: %s", hipGetErrorString(e));
-            return fail(SP_EHIP);
-        }
-        if ((rc = tmp.ensure(std::max<size_t>(std::max(t1, t2), 16)))) return fail(rc);
-        e = rocprim::radix_sort_keys(tmp.p, t1, dkeys, sorted.as<KT>(), (size_t)L, 0u, end_bit, ctx->stream);
-        if (e == hipSuccess)
-            e = rocprim::run_length_encode(tmp.p, t2, sorted.as<KT>(), (unsigned int)L, uniq.as<KT>(), cnts.as<u32>(),
-                                           nruns.as<u32>(), ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(&nr, nruns.p, 4, hipMemcpyDeviceToHost, ctx->stream);
+        // (round 3: radix_sort.h - stable LSD passes of 8 bits by wave match + a run-length encode by head flags; rounds
+        // 1 - 2 called rocprim::radix_sort_keys / run_length_encode here)
+        const KT* skeys = nullptr;
+        if ((rc = rs_sort<KT>(ctx, dkeys, sorted.as<KT>(), sorted2.as<KT>(), nullptr, nullptr, nullptr, L, 1, end_bit, tmp, &skeys,
+                              nullptr)))
+            return fail(rc);
+        if ((rc = rs_run_length_encode<KT>(ctx, skeys, L, uniq.as<KT>(), cnts.as<u32>(), nruns.as<u32>(), tmp))) return fail(rc);
+        hipError_t e = hipMemcpyAsync(&nr, nruns.p, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             sp_set_error("sort-based histogram failed: %s", hipGetErrorString(e));

@@ -3,7 +3,7 @@
 // Same block iteration, stop rule and Cholesky-QR as sparse.hip (sparse_common.h).
 #include "sparse_common.h"
 
-#include <rocprim/rocprim.hpp>   // stable segmented radix sort: both list orders of every split in one call each
+#include "radix_sort.h"   // stable segmented radix sort: both list orders of every split in one call each
 
 // =====================================================================================================================
 // Big-table form: count tables with more than 65535 patterns (the 16-bit ids / offsets of the list kernels above end
@@ -403,24 +403,21 @@ int launch_sparse_big(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, const u3
     hipLaunchKernelGGL(k_segment_offsets, dim3((unsigned)((S + 256) / 256)), dim3(256), 0, ctx->stream, off.as<u32>(), D, (int)S);
     unsigned bits = 1;
     while (bits < 32 && ((int64_t)1 << bits) < D) ++bits;   // compact ids are < D
-    size_t t1 = 0;
-    hipError_t e = rocprim::segmented_radix_sort_pairs(nullptr, t1, cc, keyc.as<u32>(), iota.as<u32>(), permc.as<u32>(),
-                                                       (unsigned)total, (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits,
-                                                       ctx->stream);
-    if (e != hipSuccess) {
-        sp_set_error("big-table form: rocPRIM size query failed: %s", hipGetErrorString(e));
-        return fail(SP_EHIP);
-    }
-    if ((rc = tmp.ensure(std::max<size_t>(t1, 16)))) return fail(rc);
-    e = rocprim::segmented_radix_sort_pairs(tmp.p, t1, cc, keyc.as<u32>(), iota.as<u32>(), permc.as<u32>(), (unsigned)total,
-                                            (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits, ctx->stream);
-    if (e == hipSuccess)
-        e = rocprim::segmented_radix_sort_pairs(tmp.p, t1, rr, keyr.as<u32>(), iota.as<u32>(), permr.as<u32>(), (unsigned)total,
-                                                (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits, ctx->stream);
-    if (e != hipSuccess) {
-        sp_set_error("big-table form: segmented sort failed: %s", hipGetErrorString(e));
-        return fail(SP_EHIP);
-    }
+    // Stable sort of every split's D (compact id, pattern index) pairs by id - S independent segments of D entries
+    // (radix_sort.h, round 3; rounds 1 - 2: rocprim::segmented_radix_sort_pairs).  The passes ping-pong between the named
+    // buffer and a shared alternate; the first target is chosen so that the last pass lands in the named one.
+    DevBuf &altk = ctx->big[12], &altv = ctx->big[13];
+    if ((rc = altk.ensure(total * 4)) || (rc = altv.ensure(total * 4))) return fail(rc);
+    const unsigned passes = (bits + RS_BITS - 1) / RS_BITS;
+    auto sort_side = [&](const u32* ids, DevBuf& keyb, DevBuf& permb) -> int {
+        const u32 *sk = nullptr, *sv = nullptr;
+        u32 *ka = (passes & 1) ? keyb.as<u32>() : altk.as<u32>(), *kb = (passes & 1) ? altk.as<u32>() : keyb.as<u32>();
+        u32 *va = (passes & 1) ? permb.as<u32>() : altv.as<u32>(), *vb = (passes & 1) ? altv.as<u32>() : permb.as<u32>();
+        SP_CHECK(rs_sort<u32>(ctx, ids, ka, kb, iota.as<u32>(), va, vb, D, S, bits, tmp, &sk, &sv));
+        SP_REQUIRE(sk == keyb.as<u32>() && sv == permb.as<u32>(), SP_EHIP, "big-table form: sorted lists landed in the wrong buffer");
+        return SP_OK;
+    };
+    if ((rc = sort_side(cc, keyc, permc)) || (rc = sort_side(rr, keyr, permr))) return fail(rc);
     const int rc2 = counts ? big_run_kernel<u32>(ctx, D, S, rr, cc, keyc.as<u32>(), permc.as<u32>(), keyr.as<u32>(), permr.as<u32>(),
                                             counts, dims, dev_cus, scores, status)
                            : big_run_kernel<double>(ctx, D, S, rr, cc, keyc.as<u32>(), permc.as<u32>(), keyr.as<u32>(),
@@ -518,28 +515,24 @@ int launch_sparse_big_keys(sp_ctx* ctx, const u64* keys, int64_t D, int n, const
                        (int64_t)total);
     hipLaunchKernelGGL(k_segment_offsets, dim3((unsigned)((S + 256) / 256)), dim3(256), 0, ctx->stream, off.as<u32>(), D, (int)S);
     const unsigned bits = (unsigned)(2 * max_side);
-    size_t t1 = 0;
-    e = rocprim::segmented_radix_sort_pairs(nullptr, t1, ck.as<u64>(), sk.as<u64>(), iota.as<u32>(), permc.as<u32>(),
-                                            (unsigned)total, (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits, ctx->stream);
-    if (e != hipSuccess) {
-        sp_set_error("big-table form: rocPRIM size query failed: %s", hipGetErrorString(e));
-        return fail(SP_EHIP);
-    }
-    if ((rc = tmp.ensure(std::max<size_t>(t1, 16)))) return fail(rc);
     int* dimp = reinterpret_cast<int*>(dims.p);
-    e = rocprim::segmented_radix_sort_pairs(tmp.p, t1, ck.as<u64>(), sk.as<u64>(), iota.as<u32>(), permc.as<u32>(),
-                                            (unsigned)total, (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits, ctx->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_compact_sorted, dim3((unsigned)S), dim3(1024), 0, ctx->stream, sk.as<u64>(), permc.as<u32>(), D,
-                           idc_s.as<u32>(), cc.as<u32>(), dimp + 1, 2);   // .y = columns
-        e = rocprim::segmented_radix_sort_pairs(tmp.p, t1, rk.as<u64>(), sk.as<u64>(), iota.as<u32>(), permr.as<u32>(),
-                                                (unsigned)total, (unsigned)S, off.as<u32>(), off.as<u32>() + 1, 0u, bits,
-                                                ctx->stream);
-    }
-    if (e != hipSuccess) {
-        sp_set_error("big-table form: segmented sort failed: %s", hipGetErrorString(e));
-        return fail(SP_EHIP);
-    }
+    // stable sort of every split's (raw side key, pattern index) pairs by key: S segments of D entries (radix_sort.h)
+    DevBuf &altk = ctx->big[12], &altv = ctx->big[13];
+    if ((rc = altk.ensure(total * 8)) || (rc = altv.ensure(total * 4))) return fail(rc);
+    const unsigned passes = (bits + RS_BITS - 1) / RS_BITS;
+    auto sort_side = [&](const u64* side_keys, DevBuf& permb) -> int {
+        const u64* skp = nullptr;
+        const u32* svp = nullptr;
+        u64 *ka = (passes & 1) ? sk.as<u64>() : altk.as<u64>(), *kb = (passes & 1) ? altk.as<u64>() : sk.as<u64>();
+        u32 *va = (passes & 1) ? permb.as<u32>() : altv.as<u32>(), *vb = (passes & 1) ? altv.as<u32>() : permb.as<u32>();
+        SP_CHECK(rs_sort<u64>(ctx, side_keys, ka, kb, iota.as<u32>(), va, vb, D, S, bits, tmp, &skp, &svp));
+        SP_REQUIRE(skp == sk.as<u64>() && svp == permb.as<u32>(), SP_EHIP, "big-table form: sorted lists landed in the wrong buffer");
+        return SP_OK;
+    };
+    if ((rc = sort_side(ck.as<u64>(), permc))) return fail(rc);
+    hipLaunchKernelGGL(k_compact_sorted, dim3((unsigned)S), dim3(1024), 0, ctx->stream, sk.as<u64>(), permc.as<u32>(), D,
+                       idc_s.as<u32>(), cc.as<u32>(), dimp + 1, 2);   // .y = columns
+    if ((rc = sort_side(rk.as<u64>(), permr))) return fail(rc);
     hipLaunchKernelGGL(k_compact_sorted, dim3((unsigned)S), dim3(1024), 0, ctx->stream, sk.as<u64>(), permr.as<u32>(), D,
                        idr_s.as<u32>(), rr.as<u32>(), dimp, 2);            // .x = rows
     const int2* dims2 = reinterpret_cast<const int2*>(dims.p);
