@@ -3,7 +3,7 @@
 //
 // Stable least-significant-digit passes of RS_BITS = 8 bits.  One pass = three launches:
 //   k_rs_hist     one workgroup (256 threads, 4 waves) per tile of RS_TILE = 4096 keys: digit histogram of the tile in LDS
-//                 (wave-private rows, LDS atomics), written to hist[(segment * 256 + digit) * blocks_per_segment + block]
+//                 (wave-private rows, LDS atomics), written to hist[(segment * RADIX + digit) * blocks_per_segment + block]
 //   k_rs_scan     exclusive scan of that array in exactly that order - segment-major, then digit, then tile: the offsets of
 //                 an independent sort per segment (segments = equal-length contiguous pieces; 1 segment = a plain sort)
 //   k_rs_scatter  the tile again: every key's rank among the keys of its digit inside the tile, by WAVE MATCH - eight
@@ -17,8 +17,8 @@
 #pragma once
 #include "common.h"
 
-#define RS_BITS 8
-#define RS_RADIX 256
+#define RS_BITS 8            // (9-bit digits - one pass fewer on 33-, 41- and 17-bit keys, a 64 KB rank table - measured the same at
+#define RS_RADIX 256         // 1 M keys, 0.33 / 0.42 ms, and slower at 4 - 8 M keys, 0.65 / 1.03 against 0.40 / 0.86 ms: kept at 8)
 #define RS_THREADS 256
 #define RS_WAVES (RS_THREADS / 64)
 #define RS_ITEMS 16
@@ -27,7 +27,7 @@
 template <typename KT>
 __device__ __forceinline__ u32 rs_digit(KT key, int shift) { return (u32)((key >> shift) & (KT)(RS_RADIX - 1)); }
 
-// hist[(seg * 256 + d) * bps + blk]: keys of digit d in tile blk of segment seg
+// hist[(seg * RADIX + d) * bps + blk]: keys of digit d in tile blk of segment seg
 template <typename KT>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const KT* __restrict__ keys, int64_t seg_len, int bps, int shift,
                                                         u32* __restrict__ hist, u32* __restrict__ tot) {
@@ -43,21 +43,24 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const KT* __restrict__ k
         if (i < seg_len) atomicAdd(&cnt[w][rs_digit(keys[base + i], shift)], 1u);
     }
     __syncthreads();
-    const u32 total = cnt[0][threadIdx.x] + cnt[1][threadIdx.x] + cnt[2][threadIdx.x] + cnt[3][threadIdx.x];
-    hist[((size_t)seg * RS_RADIX + threadIdx.x) * bps + blk] = total;
-    if (total) atomicAdd(&tot[seg * RS_RADIX + threadIdx.x], total);   // (integer: the order of the adds does not matter)
+    for (int d = threadIdx.x; d < RS_RADIX; d += RS_THREADS) {
+        const u32 total = cnt[0][d] + cnt[1][d] + cnt[2][d] + cnt[3][d];
+        hist[((size_t)seg * RS_RADIX + d) * bps + blk] = total;
+        if (total) atomicAdd(&tot[seg * RS_RADIX + d], total);   // (integer: the order of the adds does not matter)
+    }
 }
 
-// Offsets of one pass: workgroup (segment, digit) turns its row hist[(seg * 256 + d) * bps + 0 .. bps) - contiguous, read
+// Offsets of one pass: workgroup (segment, digit) turns its row hist[(seg * RADIX + d) * bps + 0 .. bps) - contiguous, read
 // coalesced - into exclusive prefixes and adds the row's base = seg * seg_len + (keys of smaller digits in the segment, from
-// the per-digit totals k_rs_hist accumulated).  256 x segments workgroups instead of one (a single-workgroup scan of the
+// the per-digit totals k_rs_hist accumulated).  RADIX x segments workgroups instead of one (a single-workgroup scan of the
 // 500 k counters of an 8 M-key sort took 0.5 ms per pass).  Also zeroes the totals of the NEXT pass (the other buffer).
 static __global__ __launch_bounds__(RS_THREADS) void k_rs_offsets(u32* __restrict__ hist, const u32* __restrict__ tot,
                                                            u32* __restrict__ tot_next, int64_t seg_len, int bps) {
     __shared__ u32 wsum[RS_WAVES + 1];
     const int seg = blockIdx.x / RS_RADIX, d = blockIdx.x % RS_RADIX;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    u32 below = (int)threadIdx.x < d ? tot[seg * RS_RADIX + threadIdx.x] : 0u;
+    u32 below = 0;
+    for (int t = threadIdx.x; t < d; t += RS_THREADS) below += tot[seg * RS_RADIX + t];
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) below += __shfl_xor(below, k, 64);
     if (lane == 0) wsum[w] = below;
@@ -86,7 +89,8 @@ static __global__ __launch_bounds__(RS_THREADS) void k_rs_offsets(u32* __restric
         run += all;
         __syncthreads();
     }
-    if (d == 0 && threadIdx.x < RS_RADIX) tot_next[seg * RS_RADIX + threadIdx.x] = 0;
+    if (d == 0)
+        for (int t = threadIdx.x; t < RS_RADIX; t += RS_THREADS) tot_next[seg * RS_RADIX + t] = 0;
 }
 
 // in-place exclusive scan of n u32 by ONE workgroup of 1024 threads (n = segments x 256 x tiles: 63 k words for a
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KT* __restrict_
     KT key[RS_ITEMS];
     u32 val[RS_ITEMS];
     unsigned short rank[RS_ITEMS];
-    unsigned char dig[RS_ITEMS];
+    unsigned short dig[RS_ITEMS];
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
         const int64_t i = lo + j * RS_THREADS + threadIdx.x;
@@ -146,17 +150,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KT* __restrict_
             const unsigned long long bal = __ballot((d >> b) & 1u);
             m &= ((d >> b) & 1u) ? bal : ~bal;
         }
-        dig[j] = (unsigned char)d;
+        dig[j] = (unsigned short)d;
         rank[j] = (unsigned short)__popcll(m & ((1ull << lane) - 1ull));
         if (in && rank[j] == 0) segcnt[j * RS_WAVES + w][d] = (unsigned short)__popcll(m);   // (the first lane of the group)
     }
     __syncthreads();
-    {   // exclusive prefix over the 64 segments, one digit per thread (tile order = item-major, then wave)
-        unsigned int run = 0;
+    for (int d = threadIdx.x; d < RS_RADIX; d += RS_THREADS) {   // exclusive prefix over the 64 segments, digit by digit
+        unsigned int run = 0;                                       // (tile order = item-major, then wave)
 #pragma unroll 8
         for (int s = 0; s < RS_ITEMS * RS_WAVES; ++s) {
-            const unsigned int c = segcnt[s][threadIdx.x];
-            segcnt[s][threadIdx.x] = (unsigned short)run;
+            const unsigned int c = segcnt[s][d];
+            segcnt[s][d] = (unsigned short)run;
             run += c;
         }
     }
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KT* __restrict_
 // Stable sort of `n_seg` independent segments of `seg_len` keys each (n_seg = 1: one array) on the bits [0, end_bit).
 // keys_in (and vals_in, optional values carried with the keys) are only read; the passes ping-pong between the two work
 // arrays keys_a / keys_b (vals_a / vals_b), n = seg_len * n_seg elements each, and the result ends up in *sorted_keys
-// (*sorted_vals), one of the two.  work: (n_seg * 256 * tiles + 16) u32.
+// (*sorted_vals), one of the two.  work: n_seg * RADIX * (tiles + 2) + 16 u32 (grown here).
 template <typename KT>
 static int rs_sort(sp_ctx* ctx, const KT* keys_in, KT* keys_a, KT* keys_b, const u32* vals_in, u32* vals_a, u32* vals_b,
                    int64_t seg_len, int64_t n_seg, unsigned end_bit, DevBuf& work, const KT** sorted_keys,
