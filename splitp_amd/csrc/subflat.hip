@@ -483,8 +483,18 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
                 if (lane == 0) sw.e2[k] = x0 * x0;
                 continue;
             }
-            const double alpha = x0 >= 0 ? -sqrt(sig) : sqrt(sig);
-            const double beta = 1.0 / (sig - alpha * x0);    // 2 / (v^T v)
+            // sqrt and reciprocal by the hardware seeds + Newton steps (an IEEE fp64 sqrt and division are ~25 and ~30
+            // instructions, and this kernel is VALU-issue bound: 75 % of the issue slots, profiles/r03a_pmc_binding_config4.json)
+            double ry = __builtin_amdgcn_rsq(sig);
+            ry = ry * fma(-0.5 * sig * ry, ry, 1.5);
+            ry = ry * fma(-0.5 * sig * ry, ry, 1.5);
+            double sq = sig * ry;
+            sq = fma(0.5 * ry, fma(-sq, sq, sig), sq);        // sqrt(sig) to the last bit or two
+            const double alpha = x0 >= 0 ? -sq : sq;
+            const double den = sig - alpha * x0;
+            double beta = __builtin_amdgcn_rcp(den);          // 2 / (v^T v)
+            beta = fma(fma(-den, beta, 1.0), beta, beta);
+            beta = fma(fma(-den, beta, 1.0), beta, beta);
             const double vi = (lane == 0) ? x0 - alpha : x;   // v (lane < L)
             if (lane == 0) sw.e2[k] = sig;                    // alpha^2
             if (lane < 32) sw.v[lane] = lane < L ? vi : 0.0;
