@@ -329,7 +329,9 @@ extern "C" int sp_alignment_destroy(sp_alignment* al) {
     return sp_guard("sp_alignment_destroy", [&]() -> int {
     if (!al) return SP_OK;
     (void)hipSetDevice(al->ctx->device);
-    (void)hipStreamSynchronize(al->ctx->stream);
+    // lanes (other contexts, other streams) may still be reading keys32 / counts / aldesc of this table: wait for the whole
+    // device, not only for the creator's stream (sp_plan_release does the same)
+    (void)hipDeviceSynchronize();
     al->keys.release();
     al->weights.release();
     al->counts.release();

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -235,7 +236,7 @@ struct SparseFitHint {
 // heaviest-first launch order.  Uploaded synchronously at creation and never written again, so any number of contexts
 // (lanes) of the same device may score with it concurrently.
 struct sp_plan {
-    int refs = 1;
+    std::atomic<int> refs{1};   // (retain / release may come from several host threads, one per lane)
     int device = 0;
     int n = 0;
     int64_t S = 0;

@@ -4,8 +4,8 @@ call with the alignment resident in HBM (the reference scores them one by one th
 
 Same contract as the reference: returns the list of chosen splits (each a sorted tuple of two sorted taxon tuples),
 memoises scores across rounds (:122-124, :142), takes the first minimum in pair-enumeration order (:146), merges the
-winning pair (:160-170).  Supported methods: Method.flattening and Method.subflattening (the reference's
-mutual-information branch scores a different functional and is out of this path's scope)."""
+winning pair (:160-170).  Supported methods: Method.flattening, Method.subflattening and Method.mutual_information
+(the reference's third branch, :135-140: flattening_rank_1_approximation_divergence, batched in csrc/divergence.hip)."""
 from itertools import combinations
 
 import numpy as np

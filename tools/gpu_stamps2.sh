@@ -29,10 +29,13 @@ for k in (5, 4, 3, 2):
         out = (C.c_longlong * 64)()
         lib.sp_debug_spk_stamps(out)
         o = np.array(out[:], dtype=np.int64)
-        print(f"k={k} block {blk}: stage={o[1]-o[0]} CSC={o[2]-o[1]} CSR={o[3]-o[2]} start={o[4]-o[3]} G/Vinit+W1+orth={o[7]-o[4]} "
-              f"spmm_it2={o[9]-o[7]} gram2={o[40]-o[9]} orth2={o[41]-o[40]} spmm_it3={o[8]-o[41]} rest={o[11]-o[8]} total={o[11]-o[0]}")
-        print(f"     CSC build: pre={o[55]-o[1]} passA={o[50]-o[55]} prefix={o[51]-o[50]} class+perm={o[52]-o[51]} scan+ptr={o[53]-o[52]} passB={o[2]-o[53]} (Gram path: scans={o[51]-o[50]} passB={o[2]-o[51]}) "
-              f"| spmm_it3: wave={o[30]-o[41]} row={o[32]-o[30]} quad={o[20]-o[32]} lane={o[8]-o[20]} | G: zero={o[44]-o[4]} pairs={o[45]-o[44]} conv={o[5]-o[45]}")
-        print(f"     atomic form (k >= 4): stage={o[1]-o[0]} top+init+orth={o[5]-o[1]} | it2: zero+product={o[9]-o[5]} convert+gram={o[40]-o[9]} chol+orth={o[41]-o[40]} "
-              f"| it3: zero={o[20]-o[41]} product={o[30]-o[20]} convert={o[8]-o[30]} | rest={o[11]-o[8]} total={o[11]-o[0]}")
+        # (every number printed is the difference of two stamps the path in question really sets: a general-path split
+        # sets none of the Gram path's stamps and vice versa - round 2's table printed those too, as garbage)
+        if k >= 4:
+            print(f"k={k} block {blk} (general path): stage={o[1]-o[0]} both lists={o[2]-o[1]} start rows={o[4]-o[3]} W init + first half product + orth={o[7]-o[4]} "
+                  f"spmm_it2={o[9]-o[7]} gram2={o[40]-o[9]} orth2={o[41]-o[40]} spmm_it3={o[8]-o[41]} rest={o[11]-o[8]} total={o[11]-o[0]}")
+            print(f"     spmm_it3 by size class: wave={o[30]-o[41]} row={o[32]-o[30]} quad={o[20]-o[32]} lane={o[8]-o[20]}")
+        else:
+            print(f"k={k} block {blk} (Gram path): stage={o[1]-o[0]} list={o[2]-o[1]} start rows={o[4]-o[3]} G zero={o[44]-o[4]} pairs={o[45]-o[44]} "
+                  f"convert + V init={o[5]-o[45]} iterate={o[11]-o[6]} total={o[11]-o[0]} | iteration 2: product={o[57]-o[56]} sum+gram={o[58]-o[57]} chol+stop={o[59]-o[58]} orth={o[60]-o[59]}")
 PY
