@@ -1554,7 +1554,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             // (S holds SQUARED Ritz values here: the cheap bound suffices when rest^2 <= 0.09 of it, i.e. rest <= 0.3 sqrt)
             const double rest_s = trace - top4;
             spk_chol_factor(sh, it >= 3, rest_s > 0 ? rest_s * rest_s * (1.0 / 0.3) : 0.0);
-            if (spk_converged(top4, sqrt(sh.L[11]), trace, it, prev_sum, prev_delta, prev_ratio, true)) {
+            if (spk_converged<true>(top4, sqrt(sh.L[11]), trace, it, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
                 break;
             }

@@ -301,8 +301,10 @@ __device__ __forceinline__ void spk_orth(double* X, int rows, int rs, int cs, Sp
 // on ONE measured ratio, provided the tail it predicts is a hundred times below the tolerance (early ratios are optimistic:
 // components of smaller eigenvalues die first - but not a hundredfold at ratios of 1e-5) and the same gap guard and rigorous
 // bound hold as for every other stop.
+// (a template parameter: the general path's copy of the rule is instruction for instruction the one of round 2)
+template <bool dense_g = false>
 __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double trace, int k, double& prev_sum,
-                                              double& prev_delta, double& prev_ratio, bool dense_g = false) {
+                                              double& prev_delta, double& prev_ratio) {
     bool conv = false;
     const double delta = fabs(s4 - prev_sum);
     double ratio = 1.0;
