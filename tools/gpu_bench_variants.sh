@@ -14,7 +14,7 @@ except Exception as e:
     print("   no JSON:", e)
 PY
 }
-run config2 python bench.py --steps 500 --warmup 20 --no-cpu-baseline
+run config2 python bench.py --steps 2000 --warmup 100 --no-cpu-baseline
 run config2_dense python bench.py --steps 30 --warmup 3 --no-cpu-baseline --route dense
 run config2_4al python bench.py --steps 300 --warmup 10 --no-cpu-baseline --alignments 4
 run config5 python bench.py --workload config5 --steps 20 --warmup 2 --no-cpu-baseline
