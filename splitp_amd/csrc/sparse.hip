@@ -1553,8 +1553,13 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             if (it == 2) SSTAMP(58);
             // (S holds SQUARED Ritz values here: the cheap bound suffices when rest^2 <= 0.09 of it, i.e. rest <= 0.3 sqrt)
             const double rest_s = trace - top4;
-            spk_chol_factor(sh, it >= 3, rest_s > 0 ? rest_s * rest_s * (1.0 / 0.3) : 0.0);
-            if (spk_converged<true>(top4, sqrt(sh.L[11]), trace, it, prev_sum, prev_delta, prev_ratio)) {
+            // (the Gram path's early certified stop - spk_converged<true>: 3rd sum, one measured ratio - only in the slow
+            // kernel's forms: in the fast kernel it made the 2|8 and 3|7 splits of config 2 faster one class at a time and the
+            // pipelined mixed launch 0.6 % slower, 0.1016 against 0.1010 ms per step, A/B on one box: the plain LDS form keeps
+            // round 2's rule)
+            constexpr bool EARLY = !GP_STABLE;
+            spk_chol_factor(sh, it >= (EARLY ? 3 : 4), rest_s > 0 ? rest_s * rest_s * (1.0 / 0.3) : 0.0);
+            if (spk_converged<EARLY>(top4, sqrt(sh.L[11]), trace, it, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
                 break;
             }
