@@ -757,7 +757,8 @@ def main():
     extra = {}
     if default_run and not args.no_pipeline_block and world == 1:
         extra["north_star_pipeline"] = north_star_pipeline(env, m["scores"])
-    if default_run and world > 1:
+    # (SPLITP_BENCH_PARTITIONS=1: take this branch at one rank too - how the one-GPU box rehearses it under torch.distributed.run)
+    if default_run and (world > 1 or (dist is not None and os.environ.get("SPLITP_BENCH_PARTITIONS") == "1")):
         # the north-star partition beside the weak-scaling run, in the same invocation: ONE alignment, its
         # candidate-split set sharded over the ranks - on config 2 (63 splits per rank at 8 ranks: latency-bound) and on
         # config 4 (524 267 splits, subflattening route: where sharding the split set pays)
