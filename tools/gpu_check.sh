@@ -1,4 +1,4 @@
-# round-3 check of a kernel change (GPU box): bash tools/gpu_r3_check.sh TAG [quick]
+# check of a kernel change (GPU box): bash tools/gpu_check.sh TAG [quick] - GPU tests, config-5 size classes, config 5 and config 2 bench
 cd $GRAFT_REPO_ROOT
 TAG=${1:-r3x}
 OUT=gpurun_out/$TAG
