@@ -756,7 +756,11 @@ def main():
                 alignments_arg=args.alignments)
     extra = {}
     if default_run and not args.no_pipeline_block and world == 1:
-        extra["north_star_pipeline"] = north_star_pipeline(env, m["scores"])
+        try:
+            extra["north_star_pipeline"] = north_star_pipeline(env, m["scores"])
+        except Exception as exc:   # noqa: BLE001 - the headline line must not be lost to a failure of this side block
+            print(f"bench.py: north_star_pipeline block failed: {exc!r}", file=sys.stderr)
+            extra["north_star_pipeline"] = {"error": repr(exc)}
     # (SPLITP_BENCH_PARTITIONS=1: take this branch at one rank too - how the one-GPU box rehearses it under torch.distributed.run)
     if default_run and (world > 1 or (dist is not None and os.environ.get("SPLITP_BENCH_PARTITIONS") == "1")):
         # the north-star partition beside the weak-scaling run, in the same invocation: ONE alignment, its
