@@ -130,6 +130,8 @@ int sp_alignment_from_site_keys(sp_ctx* ctx, const uint64_t* site_keys, int64_t 
 int sp_simulate_alignment(sp_ctx* ctx, int n_nodes, const int32_t* parent, const int32_t* leaf_taxon,
                           const double* transition, int n_taxa, int64_t L, uint64_t seed, sp_alignment** out);
 
+/* Frees the table.  An alignment must outlive all work in flight that reads it - also the work other contexts (lanes)
+ * enqueued with sp_score_plan_async / sp_score_plan_steps: the call waits for the whole device before it frees. */
 int sp_alignment_destroy(sp_alignment* al);
 /* D distinct patterns, n taxa, N sites (0 if unknown), exact = 1 when integer counts are held */
 int sp_alignment_info(const sp_alignment* al, int64_t* D, int* n_taxa, int64_t* N, int* exact);

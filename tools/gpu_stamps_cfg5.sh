@@ -36,6 +36,7 @@ for kk in (6, 5, 4, 3, 2):
     if kk >= 5:   # (general path; a Gram-path split sets none of these stamps - round 2's table printed them anyway, as garbage)
         print(f"k={kk} (general path): stage={d(1,0)} CSC list={d(2,1)} CSR list={d(3,2)} start rows={d(4,3)} W init + first half product + orth={d(7,4)} spmm_it2={d(9,7)} gram2={d(40,9)} "
               f"chol+orth2={d(41,40)} spmm_it3={d(8,41)} rest={d(11,8)} total={d(11,0)}  half products {np.bincount(st >> 8).nonzero()[0].tolist()}")
+        print(f"      CSC list build: zero={d(55,1)} passA={d(50,55)} prefix={d(51,50)} class+perm={d(52,51)} scan+ptr={d(53,52)} passB={d(2,53)}")
     if kk <= 4:
         print(f"k={kk} (Gram path, products {np.bincount(st >> 8).nonzero()[0].tolist()}): stage={d(1,0)} group={d(2,1)} start={d(4,3)} Gzero={d(44,4)} pairs={d(45,44)} convert+Vinit={d(5,45)} iterate={d(11,6)} total={d(11,0)}  | group: zero={d(55,1)} passA={d(50,55)} scans={d(51,50)} passB={d(2,51)} | iteration 2: product={d(57,56)} sum+gram={d(58,57)} chol+stop={d(59,58)} orth={d(60,59)}")
 PY
