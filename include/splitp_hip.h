@@ -71,7 +71,8 @@ int sp_ctx_synchronize(sp_ctx* ctx);
  *   "force_big" 0/1, "big_by_keys" 0/1, "subscore_jacobi" 0/1, "divergence_global" 0/1, "hist_sort" -1 auto / 0 / 1,
  *   "lds_cap" bytes (0 = off), "wide_cap" half products of the sparse route's last resort (0 = built-in 600),
  *   "gram_tile64" 0/1 (dense route's int8 Gram on 64 x 64 tiles instead of 128 x 128), "eigen_one_stream" 0/1 (dense
- *   route's eigen phase without the internal side stream for the short sides). */
+ *   route's eigen phase without the internal side stream for the short sides), "subscore_waves" 0 auto / 1..16 (waves per
+ *   workgroup of the batched subflattening score: by default the shape that puts the most waves on a CU). */
 int sp_ctx_set_option(sp_ctx* ctx, const char* name, int64_t value);
 int sp_ctx_get_option(sp_ctx* ctx, const char* name, int64_t* value);
 /* Gram-kernel selection of the dense flattening route: 0 = auto (exact integer Gram on the int8 matrix

@@ -126,6 +126,7 @@ extern "C" int sp_ctx_create(int device, void* stream, sp_ctx** out) {
     c->opt.force_big = env_flag("SPLITP_FORCE_BIG");
     c->opt.big_by_keys = env_flag("SPLITP_BIG_BY_KEYS");
     c->opt.subscore_jacobi = env_flag("SPLITP_SUBSCORE_JACOBI");
+    if (const char* sw = getenv("SPLITP_SUBSCORE_WAVES")) c->opt.subscore_waves = atoi(sw);
     c->opt.divergence_global = env_flag("SPLITP_DIVERGENCE_GLOBAL");
     c->opt.gram_tile64 = env_flag("SPLITP_GRAM_TILE64");
     c->opt.eigen_one_stream = env_flag("SPLITP_EIGEN_ONE_STREAM");
@@ -141,6 +142,7 @@ static long long* option_slot(sp_ctx* c, const char* name, int** as_int) {
     if (!strcmp(name, "force_big")) *as_int = &c->opt.force_big;
     else if (!strcmp(name, "big_by_keys")) *as_int = &c->opt.big_by_keys;
     else if (!strcmp(name, "subscore_jacobi")) *as_int = &c->opt.subscore_jacobi;
+    else if (!strcmp(name, "subscore_waves")) *as_int = &c->opt.subscore_waves;
     else if (!strcmp(name, "divergence_global")) *as_int = &c->opt.divergence_global;
     else if (!strcmp(name, "hist_sort")) *as_int = &c->opt.hist_sort;
     else if (!strcmp(name, "wide_cap")) *as_int = &c->opt.wide_cap;

@@ -98,6 +98,7 @@ struct CtxOptions {
     int force_big = 0;          // every flattening score on the big-table form
     int big_by_keys = 0;        // ... with its sort-based compaction
     int subscore_jacobi = 0;    // Jacobi kernel for the batched subflattening score
+    int subscore_waves = 0;     // waves per workgroup of the fast subflattening score kernel (0 = the shape that fills the CU)
     int divergence_global = 0;  // global-memory form of the mutual-information score
     int hist_sort = -1;         // -1 auto, 0 direct bins, 1 sort + run-length encode
     int wide_cap = 0;           // half-product cap of the wide fallback block (0 = built-in 600)

@@ -358,9 +358,8 @@ __global__ __launch_bounds__(SUB_WAVES * 64) void k_subscore(const void* __restr
 // multisection on the Sturm count of the tridiagonal matrix - 4 groups of 16 lanes, one group per wanted eigenvalue, 16
 // shifts a pass, 14 passes (17^14 > 2^53).  Both steps are backward stable: eigenvalues good to a few eps * lambda_1,
 // which is what 1 - top4 / trace needs.  No iteration that could fail to converge.
-#define SUBT_WAVES 4
+#define SUBT_MAXWAVES 16  // waves of a workgroup: chosen per launch so that the CU holds as many waves as its LDS allows
 #define SUBT_MMAX 61
-#define SUBT_P 33        // row pitch of G (odd)
 #ifndef SUBT_PASSES
 #define SUBT_PASSES 14
 #endif
@@ -386,32 +385,40 @@ __device__ __forceinline__ double subt_wave_sum(double x) {
     return (subt_readlane(x, 15) + subt_readlane(x, 31)) + (subt_readlane(x, 47) + subt_readlane(x, 63));
 }
 
-struct SubtWave {
-    double G[32 * SUBT_P];
-    double d[32], e2[32], v[32], w[32];
-    unsigned short urow[32];   // row offset u * m into the staged matrix (< 61 * 61)
-    unsigned char vcol[64];    // column index (< 61)
-};
+// Per-wave LDS: G (rmax rows of pitch P = rmax | 1 doubles: an odd pitch keeps a column walk off one bank), then d, e2, v,
+// w (32 doubles each), urow (32 x u16: row offset u * m into the staged matrix, < 61 * 61) and vcol (64 x u8: column < 61).
+// Sized for the longest side of the batch, not for 32 rows: 16 taxa (rmax 25) take 6.2 KB a wave instead of 9.6.
+__host__ __device__ __forceinline__ size_t subt_wave_bytes(int rmax) {
+    return (size_t)rmax * (rmax | 1) * 8 + 4 * 32 * 8 + 32 * 2 + 64;
+}
 
 // M32: count table with fewer than 2^31 sites - every moment fits an int32, the staged matrix takes half the LDS and a
 // third workgroup fits the CU (3 waves per SIMD instead of 2: the eigenvalue steps are dependency chains).
 template <bool EXACT, bool M32>
-__global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __restrict__ Mv, int n,
-                                                                  const int8_t* __restrict__ split_taxa,
-                                                                  const int* __restrict__ split_a, int64_t S,
-                                                                  double* __restrict__ scores, int* __restrict__ status) {
+__global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void* __restrict__ Mv, int n, int rmax,
+                                                                     const int8_t* __restrict__ split_taxa,
+                                                                     const int* __restrict__ split_a, int64_t S,
+                                                                     double* __restrict__ scores, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
     const int m = 3 * n + 1;
     typedef typename std::conditional<M32, int, double>::type MsT;
     MsT* Ms = reinterpret_cast<MsT*>(smem_t);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    SubtWave& sw = *reinterpret_cast<SubtWave*>(smem_t + (((size_t)m * m * sizeof(MsT) + 15) & ~(size_t)15) +
-                                                (size_t)w * sizeof(SubtWave));
-    for (int e = threadIdx.x; e < m * m; e += SUBT_WAVES * 64)
+    const int P = rmax | 1, nthreads = blockDim.x;
+    unsigned char* wbase = smem_t + (((size_t)m * m * sizeof(MsT) + 15) & ~(size_t)15) + (size_t)w * subt_wave_bytes(rmax);
+    double* const G = reinterpret_cast<double*>(wbase);
+    double* const sd = G + rmax * P;
+    double* const se2 = sd + 32;
+    double* const sv = se2 + 32;
+    double* const swv = sv + 32;
+    unsigned short* const urow = reinterpret_cast<unsigned short*>(swv + 32);
+    unsigned char* const vcol = reinterpret_cast<unsigned char*>(urow + 32);
+    for (int e = threadIdx.x; e < m * m; e += nthreads)
         Ms[e] = EXACT ? (MsT) reinterpret_cast<const long long*>(Mv)[e] : (MsT) reinterpret_cast<const double*>(Mv)[e];
     __syncthreads();
-    const int64_t nwaves = (int64_t)gridDim.x * SUBT_WAVES;
-    for (int64_t sid = (int64_t)blockIdx.x * SUBT_WAVES + w; sid < S; sid += nwaves) {
+    const int wpb = nthreads >> 6;
+    const int64_t nwaves = (int64_t)gridDim.x * wpb;
+    for (int64_t sid = (int64_t)blockIdx.x * wpb + w; sid < S; sid += nwaves) {
         const int8_t* taxa = split_taxa + sid * n;
         const int a = split_a[sid], b = n - a;
         const bool swap = a > b;   // rows = smaller side
@@ -420,8 +427,8 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
         const int nr = swap ? b : a, nc = swap ? a : b;
         const int r = 3 * nr + 1, c = 3 * nc + 1;
         wave_sync_lds2();   // the previous split's reads of the tables are done
-        if (lane < r) sw.urow[lane] = (unsigned short)(sub_index(rt, nr, n, lane) * m);
-        if (lane < c) sw.vcol[lane] = (unsigned char)sub_index(ct, nc, n, lane);
+        if (lane < r) urow[lane] = (unsigned short)(sub_index(rt, nr, n, lane) * m);
+        if (lane < c) vcol[lane] = (unsigned char)sub_index(ct, nc, n, lane);
         wave_sync_lds2();
         // Gram over the rows on the matrix cores: G = B B^T, B[i][k] = M[urow_i + vcol_k] gathered straight from the
         // staged moment matrix.  v_mfma_f64_16x16x4: lane (fr = lane & 15, fk = lane >> 4) supplies B[16 I + fr][4 s + fk]
@@ -431,11 +438,11 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
             typedef double d4 __attribute__((ext_vector_type(4)));
             const int fr = lane & 15, fk = lane >> 4;
             const bool two = r > 16;
-            const int u0 = fr < r ? (int)sw.urow[fr] : -1, u1 = (two && 16 + fr < r) ? (int)sw.urow[16 + fr] : -1;
+            const int u0 = fr < r ? (int)urow[fr] : -1, u1 = (two && 16 + fr < r) ? (int)urow[16 + fr] : -1;
             d4 g00 = {0, 0, 0, 0}, g01 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
             for (int k0 = 0; k0 < c; k0 += 4) {
                 const int k = k0 + fk;
-                const int v = k < c ? (int)sw.vcol[k] : -1;
+                const int v = k < c ? (int)vcol[k] : -1;
                 const double x0 = (v >= 0 && u0 >= 0) ? (double)Ms[u0 + v] : 0.0;
                 g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, g00, 0, 0, 0);
                 if (two) {
@@ -446,18 +453,20 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = fk + 4 * q;
-                sw.G[i * SUBT_P + fr] = g00[q];
+                const int i = fk + 4 * q;   // (G has r <= rmax rows: the padding of the 16 x 16 tiles is not stored)
+                if (i < r && fr < r) G[i * P + fr] = g00[q];
                 if (two) {
-                    sw.G[i * SUBT_P + 16 + fr] = g01[q];
-                    sw.G[(16 + fr) * SUBT_P + i] = g01[q];
-                    sw.G[(16 + i) * SUBT_P + 16 + fr] = g11[q];
+                    if (16 + fr < r) {
+                        G[i * P + 16 + fr] = g01[q];
+                        G[(16 + fr) * P + i] = g01[q];
+                        if (16 + i < r) G[(16 + i) * P + 16 + fr] = g11[q];
+                    }
                 }
             }
         }
         wave_sync_lds2();
         double tr = 0;
-        for (int i = lane; i < r; i += 64) tr += sw.G[i * SUBT_P + i];
+        for (int i = lane; i < r; i += 64) tr += G[i * P + i];
 #pragma unroll
         for (int dd = 32; dd >= 1; dd >>= 1) tr += __shfl_xor(tr, dd, 64);
         if (r <= 4 || !(tr > 0)) {
@@ -473,14 +482,14 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
         const int row = lane >> 1, par = lane & 1;
         for (int k = 0; k < r - 2; ++k) {
             const int L = r - k - 1, o = k + 1;
-            const double x = (lane < L) ? sw.G[(o + lane) * SUBT_P + k] : 0.0;
+            const double x = (lane < L) ? G[(o + lane) * P + k] : 0.0;
             const double sig = subt_wave_sum(x * x);
             const double x0 = subt_readlane(x, 0);
-            if (lane == 0) sw.d[k] = sw.G[k * SUBT_P + k];
+            if (lane == 0) sd[k] = G[k * P + k];
             // (rest of the column negligible against its head: nothing to annihilate; alpha and v below have no
             // cancellation, so the tail's own norm is not needed)
             if (!(sig - x0 * x0 > 0)) {   // already tridiagonal in this column
-                if (lane == 0) sw.e2[k] = x0 * x0;
+                if (lane == 0) se2[k] = x0 * x0;
                 continue;
             }
             // sqrt and reciprocal by the hardware seeds + Newton steps (an IEEE fp64 sqrt and division are ~25 and ~30
@@ -496,41 +505,41 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
             beta = fma(fma(-den, beta, 1.0), beta, beta);
             beta = fma(fma(-den, beta, 1.0), beta, beta);
             const double vi = (lane == 0) ? x0 - alpha : x;   // v (lane < L)
-            if (lane == 0) sw.e2[k] = sig;                    // alpha^2
-            if (lane < 32) sw.v[lane] = lane < L ? vi : 0.0;
+            if (lane == 0) se2[k] = sig;                    // alpha^2
+            if (lane < 32) sv[lane] = lane < L ? vi : 0.0;
             wave_sync_lds2();
             double p = 0;
             if (row < L) {
-                const double* g = sw.G + (o + row) * SUBT_P + o;
-                for (int j = par; j < L; j += 2) p += g[j] * sw.v[j];
+                const double* g = G + (o + row) * P + o;
+                for (int j = par; j < L; j += 2) p += g[j] * sv[j];
             }
             p += subt_dpp<0xB1>(p);   // the partner lane of the row
             p *= beta;
-            const double vr = row < L ? sw.v[row] : 0.0;
+            const double vr = row < L ? sv[row] : 0.0;
             const double kk = subt_wave_sum((par == 0 && row < L) ? vr * p : 0.0);
             const double wr = p - 0.5 * beta * kk * vr;
-            if (par == 0 && row < 32) sw.w[row] = row < L ? wr : 0.0;
+            if (par == 0 && row < 32) swv[row] = row < L ? wr : 0.0;
             wave_sync_lds2();
             if (row < L) {
-                double* g = sw.G + (o + row) * SUBT_P + o;
-                for (int j = par; j < L; j += 2) g[j] -= vr * sw.w[j] + wr * sw.v[j];
+                double* g = G + (o + row) * P + o;
+                for (int j = par; j < L; j += 2) g[j] -= vr * swv[j] + wr * sv[j];
             }
             wave_sync_lds2();
         }
         if (lane == 0) {
-            const double eo = sw.G[(r - 1) * SUBT_P + (r - 2)];
-            sw.d[r - 2] = sw.G[(r - 2) * SUBT_P + (r - 2)];
-            sw.d[r - 1] = sw.G[(r - 1) * SUBT_P + (r - 1)];
-            sw.e2[r - 2] = eo * eo;
+            const double eo = G[(r - 1) * P + (r - 2)];
+            sd[r - 2] = G[(r - 2) * P + (r - 2)];
+            sd[r - 1] = G[(r - 1) * P + (r - 1)];
+            se2[r - 2] = eo * eo;
         }
         wave_sync_lds2();
         // ---- four largest eigenvalues of the tridiagonal matrix by multisection on the Sturm count ---------------------
         double gl = 1e300, gu = -1e300, emax = 0;
         if (lane < r) {
-            const double el = lane > 0 ? sqrt(sw.e2[lane - 1]) : 0.0, er = lane < r - 1 ? sqrt(sw.e2[lane]) : 0.0;
-            gl = sw.d[lane] - el - er;
-            gu = sw.d[lane] + el + er;
-            emax = lane < r - 1 ? sw.e2[lane] : 0.0;
+            const double el = lane > 0 ? sqrt(se2[lane - 1]) : 0.0, er = lane < r - 1 ? sqrt(se2[lane]) : 0.0;
+            gl = sd[lane] - el - er;
+            gu = sd[lane] + el + er;
+            emax = lane < r - 1 ? se2[lane] : 0.0;
         }
 #pragma unroll
         for (int dd = 32; dd >= 1; dd >>= 1) {
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
         const int want = r - 1 - grp;                     // ascending index of this group's eigenvalue
         for (int pass = 0; pass < SUBT_PASSES; ++pass) {
             const double sigma = lo + (hi - lo) * ((double)(t + 1) * (1.0 / 17.0));
-            double q = sw.d[0] - sigma;
+            double q = sd[0] - sigma;
             int cnt = q < 0 ? 1 : 0;
             for (int i = 1; i < r; ++i) {
                 if (fabs(q) < pivmin) q = -pivmin;
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(SUBT_WAVES * 64) void k_subscore_tri(const void* __
                 // half of the kernel); the Sturm count tolerates the last-bit difference like any rounding
                 double y = __builtin_amdgcn_rcp(q);
                 y = fma(fma(-q, y, 1.0), y, y);
-                q = sw.d[i] - sigma - sw.e2[i - 1] * y;
+                q = sd[i] - sigma - se2[i - 1] * y;
                 cnt += q < 0 ? 1 : 0;
             }
             // cnt = eigenvalues below sigma; the wanted one is below sigma iff cnt > want
@@ -740,37 +749,60 @@ static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da,
     const int mdim = 3 * n + 1;
     if (mdim <= SUBT_MMAX && rmax <= 32 && !ctx->opt.subscore_jacobi) {   // fast form (the option keeps the Jacobi kernel testable)
         const bool m32 = al->exact && al->N < ((int64_t)1 << 31);
-        const size_t lds_t = (((size_t)mdim * mdim * (m32 ? 4 : 8) + 15) & ~(size_t)15) + (size_t)SUBT_WAVES * sizeof(SubtWave);
+        const int rt = 3 * kmax + 1;   // longest row side of the batch
+        const size_t ms_bytes = ((size_t)mdim * mdim * (m32 ? 4 : 8) + 15) & ~(size_t)15;
         int dev_cus = 256;
         if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) dev_cus = 256;
-        int per_cu = 0;   // workgroups of this LDS size resident on a CU (allocation granularity included)
         const void* kfn = m32 ? reinterpret_cast<const void*>(k_subscore_tri<true, true>)
                               : (al->exact ? reinterpret_cast<const void*>(k_subscore_tri<true, false>)
                                            : reinterpret_cast<const void*>(k_subscore_tri<false, false>));
-        const int64_t want_blocks = (S + SUBT_WAVES - 1) / SUBT_WAVES;
         static bool attr_t = false;
         if (!attr_t) {
             SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<true, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_TOTAL));
             SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<true, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_TOTAL));
             SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<false, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_TOTAL));
             attr_t = true;
         }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, SUBT_WAVES * 64, lds_t) != hipSuccess || per_cu < 1)
-            per_cu = std::max(1, (int)((size_t)SPK_LDS_TOTAL / (lds_t + 1024)));
+        // Workgroup shape: the eigenvalue steps are dependency chains, so what counts is the number of waves resident on a
+        // CU, and that is set by the LDS (one staged matrix per workgroup + one work area per wave).  Take the shape that
+        // holds the most waves - whole multiples of 4 only (every SIMD the same number: the splits are dealt out statically,
+        // so the fullest SIMD sets the time; 2 x 10 waves ran 20 % slower than 4 x 4 at 16 taxa), the smaller workgroup on
+        // ties (4 x 4 waves 0.641 ms, 1 x 16 waves 0.654 ms at 16 taxa).  `subscore_waves` pins the workgroup (tests, tuning).
+        int waves = 0, per_cu = 0;
+        for (int wv = 4; wv <= SUBT_MAXWAVES; wv += 4) {
+            if (ctx->opt.subscore_waves > 0) continue;
+            const size_t lds = ms_bytes + (size_t)wv * subt_wave_bytes(rt);
+            if (lds > SPK_LDS_TOTAL) break;
+            int pc = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, kfn, wv * 64, lds) != hipSuccess || pc < 1) continue;
+            if (wv * pc > waves * per_cu) { waves = wv; per_cu = pc; }
+        }
+        if (ctx->opt.subscore_waves > 0) {
+            const int wv = std::min(ctx->opt.subscore_waves, SUBT_MAXWAVES);
+            const size_t lds = ms_bytes + (size_t)wv * subt_wave_bytes(rt);
+            int pc = 0;
+            if (lds <= SPK_LDS_TOTAL && hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, kfn, wv * 64, lds) == hipSuccess && pc >= 1) {
+                waves = wv;
+                per_cu = pc;
+            }
+        }
+        SP_REQUIRE(waves > 0, SP_ELIMIT, "subflattening score: no workgroup shape fits the LDS (%d taxa)", n);
+        const size_t lds_t = ms_bytes + (size_t)waves * subt_wave_bytes(rt);
+        const int64_t want_blocks = (S + waves - 1) / waves;
         // as many workgroups as are resident at once: persistent waves, grid-stride over the splits
         const unsigned blocks_t = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)dev_cus * per_cu));
         if (m32)
-            hipLaunchKernelGGL((k_subscore_tri<true, true>), dim3(blocks_t), dim3(SUBT_WAVES * 64), lds_t, ctx->stream,
-                               al->moments.p, n, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
+            hipLaunchKernelGGL((k_subscore_tri<true, true>), dim3(blocks_t), dim3(waves * 64), lds_t, ctx->stream,
+                               al->moments.p, n, rt, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
         else if (al->exact)
-            hipLaunchKernelGGL((k_subscore_tri<true, false>), dim3(blocks_t), dim3(SUBT_WAVES * 64), lds_t, ctx->stream,
-                               al->moments.p, n, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
+            hipLaunchKernelGGL((k_subscore_tri<true, false>), dim3(blocks_t), dim3(waves * 64), lds_t, ctx->stream,
+                               al->moments.p, n, rt, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
         else
-            hipLaunchKernelGGL((k_subscore_tri<false, false>), dim3(blocks_t), dim3(SUBT_WAVES * 64), lds_t, ctx->stream,
-                               al->moments.p, n, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
+            hipLaunchKernelGGL((k_subscore_tri<false, false>), dim3(blocks_t), dim3(waves * 64), lds_t, ctx->stream,
+                               al->moments.p, n, rt, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
         SP_HIP(hipGetLastError());
         return SP_OK;
     }

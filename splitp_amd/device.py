@@ -59,7 +59,7 @@ class Context:
 
     def set_option(self, name, value):
         """Test / tuning switch of the library (include/splitp_hip.h sp_ctx_set_option): 'force_big', 'big_by_keys',
-        'subscore_jacobi', 'divergence_global', 'hist_sort' (-1 auto / 0 / 1), 'lds_cap' (bytes), 'wide_cap', 'gram_tile64',
+        'subscore_jacobi', 'subscore_waves' (0 auto / 1..16), 'divergence_global', 'hist_sort' (-1 auto / 0 / 1), 'lds_cap' (bytes), 'wide_cap', 'gram_tile64',
         'eigen_one_stream'."""
         _lib.check(self._lib.sp_ctx_set_option(self.handle, name.encode(), int(value)))
 

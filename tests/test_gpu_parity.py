@@ -1360,6 +1360,32 @@ def test_config4_size_subflattening(sp):
         assert abs(O.dense_split_score(S) - got[i]) <= SCORE_TOL
 
 
+@pytest.mark.gpu
+def test_subflattening_score_workgroup_shapes_agree(sp):
+    """The fast subflattening score kernel picks its workgroup shape per launch (waves per workgroup x workgroups per CU,
+    the per-wave LDS area sized for the longest side of the batch): every shape the option `subscore_waves` can pin gives
+    bit-identical scores - a wave's arithmetic does not depend on where it runs - for a batch of every size class and for
+    one of short sides only (another LDS pitch)."""
+    from splitp_amd import synthetic as syn
+
+    n = 14
+    sites = syn.simulate_sites(n, 100_000, 0.05, seed=19)
+    keys, counts = syn.pattern_table(sites)
+    names = syn.taxa_names(n)
+    dev = sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=100_000, taxa=names)
+    allsp = list(sp.all_splits(names))
+    for splits in (allsp[::5], [s for s in allsp if min(len(s[0]), len(s[1])) <= 3][::3]):
+        ref = sp.score_splits(dev, splits, method=sp.Method.subflattening)
+        assert np.all(np.isfinite(ref))
+        try:
+            for wv in (1, 3, 4, 7, 8, 12, 16):
+                sp.get_context().set_option("subscore_waves", wv)
+                got = sp.score_splits(dev, splits, method=sp.Method.subflattening)
+                assert np.array_equal(got, ref), wv
+        finally:
+            sp.get_context().set_option("subscore_waves", 0)
+
+
 def test_subflattening_score_kernels_agree(sp, monkeypatch):
     """The two eigen-solvers behind the batched subflattening score - Householder tridiagonalisation + Sturm multisection
     (default up to 20 taxa) and the cyclic Jacobi kernel (larger tables; forced here by SPLITP_SUBSCORE_JACOBI) - on the same
