@@ -356,12 +356,12 @@ __global__ __launch_bounds__(SUB_WAVES * 64) void k_subscore(const void* __restr
 // loop, and the eigenvalues come from the classical dense symmetric route instead of cyclic Jacobi: Householder
 // tridiagonalisation (two lanes per row; ~3 r^2 LDS operations a lane instead of ~14 r^2 for 7 Jacobi sweeps) followed by
 // multisection on the Sturm count of the tridiagonal matrix - 4 groups of 16 lanes, one group per wanted eigenvalue, 16
-// shifts a pass, 14 passes (17^14 > 2^53).  Both steps are backward stable: eigenvalues good to a few eps * lambda_1,
+// shifts a pass, 13 passes (17^13 = 9.9e15 > 2^53: the bracket ends below eps * span; a 14th pass only moved noise).  Both steps are backward stable: eigenvalues good to a few eps * lambda_1,
 // which is what 1 - top4 / trace needs.  No iteration that could fail to converge.
 #define SUBT_MAXWAVES 16  // waves of a workgroup: chosen per launch so that the CU holds as many waves as its LDS allows
 #define SUBT_MMAX 61
 #ifndef SUBT_PASSES
-#define SUBT_PASSES 14
+#define SUBT_PASSES 13
 #endif
 #define SPK_LDS_TOTAL 163840   // LDS of a CU
 
@@ -385,11 +385,31 @@ __device__ __forceinline__ double subt_wave_sum(double x) {
     return (subt_readlane(x, 15) + subt_readlane(x, 31)) + (subt_readlane(x, 47) + subt_readlane(x, 63));
 }
 
-// Per-wave LDS: G (rmax rows of pitch P = rmax | 1 doubles: an odd pitch keeps a column walk off one bank), then d, e2, v,
-// w (32 doubles each), urow (32 x u16: row offset u * m into the staged matrix, < 61 * 61) and vcol (64 x u8: column < 61).
-// Sized for the longest side of the batch, not for 32 rows: 16 taxa (rmax 25) take 6.2 KB a wave instead of 9.6.
+// Per-wave LDS: de (32 pairs {d_i, e2_(i-1)}: diagonal and squared sub-diagonal of the tridiagonal matrix, one 16-byte
+// read per step of the Sturm recurrence), v, w (32 doubles each), G (rmax rows of pitch P = rmax | 1 doubles: an odd pitch
+// keeps a column walk off one bank), urow (32 x u16: row offset u * m into the staged matrix, < 61 * 61) and vcol
+// (64 x u8: column < 61).  Sized for the longest side of the batch, not for 32 rows: 16 taxa (rmax 25) take 6.2 KB a wave
+// instead of 9.6.
 __host__ __device__ __forceinline__ size_t subt_wave_bytes(int rmax) {
-    return (size_t)rmax * (rmax | 1) * 8 + 4 * 32 * 8 + 32 * 2 + 64;
+    return ((size_t)rmax * (rmax | 1) * 8 + 4 * 32 * 8 + 32 * 2 + 64 + 15) & ~(size_t)15;
+}
+// min(max(1 / q, lo), hi) from the hardware reciprocal, as three instructions (fmin / fmax add a canonicalising
+// v_max_f64 x, x per operand and call, inside the loop; 1 / q is never NaN: q is finite).  The reciprocal sits inside the
+// asm block with its own wait state: on gfx940+ a VALU instruction that reads the result of a transcendental one needs an
+// instruction in between, which the compiler inserts for its own code but not for operands of inline asm (a clamp written
+// as asm right behind `__builtin_amdgcn_rcp` read the register too early: every score of a table was wrong).
+__device__ __forceinline__ double subt_rcp_clamped(double q, double lo, double hi) {
+    double y;
+    asm("v_rcp_f64 %0, %1\n\ts_nop 1\n\tv_max_f64 %0, %0, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(y) : "v"(q), "v"(lo), "v"(hi));
+    return y;
+}
+// sum over the lanes when lanes 32..63 hold 0 (a column of <= 31 entries): rows 0 and 1 only
+__device__ __forceinline__ double subt_half_sum(double x) {
+    x += subt_dpp<0xB1>(x);
+    x += subt_dpp<0x4E>(x);
+    x += subt_dpp<0x114>(x);
+    x += subt_dpp<0x118>(x);
+    return subt_readlane(x, 15) + subt_readlane(x, 31);
 }
 
 // M32: count table with fewer than 2^31 sites - every moment fits an int32, the staged matrix takes half the LDS and a
@@ -403,15 +423,16 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
     const int m = 3 * n + 1;
     typedef typename std::conditional<M32, int, double>::type MsT;
     MsT* Ms = reinterpret_cast<MsT*>(smem_t);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: the compiler then knows that the split, its side lengths and every loop
+    // bound below are wave-uniform - scalar registers and scalar branches instead of 64 identical vector lanes)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int P = rmax | 1, nthreads = blockDim.x;
     unsigned char* wbase = smem_t + (((size_t)m * m * sizeof(MsT) + 15) & ~(size_t)15) + (size_t)w * subt_wave_bytes(rmax);
-    double* const G = reinterpret_cast<double*>(wbase);
-    double* const sd = G + rmax * P;
-    double* const se2 = sd + 32;
-    double* const sv = se2 + 32;
+    double* const sde = reinterpret_cast<double*>(wbase);   // [2 i] = d_i, [2 i + 1] = e2_(i-1)
+    double* const sv = sde + 64;
     double* const swv = sv + 32;
-    unsigned short* const urow = reinterpret_cast<unsigned short*>(swv + 32);
+    double* const G = swv + 32;
+    unsigned short* const urow = reinterpret_cast<unsigned short*>(G + rmax * P);
     unsigned char* const vcol = reinterpret_cast<unsigned char*>(urow + 32);
     for (int e = threadIdx.x; e < m * m; e += nthreads)
         Ms[e] = EXACT ? (MsT) reinterpret_cast<const long long*>(Mv)[e] : (MsT) reinterpret_cast<const double*>(Mv)[e];
@@ -479,17 +500,16 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
         // ---- Householder tridiagonalisation: d (diagonal), e2 (squared off-diagonal) -----------------------------------
         // step k annihilates column k below the sub-diagonal with H = I - beta v v^T on the trailing block A (L x L):
         // A <- H A H = A - v w^T - w v^T,  p = beta A v,  w = p - (beta v^T p / 2) v.   Lane pair (2i, 2i+1) owns row i.
-        const int row = lane >> 1, par = lane & 1;
         for (int k = 0; k < r - 2; ++k) {
             const int L = r - k - 1, o = k + 1;
             const double x = (lane < L) ? G[(o + lane) * P + k] : 0.0;
-            const double sig = subt_wave_sum(x * x);
+            const double sig = subt_half_sum(x * x);          // (L <= 30: lanes 32.. hold 0)
             const double x0 = subt_readlane(x, 0);
-            if (lane == 0) sd[k] = G[k * P + k];
+            if (lane == 0) sde[2 * k] = G[k * P + k];
             // (rest of the column negligible against its head: nothing to annihilate; alpha and v below have no
             // cancellation, so the tail's own norm is not needed)
             if (!(sig - x0 * x0 > 0)) {   // already tridiagonal in this column
-                if (lane == 0) se2[k] = x0 * x0;
+                if (lane == 0) sde[2 * k + 3] = x0 * x0;
                 continue;
             }
             // sqrt and reciprocal by the hardware seeds + Newton steps (an IEEE fp64 sqrt and division are ~25 and ~30
@@ -505,41 +525,50 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
             beta = fma(fma(-den, beta, 1.0), beta, beta);
             beta = fma(fma(-den, beta, 1.0), beta, beta);
             const double vi = (lane == 0) ? x0 - alpha : x;   // v (lane < L)
-            if (lane == 0) se2[k] = sig;                    // alpha^2
+            if (lane == 0) sde[2 * k + 3] = sig;              // alpha^2
             if (lane < 32) sv[lane] = lane < L ? vi : 0.0;
             wave_sync_lds2();
-            double p = 0;
-            if (row < L) {
-                const double* g = G + (o + row) * P + o;
-                for (int j = par; j < L; j += 2) p += g[j] * sv[j];
-            }
-            p += subt_dpp<0xB1>(p);   // the partner lane of the row
-            p *= beta;
-            const double vr = row < L ? sv[row] : 0.0;
-            const double kk = subt_wave_sum((par == 0 && row < L) ? vr * p : 0.0);
-            const double wr = p - 0.5 * beta * kk * vr;
-            if (par == 0 && row < 32) swv[row] = row < L ? wr : 0.0;
-            wave_sync_lds2();
-            if (row < L) {
-                double* g = G + (o + row) * P + o;
-                for (int j = par; j < L; j += 2) g[j] -= vr * swv[j] + wr * sv[j];
-            }
-            wave_sync_lds2();
+            // rows of the trailing block: 2 lanes a row, 4 once the block has <= 16 rows (half the trips of both loops)
+            auto rows = [&](auto shc) {
+                constexpr int SH = decltype(shc)::value, LPR = 1 << SH;
+                const int row = lane >> SH, par = lane & (LPR - 1);
+                double p = 0;
+                if (row < L) {
+                    const double* g = G + (o + row) * P + o;
+                    for (int j = par; j < L; j += LPR) p += g[j] * sv[j];
+                }
+                p += subt_dpp<0xB1>(p);   // the partner lane(s) of the row
+                if (SH == 2) p += subt_dpp<0x4E>(p);
+                p *= beta;
+                const double vr = row < L ? sv[row] : 0.0;
+                const double kk = subt_wave_sum((par == 0 && row < L) ? vr * p : 0.0);
+                const double wr = p - 0.5 * beta * kk * vr;
+                if (par == 0 && row < 32) swv[row] = row < L ? wr : 0.0;
+                wave_sync_lds2();
+                if (row < L) {
+                    double* g = G + (o + row) * P + o;
+                    for (int j = par; j < L; j += LPR) g[j] -= vr * swv[j] + wr * sv[j];
+                }
+                wave_sync_lds2();
+            };
+            if (L <= 16) rows(std::integral_constant<int, 2>());
+            else rows(std::integral_constant<int, 1>());
         }
         if (lane == 0) {
             const double eo = G[(r - 1) * P + (r - 2)];
-            sd[r - 2] = G[(r - 2) * P + (r - 2)];
-            sd[r - 1] = G[(r - 1) * P + (r - 1)];
-            se2[r - 2] = eo * eo;
+            sde[2 * (r - 2)] = G[(r - 2) * P + (r - 2)];
+            sde[2 * (r - 1)] = G[(r - 1) * P + (r - 1)];
+            sde[2 * (r - 1) + 1] = eo * eo;
         }
         wave_sync_lds2();
         // ---- four largest eigenvalues of the tridiagonal matrix by multisection on the Sturm count ---------------------
         double gl = 1e300, gu = -1e300, emax = 0;
         if (lane < r) {
-            const double el = lane > 0 ? sqrt(se2[lane - 1]) : 0.0, er = lane < r - 1 ? sqrt(se2[lane]) : 0.0;
-            gl = sd[lane] - el - er;
-            gu = sd[lane] + el + er;
-            emax = lane < r - 1 ? se2[lane] : 0.0;
+            const double e2l = lane > 0 ? sde[2 * lane + 1] : 0.0, e2r = lane < r - 1 ? sde[2 * lane + 3] : 0.0;
+            const double el = sqrt(e2l), er = sqrt(e2r);
+            gl = sde[2 * lane] - el - er;
+            gu = sde[2 * lane] + el + er;
+            emax = e2r;
         }
 #pragma unroll
         for (int dd = 32; dd >= 1; dd >>= 1) {
@@ -548,21 +577,28 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
             emax = fmax(emax, __shfl_xor(emax, dd, 64));
         }
         const double pivmin = 2.3e-308 * fmax(1.0, emax);
+        const double ybig = 0.25 / pivmin;
+        double nybig = -ybig;
+        asm volatile("" : "+v"(nybig));              // (kept in its own register pair: otherwise re-derived from ybig inside the loop)             // (0.25 / 2.3e-308 = 1.1e307: finite, and so is e2 * 2 ybig)
         const double span = fmax(gu - gl, 0.0);
         double lo = gl - 1e-15 * span - pivmin, hi = gu + 1e-15 * span + pivmin;   // (per group of 16 lanes)
         const int grp = lane >> 4, t = lane & 15;
         const int want = r - 1 - grp;                     // ascending index of this group's eigenvalue
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2* de = reinterpret_cast<const d2*>(sde);
         for (int pass = 0; pass < SUBT_PASSES; ++pass) {
             const double sigma = lo + (hi - lo) * ((double)(t + 1) * (1.0 / 17.0));
-            double q = sd[0] - sigma;
+            double q = sde[0] - sigma;
             int cnt = q < 0 ? 1 : 0;
             for (int i = 1; i < r; ++i) {
-                if (fabs(q) < pivmin) q = -pivmin;
                 // 1 / q by v_rcp_f64 + one Newton step (a full IEEE division is ~30 instructions and this recurrence is
-                // half of the kernel); the Sturm count tolerates the last-bit difference like any rounding
-                double y = __builtin_amdgcn_rcp(q);
+                // a third of the kernel); the Sturm count tolerates the last-bit difference like any rounding.  A pivot
+                // below pivmin in size is replaced by one of that size (LAPACK dlaebz's safeguard) by clamping the
+                // reciprocal: two instructions instead of the compare and two selects on q (subt_rcp_clamped).
+                const d2 v = de[i];
+                double y = subt_rcp_clamped(q, nybig, ybig);
                 y = fma(fma(-q, y, 1.0), y, y);
-                q = sd[i] - sigma - se2[i - 1] * y;
+                q = fma(-v.y, y, v.x - sigma);
                 cnt += q < 0 ? 1 : 0;
             }
             // cnt = eigenvalues below sigma; the wanted one is below sigma iff cnt > want

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 set -e
 timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "subflat or config3 or config4 or kernels_agree" 2>&1 | tail -3
-for rep in 1 2; do
+for rep in ${REPS:-1 2}; do
 for wv in 4 8 12 16 0; do
   export SPLITP_SUBSCORE_WAVES=$wv
   for wl in config3 config4; do
