@@ -386,8 +386,8 @@ __device__ __forceinline__ double subt_wave_sum(double x) {
 }
 
 // Per-wave LDS: de (32 pairs {d_i, e2_(i-1)}: diagonal and squared sub-diagonal of the tridiagonal matrix, one 16-byte
-// read per step of the Sturm recurrence), v, w (32 doubles each), G (rmax rows of pitch P = rmax | 1 doubles: an odd pitch
-// keeps a column walk off one bank), urow (32 x u16: row offset u * m into the staged matrix, < 61 * 61) and vcol
+// read per step of the Sturm recurrence), G (rmax rows of pitch P = rmax | 1 doubles: an odd pitch keeps a column walk off
+// one bank), v, w (32 doubles each), urow (32 x u16: row offset u * m into the staged matrix, < 61 * 61) and vcol
 // (64 x u8: column < 61).  Sized for the longest side of the batch, not for 32 rows: 16 taxa (rmax 25) take 6.2 KB a wave
 // instead of 9.6.
 __host__ __device__ __forceinline__ size_t subt_wave_bytes(int rmax) {
@@ -429,10 +429,10 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
     const int P = rmax | 1, nthreads = blockDim.x;
     unsigned char* wbase = smem_t + (((size_t)m * m * sizeof(MsT) + 15) & ~(size_t)15) + (size_t)w * subt_wave_bytes(rmax);
     double* const sde = reinterpret_cast<double*>(wbase);   // [2 i] = d_i, [2 i + 1] = e2_(i-1)
-    double* const sv = sde + 64;
+    double* const G = sde + 64;
+    double* const sv = G + rmax * P;                         // (behind G: a read past G's last row meets finite numbers)
     double* const swv = sv + 32;
-    double* const G = swv + 32;
-    unsigned short* const urow = reinterpret_cast<unsigned short*>(G + rmax * P);
+    unsigned short* const urow = reinterpret_cast<unsigned short*>(swv + 32);
     unsigned char* const vcol = reinterpret_cast<unsigned char*>(urow + 32);
     for (int e = threadIdx.x; e < m * m; e += nthreads)
         Ms[e] = EXACT ? (MsT) reinterpret_cast<const long long*>(Mv)[e] : (MsT) reinterpret_cast<const double*>(Mv)[e];
@@ -485,6 +485,16 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
                 }
             }
         }
+        // The row loops of the tridiagonalisation run whole trips of 2 or 4 entries and may read up to 3 entries past the end
+        // of a row, times a zero of v: those entries must be finite.  Past the row lies its padding (zeroed here), the head
+        // of the next row (data), the row behind the last one (zeroed here) or, behind G, the vector v.
+        if (lane <= r && lane < rmax) {
+#pragma unroll
+            for (int cpad = 0; cpad < 3; ++cpad) {
+                const int col = lane < r ? r + cpad : cpad;
+                if (col < P) G[lane * P + col] = 0.0;
+            }
+        }
         wave_sync_lds2();
         double tr = 0;
         for (int i = lane; i < r; i += 64) tr += G[i * P + i];
@@ -528,26 +538,40 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
             if (lane == 0) sde[2 * k + 3] = sig;              // alpha^2
             if (lane < 32) sv[lane] = lane < L ? vi : 0.0;
             wave_sync_lds2();
-            // rows of the trailing block: 2 lanes a row, 4 once the block has <= 16 rows (half the trips of both loops)
+            // rows of the trailing block: 2 lanes a row, 4 once the block has <= 16 rows (half the trips of both loops).
+            // Both loops are unrolled over wave-uniform trips (constant LDS offsets, one scalar test a trip): the product
+            // runs whole trips - v_j = w_j = 0 for L <= j < 32 -, the update masks its last partial trip (an entry past the
+            // row can be a live entry of the next one).
             auto rows = [&](auto shc) {
-                constexpr int SH = decltype(shc)::value, LPR = 1 << SH;
+                constexpr int SH = decltype(shc)::value, LPR = 1 << SH, TRIPS = SH == 2 ? 4 : 15;
                 const int row = lane >> SH, par = lane & (LPR - 1);
+                const bool act = row < L;
+                double* const g = G + (o + row) * P + o + par;   // this lane's first entry of its row
+                const double* const vp = sv + par;
+                const double* const wp = swv + par;
                 double p = 0;
-                if (row < L) {
-                    const double* g = G + (o + row) * P + o;
-                    for (int j = par; j < L; j += LPR) p += g[j] * sv[j];
+                if (act) {
+#pragma unroll
+                    for (int tq = 0; tq < TRIPS; ++tq) {
+                        if (tq * LPR >= L) break;
+                        p = fma(g[tq * LPR], vp[tq * LPR], p);
+                    }
                 }
                 p += subt_dpp<0xB1>(p);   // the partner lane(s) of the row
                 if (SH == 2) p += subt_dpp<0x4E>(p);
                 p *= beta;
-                const double vr = row < L ? sv[row] : 0.0;
-                const double kk = subt_wave_sum((par == 0 && row < L) ? vr * p : 0.0);
+                const double vr = act ? sv[row] : 0.0;
+                const double kk = subt_wave_sum((par == 0 && act) ? vr * p : 0.0);
                 const double wr = p - 0.5 * beta * kk * vr;
-                if (par == 0 && row < 32) swv[row] = row < L ? wr : 0.0;
+                if (par == 0 && row < 32) swv[row] = act ? wr : 0.0;
                 wave_sync_lds2();
-                if (row < L) {
-                    double* g = G + (o + row) * P + o;
-                    for (int j = par; j < L; j += LPR) g[j] -= vr * swv[j] + wr * sv[j];
+                if (act) {
+#pragma unroll
+                    for (int tq = 0; tq < TRIPS; ++tq) {
+                        if (tq * LPR >= L) break;
+                        if ((tq + 1) * LPR <= L || par < L - tq * LPR)
+                            g[tq * LPR] = fma(-vr, wp[tq * LPR], fma(-wr, vp[tq * LPR], g[tq * LPR]));
+                    }
                 }
                 wave_sync_lds2();
             };
