@@ -393,15 +393,31 @@ __device__ __forceinline__ double subt_wave_sum(double x) {
 __host__ __device__ __forceinline__ size_t subt_wave_bytes(int rmax) {
     return ((size_t)rmax * (rmax | 1) * 8 + 4 * 32 * 8 + 32 * 2 + 64 + 15) & ~(size_t)15;
 }
-// min(max(1 / q, lo), hi) from the hardware reciprocal, as three instructions (fmin / fmax add a canonicalising
-// v_max_f64 x, x per operand and call, inside the loop; 1 / q is never NaN: q is finite).  The reciprocal sits inside the
-// asm block with its own wait state: on gfx940+ a VALU instruction that reads the result of a transcendental one needs an
-// instruction in between, which the compiler inserts for its own code but not for operands of inline asm (a clamp written
-// as asm right behind `__builtin_amdgcn_rcp` read the register too early: every score of a table was wrong).
-__device__ __forceinline__ double subt_rcp_clamped(double q, double lo, double hi) {
-    double y;
-    asm("v_rcp_f64 %0, %1\n\ts_nop 1\n\tv_max_f64 %0, %0, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(y) : "v"(q), "v"(lo), "v"(hi));
-    return y;
+// max(|a|, |b|) as one instruction (fmax(fabs(a), fabs(b)) adds a canonicalising v_max_f64 x, x per operand)
+__device__ __forceinline__ double subt_max_abs(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+typedef double subt_d2 __attribute__((ext_vector_type(2)));
+// Steps I, I + 1, ... r - 1 of the minor recurrence (k_subscore_tri), written out by recursion: constant LDS offsets, the
+// pair (P_(i-1), P_i) changes registers instead of being moved, one scalar test a step (`#pragma unroll` leaves this loop
+// rolled).  de[i] = {d_i, e2_(i-1)}; the sign of every new minor is shifted into `mask`.
+template <int I>
+__device__ __forceinline__ void subt_minor_steps(int r, const subt_d2* de, double sigma, double pp, double pc, unsigned& mask) {
+    if constexpr (I < 31) {
+        if (I < r) {
+            const subt_d2 v = de[I];
+            double pn = fma(v.x - sigma, pc, -(v.y * pp));
+            mask = __builtin_amdgcn_alignbit(mask, (unsigned)__double2hiint(pn), 31);   // (mask << 1) | sign
+            if ((I & 7) == 0) {
+                const int ex = __builtin_amdgcn_frexp_exp(subt_max_abs(pn, pc));
+                pn = ldexp(pn, -ex);
+                pc = ldexp(pc, -ex);
+            }
+            subt_minor_steps<I + 1>(r, de, sigma, pc, pn, mask);
+        }
+    }
 }
 // sum over the lanes when lanes 32..63 hold 0 (a column of <= 31 entries): rows 0 and 1 only
 __device__ __forceinline__ double subt_half_sum(double x) {
@@ -586,45 +602,49 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
         }
         wave_sync_lds2();
         // ---- four largest eigenvalues of the tridiagonal matrix by multisection on the Sturm count ---------------------
-        double gl = 1e300, gu = -1e300, emax = 0;
+        // The count of eigenvalues below a shift is the number of sign changes in the sequence of leading principal minors
+        // P_0 = 1, P_1 = d_0 - s, P_(i+1) = (d_i - s) P_i - e2_(i-1) P_(i-1): three full-rate fp64 instructions and one
+        // integer instruction a step (the sign bits are shifted into a mask; r <= 31 of them).  The usual ratio form
+        // q_i = P_(i+1) / P_i needs a reciprocal a step - v_rcp_f64 issues at a quarter of the rate, plus its Newton step
+        // and the small-pivot guard: 12 issue slots a step against 4.6 - and exists because the minors over- and underflow.
+        // Here the matrix is moved to units in which the Gershgorin interval has length in [0.5, 1) (exact: a power of two),
+        // so |d_i - s| <= 1, e2 <= 1 and a minor grows at most 2x a step; squared off-diagonals below 2^-120 are raised to
+        // that (an off-diagonal of 2^-60 of the interval: eigenvalues move by less than 2^-59 of it), so no minor of a pair
+        // is less than 2^-120 of the pair two steps before, an exact zero is followed by a non-zero of the opposite sign
+        // to its predecessor (one sign change whichever sign the zero is given), and rescaling the pair by the exponent of
+        // its larger member every 8th step keeps it inside 2^+-500.
+        double gl = 1e300, gu = -1e300;
         if (lane < r) {
             const double e2l = lane > 0 ? sde[2 * lane + 1] : 0.0, e2r = lane < r - 1 ? sde[2 * lane + 3] : 0.0;
             const double el = sqrt(e2l), er = sqrt(e2r);
             gl = sde[2 * lane] - el - er;
             gu = sde[2 * lane] + el + er;
-            emax = e2r;
         }
 #pragma unroll
         for (int dd = 32; dd >= 1; dd >>= 1) {
             gl = fmin(gl, __shfl_xor(gl, dd, 64));
             gu = fmax(gu, __shfl_xor(gu, dd, 64));
-            emax = fmax(emax, __shfl_xor(emax, dd, 64));
         }
-        const double pivmin = 2.3e-308 * fmax(1.0, emax);
-        const double ybig = 0.25 / pivmin;
-        double nybig = -ybig;
-        asm volatile("" : "+v"(nybig));              // (kept in its own register pair: otherwise re-derived from ybig inside the loop)             // (0.25 / 2.3e-308 = 1.1e307: finite, and so is e2 * 2 ybig)
-        const double span = fmax(gu - gl, 0.0);
-        double lo = gl - 1e-15 * span - pivmin, hi = gu + 1e-15 * span + pivmin;   // (per group of 16 lanes)
+        // (tr > 0, so gu > 0; an interval of length 0 - a multiple of the identity - is scaled by its position instead)
+        const int E = __builtin_amdgcn_frexp_exp(fmax(gu - gl, fmax(fabs(gl), fabs(gu)) * 0x1p-40));
+        wave_sync_lds2();   // every lane has read its neighbours' entries
+        if (lane < r) {
+            sde[2 * lane] = ldexp(sde[2 * lane], -E);
+            sde[2 * lane + 1] = lane > 0 ? fmax(ldexp(sde[2 * lane + 1], -2 * E), 0x1p-120) : 0.0;
+        }
+        wave_sync_lds2();
+        double lo = ldexp(gl, -E) - 0x1p-44, hi = ldexp(gu, -E) + 0x1p-44;   // (per group of 16 lanes)
         const int grp = lane >> 4, t = lane & 15;
         const int want = r - 1 - grp;                     // ascending index of this group's eigenvalue
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        const d2* de = reinterpret_cast<const d2*>(sde);
+        const unsigned rmask = (1u << r) - 1u;            // r <= 31
+        const subt_d2* de = reinterpret_cast<const subt_d2*>(sde);
         for (int pass = 0; pass < SUBT_PASSES; ++pass) {
             const double sigma = lo + (hi - lo) * ((double)(t + 1) * (1.0 / 17.0));
-            double q = sde[0] - sigma;
-            int cnt = q < 0 ? 1 : 0;
-            for (int i = 1; i < r; ++i) {
-                // 1 / q by v_rcp_f64 + one Newton step (a full IEEE division is ~30 instructions and this recurrence is
-                // a third of the kernel); the Sturm count tolerates the last-bit difference like any rounding.  A pivot
-                // below pivmin in size is replaced by one of that size (LAPACK dlaebz's safeguard) by clamping the
-                // reciprocal: two instructions instead of the compare and two selects on q (subt_rcp_clamped).
-                const d2 v = de[i];
-                double y = subt_rcp_clamped(q, nybig, ybig);
-                y = fma(fma(-q, y, 1.0), y, y);
-                q = fma(-v.y, y, v.x - sigma);
-                cnt += q < 0 ? 1 : 0;
-            }
+            double pp = 1.0, pc = sde[0] - sigma;
+            unsigned mask = (unsigned)__double2hiint(pc) >> 31;
+            subt_minor_steps<1>(r, de, sigma, pp, pc, mask);
+            // bit j of mask = sign of P_(r-j), bit r = 0 = sign of P_0: sign changes = eigenvalues below sigma
+            const int cnt = __popc((mask ^ (mask >> 1)) & rmask);
             // cnt = eigenvalues below sigma; the wanted one is below sigma iff cnt > want
             const unsigned long long above = __ballot(cnt > want);
             const unsigned int mine = (unsigned int)((above >> (16 * grp)) & 0xFFFFull);
@@ -640,7 +660,7 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
         top += __shfl_xor(top, 16, 64);
         top += __shfl_xor(top, 32, 64);
         if (lane == 0) {
-            const double op = 1.0 - top / tr;
+            const double op = 1.0 - top / ldexp(tr, -E);   // (top in the scaled units)
             scores[sid] = sqrt(op > 0 ? op : 0.0);
             status[sid] = SUBT_PASSES << 8;
         }
