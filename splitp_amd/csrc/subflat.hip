@@ -402,12 +402,16 @@ __device__ __forceinline__ double subt_max_abs(double a, double b) {
 typedef double subt_d2 __attribute__((ext_vector_type(2)));
 // Steps I, I + 1, ... r - 1 of the minor recurrence (k_subscore_tri), written out by recursion: constant LDS offsets, the
 // pair (P_(i-1), P_i) changes registers instead of being moved, one scalar test a step (`#pragma unroll` leaves this loop
-// rolled).  de[i] = {d_i, e2_(i-1)}; the sign of every new minor is shifted into `mask`.
+// rolled).  de[i] = {d_i, e2_(i-1)}, v = de[I]; the sign of every new minor is shifted into `mask`.
 template <int I>
-__device__ __forceinline__ void subt_minor_steps(int r, const subt_d2* de, double sigma, double pp, double pc, unsigned& mask) {
+__device__ __forceinline__ void subt_minor_steps(int r, const subt_d2* de, double sigma, double pp, double pc, subt_d2 v,
+                                                 unsigned& mask) {
     if constexpr (I < 31) {
         if (I < r) {
-            const subt_d2 v = de[I];
+            // the next step's pair is requested before this step's arithmetic (nothing is scheduled across the barrier), or
+            // the compiler moves the read down to its use and every step waits out an LDS round trip (de has 32 pairs)
+            const subt_d2 vn = de[I + 1];
+            __builtin_amdgcn_sched_barrier(0);
             double pn = fma(v.x - sigma, pc, -(v.y * pp));
             mask = __builtin_amdgcn_alignbit(mask, (unsigned)__double2hiint(pn), 31);   // (mask << 1) | sign
             if ((I & 7) == 0) {
@@ -415,7 +419,7 @@ __device__ __forceinline__ void subt_minor_steps(int r, const subt_d2* de, doubl
                 pn = ldexp(pn, -ex);
                 pc = ldexp(pc, -ex);
             }
-            subt_minor_steps<I + 1>(r, de, sigma, pc, pn, mask);
+            subt_minor_steps<I + 1>(r, de, sigma, pc, pn, vn, mask);
         }
     }
 }
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
             const double sigma = lo + (hi - lo) * ((double)(t + 1) * (1.0 / 17.0));
             double pp = 1.0, pc = sde[0] - sigma;
             unsigned mask = (unsigned)__double2hiint(pc) >> 31;
-            subt_minor_steps<1>(r, de, sigma, pp, pc, mask);
+            subt_minor_steps<1>(r, de, sigma, pp, pc, de[1], mask);
             // bit j of mask = sign of P_(r-j), bit r = 0 = sign of P_0: sign changes = eigenvalues below sigma
             const int cnt = __popc((mask ^ (mask >> 1)) & rmask);
             // cnt = eigenvalues below sigma; the wanted one is below sigma iff cnt > want
