@@ -1292,7 +1292,7 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
 }
 
 int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int shard_rank, int shard_world, int64_t* n_out,
-                           bool score);  // subflat.hip
+                           bool score, double* scores_out, int* status_out);  // subflat.hip
 
 // Every split of the table's taxa in the reference's all_splits order (splits.py:39-59), enumerated on the device.
 extern "C" int sp_score_all_splits_shard(sp_alignment* al, int method, int trivial, int size, int shard_rank,
@@ -1305,8 +1305,15 @@ extern "C" int sp_score_all_splits_shard(sp_alignment* al, int method, int trivi
     const bool score = scores_host || scores_dev || status_host || status_dev;
     SP_REQUIRE(!score || al->D > 0, SP_EINVAL, "empty pattern table");
     int64_t n = 0;
+    // where the scores / status words are on the device when the route returns (the subflattening kernel writes straight
+    // into the caller's device buffers; the other routes leave them in the context's and they are copied below)
+    const void* sc_at = nullptr;
+    const void* st_at = nullptr;
     if (method == SP_METHOD_SUBFLATTENING) {
-        SP_CHECK(run_subflat_all_splits(al, trivial, size, shard_rank, shard_world, &n, score));
+        SP_CHECK(run_subflat_all_splits(al, trivial, size, shard_rank, shard_world, &n, score,
+                                        static_cast<double*>(scores_dev), static_cast<int*>(status_dev)));
+        sc_at = scores_dev;
+        st_at = status_dev;
     } else {
         SP_REQUIRE(method == SP_METHOD_FLATTENING || method == SP_METHOD_FLATTENING_DENSE ||
                    method == SP_METHOD_FLATTENING_SPARSE || method == SP_METHOD_MUTUAL_INFORMATION, SP_EINVAL,
@@ -1315,10 +1322,16 @@ extern "C" int sp_score_all_splits_shard(sp_alignment* al, int method, int trivi
     }
     if (n_splits) *n_splits = n;
     if (!score || n == 0) return SP_OK;
-    if (scores_dev) SP_HIP(hipMemcpyAsync(scores_dev, ctx->scores.p, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    if (status_dev) SP_HIP(hipMemcpyAsync(status_dev, ctx->status.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    if (scores_host) SP_HIP(hipMemcpyAsync(scores_host, ctx->scores.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (status_host) SP_HIP(hipMemcpyAsync(status_host, ctx->status.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (!sc_at) {
+        sc_at = ctx->scores.p;
+        if (scores_dev) SP_HIP(hipMemcpyAsync(scores_dev, sc_at, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (!st_at) {
+        st_at = ctx->status.p;
+        if (status_dev) SP_HIP(hipMemcpyAsync(status_dev, st_at, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (scores_host) SP_HIP(hipMemcpyAsync(scores_host, sc_at, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (status_host) SP_HIP(hipMemcpyAsync(status_host, st_at, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (scores_host || status_host) SP_HIP(hipStreamSynchronize(ctx->stream));
     if (status_host) {
         int64_t bad = 0;

@@ -672,7 +672,9 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
 }
 
 // Scores of S splits whose taxon lists (int8, split-major) and first-side sizes already sit on the device.
-static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da, int64_t S, int kmax);
+// scores_out / status_out: device buffers of the caller (NULL = the context's own, ctx->scores / ctx->status).
+static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da, int64_t S, int kmax,
+                           double* scores_out = nullptr, int* status_out = nullptr);
 
 int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S) {
     sp_ctx* ctx = al->ctx;
@@ -708,13 +710,34 @@ int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t
 // here thread i un-ranks combination i of its class (combinatorial number system) and writes the taxon list itself.
 // Shards (multi-GPU, SURVEY 8e "index-mod-P within each class"): rank r of P enumerates the combinations r, r + P, ... of
 // every class; thread `local` writes combination local * P + r at position local.
-__global__ __launch_bounds__(256) void k_enumerate_splits(int n, int bal, int even, unsigned long long count,
-                                                          const unsigned long long* __restrict__ binom,   // [33][33]
-                                                          int8_t* __restrict__ taxa_out, int* __restrict__ a_out,
-                                                          unsigned shard_rank, unsigned shard_world) {
-    const unsigned long long local = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    const unsigned long long idx = local * shard_world + shard_rank;
-    if (idx >= count) return;
+// Pascal's triangle up to 32, built at compile time: part of the code object (no upload, no host synchronisation a call).
+struct BinomTable {
+    unsigned long long v[33 * 33];
+    constexpr BinomTable() : v{} {
+        for (int i = 0; i < 33; ++i)
+            for (int j = 0; j <= i; ++j) v[i * 33 + j] = (j == 0 || j == i) ? 1ull : v[(i - 1) * 33 + j - 1] + v[(i - 1) * 33 + j];
+    }
+};
+__device__ const BinomTable g_binom{};
+
+// the size classes of one enumeration (at most 16: sizes 1 .. 16 of <= 32 taxa), passed by value
+struct EnumClasses {
+    int nclass;
+    int b[16];                        // size of the smaller side
+    unsigned long long full[16];      // combinations of the class
+    unsigned long long offset[17];    // first output position of the class (this shard's counts, prefix sums)
+};
+
+__global__ __launch_bounds__(256) void k_enumerate_splits(int n, EnumClasses cl, int8_t* __restrict__ taxa_out,
+                                                          int* __restrict__ a_out, unsigned shard_rank, unsigned shard_world) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= cl.offset[cl.nclass]) return;
+    int q = 0;
+    while (q + 1 < cl.nclass && g >= cl.offset[q + 1]) ++q;
+    const unsigned long long local = g - cl.offset[q];
+    const unsigned long long idx = local * shard_world + shard_rank;   // < cl.full[q] by the definition of the shard's count
+    const int bal = cl.b[q], even = 2 * bal == n ? 1 : 0;
+    const unsigned long long* __restrict__ binom = g_binom.v;
     const int m = even ? n - 1 : n, r = even ? bal - 1 : bal, base = even ? 1 : 0;
     unsigned int member = even ? 1u : 0u;
     unsigned long long x = idx;
@@ -732,14 +755,14 @@ __global__ __launch_bounds__(256) void k_enumerate_splits(int n, int bal, int ev
     }
     const unsigned int all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
     const unsigned int first = (member & 1u) ? member : (~member & all);   // the side that holds taxon 0
-    int8_t* out = taxa_out + local * (unsigned long long)n;
+    int8_t* out = taxa_out + g * (unsigned long long)n;
     int pos = 0;
     for (int t = 0; t < n; ++t)
         if (first & (1u << t)) out[pos++] = (int8_t)t;
     const int a = pos;
     for (int t = 0; t < n; ++t)
         if (!(first & (1u << t))) out[pos++] = (int8_t)t;
-    a_out[local] = a;
+    a_out[g] = a;
 }
 
 static unsigned long long binom_host(int nn, int kk) {
@@ -778,25 +801,22 @@ int enumerate_all_splits(sp_ctx* ctx, int n, int trivial, int size, bool enumera
     if (total_out) *total_out = total;
     if (!enumerate || total == 0) return SP_OK;
     SP_REQUIRE(total < ((int64_t)1 << 31), SP_ELIMIT, "%lld splits: more than one call takes", (long long)total);
-    std::vector<unsigned long long> bt(33 * 33, 0);
-    for (int i = 0; i < 33; ++i)
-        for (int j = 0; j <= i; ++j) bt[i * 33 + j] = binom_host(i, j);
+    SP_REQUIRE(sizes.size() <= 16, SP_ELIMIT, "%d size classes", (int)sizes.size());
     const size_t taxa_bytes = ((size_t)total * n + 15) & ~(size_t)15;
     SP_CHECK(ctx->coords.ensure(taxa_bytes + (size_t)total * 4 + 64));
-    SP_CHECK(ctx->misc2.ensure(bt.size() * 8));
     int8_t* dtaxa = ctx->coords.as<int8_t>();
     int* da = reinterpret_cast<int*>(dtaxa + taxa_bytes);
-    SP_HIP(hipMemcpyAsync(ctx->misc2.p, bt.data(), bt.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    SP_HIP(hipStreamSynchronize(ctx->stream));   // bt is a host temporary
-    int64_t off = 0;
+    // one launch for all classes, nothing uploaded and no host synchronisation (round 2 launched a kernel a class behind
+    // an upload of the binomial table and a stream synchronise: 0.15 ms of a 0.5 ms step at 16 taxa)
+    EnumClasses cl = {};
+    cl.nclass = (int)sizes.size();
     for (size_t q = 0; q < sizes.size(); ++q) {
-        const int b = sizes[q];
-        if (counts[q] == 0) continue;
-        hipLaunchKernelGGL(k_enumerate_splits, dim3((unsigned)((counts[q] + 255) / 256)), dim3(256), 0, ctx->stream, n, b,
-                           2 * b == n ? 1 : 0, full[q], ctx->misc2.as<unsigned long long>(), dtaxa + (size_t)off * n, da + off,
-                           (unsigned)shard_rank, (unsigned)shard_world);
-        off += (int64_t)counts[q];
+        cl.b[q] = sizes[q];
+        cl.full[q] = full[q];
+        cl.offset[q + 1] = cl.offset[q] + counts[q];
     }
+    hipLaunchKernelGGL(k_enumerate_splits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, n, cl, dtaxa, da,
+                       (unsigned)shard_rank, (unsigned)shard_world);
     SP_HIP(hipGetLastError());
     *dtaxa_out = dtaxa;
     *da_out = da;
@@ -804,8 +824,9 @@ int enumerate_all_splits(sp_ctx* ctx, int n, int trivial, int size, bool enumera
 }
 
 // Number of splits all_splits yields, and - when scores are asked for - their subflattening scores in that order.
+// scores_out / status_out (device, optional): where the kernel writes instead of the context's buffers.
 int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int shard_rank, int shard_world, int64_t* n_out,
-                           bool score) {
+                           bool score, double* scores_out, int* status_out) {
     sp_ctx* ctx = al->ctx;
     const int8_t* dtaxa = nullptr;
     const int* da = nullptr;
@@ -819,16 +840,23 @@ int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int shard_ra
     int kmax = 0;
     for (size_t q = 0; q < sizes.size(); ++q)
         if (counts[q]) kmax = std::max(kmax, sizes[q]);
-    return launch_subscore(al, dtaxa, da, total, kmax);
+    return launch_subscore(al, dtaxa, da, total, kmax, scores_out, status_out);
 }
 
-static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da, int64_t S, int kmax) {
+static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da, int64_t S, int kmax, double* scores_out,
+                           int* status_out) {
     sp_ctx* ctx = al->ctx;
     const int n = al->n_taxa;
     SP_CHECK(ensure_moments(al));
     const int rmax = (3 * kmax + 1 + 1) & ~1;
-    SP_CHECK(ctx->scores.ensure((size_t)S * 8));
-    SP_CHECK(ctx->status.ensure((size_t)S * 4));
+    if (!scores_out) {
+        SP_CHECK(ctx->scores.ensure((size_t)S * 8));
+        scores_out = ctx->scores.as<double>();
+    }
+    if (!status_out) {
+        SP_CHECK(ctx->status.ensure((size_t)S * 4));
+        status_out = ctx->status.as<int>();
+    }
     PhaseScope ps(ctx, SP_PHASE_SUBSCORE);
     const int mdim = 3 * n + 1;
     if (mdim <= SUBT_MMAX && rmax <= 32 && !ctx->opt.subscore_jacobi) {   // fast form (the option keeps the Jacobi kernel testable)
@@ -880,13 +908,13 @@ static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da,
         const unsigned blocks_t = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)dev_cus * per_cu));
         if (m32)
             hipLaunchKernelGGL((k_subscore_tri<true, true>), dim3(blocks_t), dim3(waves * 64), lds_t, ctx->stream,
-                               al->moments.p, n, rt, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
+                               al->moments.p, n, rt, dtaxa, da, S, scores_out, status_out);
         else if (al->exact)
             hipLaunchKernelGGL((k_subscore_tri<true, false>), dim3(blocks_t), dim3(waves * 64), lds_t, ctx->stream,
-                               al->moments.p, n, rt, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
+                               al->moments.p, n, rt, dtaxa, da, S, scores_out, status_out);
         else
             hipLaunchKernelGGL((k_subscore_tri<false, false>), dim3(blocks_t), dim3(waves * 64), lds_t, ctx->stream,
-                               al->moments.p, n, rt, dtaxa, da, S, ctx->scores.as<double>(), ctx->status.as<int>());
+                               al->moments.p, n, rt, dtaxa, da, S, scores_out, status_out);
         SP_HIP(hipGetLastError());
         return SP_OK;
     }
@@ -894,10 +922,10 @@ static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da,
     const unsigned blocks = (unsigned)((S + SUB_WAVES - 1) / SUB_WAVES);
     if (al->exact)
         hipLaunchKernelGGL(k_subscore<true>, dim3(blocks), dim3(SUB_WAVES * 64), lds, ctx->stream, al->moments.p, n,
-                           dtaxa, da, S, rmax, ctx->scores.as<double>(), ctx->status.as<int>());
+                           dtaxa, da, S, rmax, scores_out, status_out);
     else
         hipLaunchKernelGGL(k_subscore<false>, dim3(blocks), dim3(SUB_WAVES * 64), lds, ctx->stream, al->moments.p, n,
-                           dtaxa, da, S, rmax, ctx->scores.as<double>(), ctx->status.as<int>());
+                           dtaxa, da, S, rmax, scores_out, status_out);
     SP_HIP(hipGetLastError());
     return SP_OK;
 }
