@@ -68,7 +68,7 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const CT* cnt, int
     constexpr int PER = 32 / BITS;                     // counters per word
     constexpr u32 FMASK = (1u << BITS) - 1;
     const int stride = (nmajor + PER - 1) / PER;       // words per wave row
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = spk_wave_id();
     // entries per lane: ODD, so that the 64 lanes of a load (stride q words) spread over all LDS banks - an even q puts
     // them on 2 .. 16 banks (q = 16: a 32-way conflict on every load of both passes)
     const int q = ((D + nsort * 64 - 1) / (nsort * 64)) | 1;   // nsort = wave-private counter rows in use (<= SPK_WAVES)
@@ -284,7 +284,7 @@ struct SpkListOut {
 
 // exclusive scan of one u32 per thread over the thread's HALF of the block (both halves call it together)
 __device__ __forceinline__ u32 spk_scan_half(u32 v, SpkShared& sh, u32& total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = w / SPK_HALF_WAVES, wh = w % SPK_HALF_WAVES;
+    const int lane = threadIdx.x & 63, w = spk_wave_id(), h = w / SPK_HALF_WAVES, wh = w % SPK_HALF_WAVES;
     u32 x = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -310,7 +310,7 @@ __device__ __forceinline__ void spk_build_pair(const u32* pc, const CT* cnt, int
                                                const SpkListOut& Lr, SpkShared& sh) {
     constexpr int BITS = 16, PER = 2;
     constexpr u32 FMASK = 0xFFFFu;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = spk_wave_id();
     const int h = w / SPK_HALF_WAVES, wh = w % SPK_HALF_WAVES, th = threadIdx.x % SPK_HALF_THREADS;
     const bool is_col = h == 0;
     // (wave-uniform selects: the half's own list)
@@ -526,7 +526,7 @@ __device__ __forceinline__ void spk_group_cols(const u32* pc, const CT* cnt, int
             sum += ((u64)a << cls_sh(a)) + ((u64)b << cls_sh(b));
             nz += (a != 0) + (b != 0);
         }
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, w = spk_wave_id();
         u64 x = sum;
         u32 xn = nz;
 #pragma unroll
@@ -670,7 +670,7 @@ __device__ __forceinline__ void spk_spmm(const unsigned short* ptrp, const u32* 
                                          const unsigned short* perm, int nwave, int nrow, int nquad, const double* in_d,
                                          int in_pitch, int in_cs, double* out, int out_pitch, int out_cs,
                                          int stamp_at = -1) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = spk_wave_id();
     const char* in = reinterpret_cast<const char*>(in_d);
     const int pb = in_pitch * 8;
     for (int idx = w; idx < nwave; idx += SPK_WAVES) {                      // one wave per group
@@ -1465,7 +1465,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
                 // and k = s16, 16 + s16, ...: the 16 lanes of a group read 16 consecutive cells of a G row and 16 consecutive
                 // rows of V per instruction (no bank conflicts), a V row is fetched once per 4 rows of G, and the 16 partial
                 // sums of a (row, column) meet in the DPP row reduction of spk_spmm.
-                const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+                const int lane = threadIdx.x & 63, w = spk_wave_id();
                 const int s16 = lane & 15, r0 = 16 * w + 4 * (lane >> 4);
                 double a4[4][4];
 #pragma unroll
@@ -1543,7 +1543,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
                 __syncthreads();
                 if (row < R) V[row * v_rs + j * v_cs] = acc;
             }
-            if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = part;
+            if ((threadIdx.x & 63) == 0) sh.red[spk_wave_id()] = part;
             __syncthreads();
             top4 = 0;
 #pragma unroll
@@ -1753,7 +1753,7 @@ __global__ __launch_bounds__(1024) void k_sparse_meta(const u64* __restrict__ ke
                                                       unsigned long long trace_override, u32 orig_rows) {
     __shared__ unsigned long long red[16];
     __shared__ unsigned long long winner;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = spk_wave_id();
     unsigned long long tr = 0;
     for (int i = threadIdx.x; i < D; i += 1024) {
         keys32[i] = (u32)keys[i];

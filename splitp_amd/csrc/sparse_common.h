@@ -77,6 +77,11 @@ struct SpkShared {
     unsigned int bucket[68];
 };
 
+// The wave's index in the workgroup as a value the compiler knows to be wave-uniform (threadIdx.x >> 6 is "divergent" to
+// its analysis): loops dealt out by wave, their bounds and the addresses built from them then live in scalar registers and
+// branch on the scalar unit instead of occupying a vector register and an exec-mask dance each.
+__device__ __forceinline__ int spk_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 __device__ __forceinline__ double spk_hash(unsigned a, unsigned b) {
     unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
@@ -101,7 +106,7 @@ __device__ __forceinline__ void spk_rowcol(u64 key, const int* shifts, int nr, i
 
 // exclusive scan of one u32 per thread over the block; returns the exclusive prefix, total in `total`
 __device__ __forceinline__ u32 spk_scan(u32 v, SpkShared& sh, u32& total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = spk_wave_id();
     u32 x = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -137,7 +142,7 @@ __device__ __forceinline__ u32 bm_rank(const u64* bm, const u32* pf, u32 k) {
 // i + 4b + 16k, B[k][j] in lane j + 4b + 16k - probed, tools/mfma_f64_4x4_probe.hip), D[i][j] of block b comes back in
 // lane j + 4b + 16i.  Blocks are summed with two shuffles, waves through LDS in a fixed order.  Ends with a barrier.
 __device__ __forceinline__ void spk_gram(const double* X, int rows, int rs, int cs, SpkShared& sh) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = spk_wave_id();
     const int c = lane & 3, rl = lane >> 2;
     double acc = 0.0;
     for (int base = w * 16; base < rows; base += SPK_WAVES * 16) {
@@ -356,7 +361,7 @@ __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double t
 // esh.H (16 x EIG_VP, first 8 x 8 used) = X^T X of the rows x 8 column-major block X: one (i, j >= i) pair per wave and
 // turn, lanes stride the rows, fixed shuffle tree.  Ends with a barrier.
 __device__ __forceinline__ void spk_wide_gram(const double* X, int rows, int cs, EigShared& esh) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = spk_wave_id();
     for (int p = w; p < SPK_WB * (SPK_WB + 1) / 2; p += SPK_WAVES) {
         int i = 0, q = p;
         while (q >= SPK_WB - i) { q -= SPK_WB - i; ++i; }
