@@ -12,6 +12,11 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
+// The wave's index in its workgroup as a value the compiler knows to be wave-uniform (threadIdx.x >> 6 is "divergent" to its
+// analysis): loops dealt out by wave, their bounds and the addresses built from them then live in scalar registers and
+// branch on the scalar unit instead of taking a vector register and an exec-mask sequence each.
+__device__ __forceinline__ int sp_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 void sp_set_error(const char* fmt, ...);
 
 #define SP_HIP(call)                                                                              \

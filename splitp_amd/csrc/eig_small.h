@@ -50,7 +50,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 // Waves 4-7 deposit first, waves 0-3 add theirs on top, then 256 threads add the 4 slots in a
 // fixed order (deterministic).  Ends with a barrier.
 __device__ __forceinline__ void reduce16(const double4_t& acc, EigShared& sh, double* out) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = sp_wave_id();
     const int fr = lane & 15, fk = lane >> 4;
     if (w >= EIG_WAVES / 2) {
 #pragma unroll
@@ -75,7 +75,7 @@ __device__ __forceinline__ void reduce16(const double4_t& acc, EigShared& sh, do
 // into sh.part, then summed into `out` (16 x EIG_VP).  Ends with a barrier.
 template <int NB, int VP>
 __device__ __forceinline__ void gram_nb(const double* X, int Rp, EigShared& sh, double* out) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = sp_wave_id();
     const int fr = lane & 15, fk = lane >> 4;
     double4_t acc = {0, 0, 0, 0};
     for (int r0 = w * 4; r0 < Rp; r0 += EIG_WAVES * 4) {
@@ -89,7 +89,7 @@ __device__ __forceinline__ void gram_nb(const double* X, int Rp, EigShared& sh, 
 // (each wave owns whole 16-row tiles: all reads of a tile precede its writes).  Ends with a barrier.
 template <int NB, int VP>
 __device__ __forceinline__ void rowmul_nb(double* X, int Rp, const double* B) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = sp_wave_id();
     const int fr = lane & 15, fk = lane >> 4;
     constexpr int KB = NB / 4;
     double bfrag[KB];
@@ -275,7 +275,7 @@ struct EigSpec {
 };
 template <int NB>
 __device__ __forceinline__ void jacobi_dual(EigShared& sh, EigSpec& sp2) {
-    const int w = threadIdx.x >> 6;
+    const int w = sp_wave_id();
     if (w == 0) jacobi_core<NB>(sh.H, sh.Q, sh.theta, true);
     else if (w == 1) {
         jacobi_core<EIG_B>(sp2.H, sp2.Q, sp2.theta, false);
@@ -404,7 +404,7 @@ __device__ __forceinline__ void polish_nb(double* X, int Rp, EigShared& sh) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) err = fmax(err, __shfl_xor(err, d, 64));
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = err;
+        if ((threadIdx.x & 63) == 0) sh.red[sp_wave_id()] = err;
         __syncthreads();
         double emx = 0;
         for (int k = 0; k < EIG_WAVES; ++k) emx = fmax(emx, sh.red[k]);
@@ -440,7 +440,7 @@ __device__ __forceinline__ void orth_near_nb(double* X, int Rp, EigShared& sh) {
 template <int VP>
 __device__ __forceinline__ void proj_first_power(const double* Y, int Rp, const double* __restrict__ Vt, int vp,
                                                  EigShared& sh) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = sp_wave_id();
     const int fr = lane & 15, fk = lane >> 4;
     double4_t acc = {0, 0, 0, 0};
     // 16 rows a step: a lane loads 4 consecutive entries of its V^T row (32 B; the 4 lanes of a row read one 128-B
@@ -500,7 +500,7 @@ struct EigState {
 #define EIG_NFAST 5
 
 __device__ __forceinline__ double block_sum(double v, EigShared& sh) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = sp_wave_id();
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     __syncthreads();

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_eig_gv(const GramItem* __restrict__ ite
     const SplitDev& sp = splits[sid];
     const int R = min(dims[sid].x, sp.rcap);
     const int Rp = (R + 15) & ~15;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = sp_wave_id();
     const int fr = lane & 15, fk = lane >> 4;
     const int row0 = it.ti * 64 + w * 16;
     if (row0 >= Rp) return;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_finish(const SplitDev* __re
     const int Rp = (R + 15) & ~15;
     const GT* __restrict__ G = grams + sp.g_off;
     const int64_t gp = sp.g_pitch;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = sp_wave_id();
     const int fr = lane & 15, fk = lane >> 4;
     load_vt(V, Rp, vt_pool + sp.ev_off, sp.rcap);
     __syncthreads();

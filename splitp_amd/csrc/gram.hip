@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_gram(const SplitDev* __restrict__ split
     const T* __restrict__ base = mats + sp.mat_off;
     const int64_t pitch = sp.pitch;
     const bool diag = (ti == tj);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = sp_wave_id();
     const int wr = w >> 1, wc = w & 1;
     const int fr = lane & 15, fk = lane >> 4;
 

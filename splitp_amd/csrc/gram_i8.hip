@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, GI_WAVES_PER_SIMD) void k_gram_i8(const SplitD
     const int64_t plane = (int64_t)sp.rcap * pitch;       // bytes per limb plane
     const uint8_t* __restrict__ base = mats + sp.mat_off;
     const bool diag = (ti == tj);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = sp_wave_id();
     const int wr = w >> 1, wc = w & 1;
     const int fr = lane & 31, fh = lane >> 5;
 
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void k_gram_i8_big(const SplitDev* __restri
     const int64_t plane = (int64_t)sp.rcap * pitch;       // bytes per limb plane
     const uint8_t* __restrict__ base = mats + sp.mat_off;
     const bool diag = (ti == tj);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = sp_wave_id();
     const int wr = w >> 2, wc = w & 3;
     const int fr = lane & 31, fh = lane >> 5;
     const int row0 = ti * GB_TILE + wr * 64, col0 = tj * GB_TILE + wc * 32;   // this wave's 64 x 32 sub-tile of G

@@ -77,10 +77,7 @@ struct SpkShared {
     unsigned int bucket[68];
 };
 
-// The wave's index in the workgroup as a value the compiler knows to be wave-uniform (threadIdx.x >> 6 is "divergent" to
-// its analysis): loops dealt out by wave, their bounds and the addresses built from them then live in scalar registers and
-// branch on the scalar unit instead of occupying a vector register and an exec-mask dance each.
-__device__ __forceinline__ int spk_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int spk_wave_id() { return sp_wave_id(); }   // (common.h)
 
 __device__ __forceinline__ double spk_hash(unsigned a, unsigned b) {
     unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
