@@ -377,9 +377,11 @@ __device__ __forceinline__ double subt_dpp(double x) {
 __device__ __forceinline__ double subt_readlane(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
+// SKIP = 1: lanes 2i and 2i + 1 hold the same addend (it is counted once), SKIP = 2: all four lanes of a quad do.
+template <int SKIP = 0>
 __device__ __forceinline__ double subt_wave_sum(double x) {
-    x += subt_dpp<0xB1>(x);    // quad_perm [1,0,3,2]
-    x += subt_dpp<0x4E>(x);    // quad_perm [2,3,0,1]
+    if (SKIP < 1) x += subt_dpp<0xB1>(x);    // quad_perm [1,0,3,2]
+    if (SKIP < 2) x += subt_dpp<0x4E>(x);    // quad_perm [2,3,0,1]
     x += subt_dpp<0x114>(x);   // row_shr:4
     x += subt_dpp<0x118>(x);   // row_shr:8  -> lanes 12..15 of every row hold the row total
     return (subt_readlane(x, 15) + subt_readlane(x, 31)) + (subt_readlane(x, 47) + subt_readlane(x, 63));
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
                 if (SH == 2) p += subt_dpp<0x4E>(p);
                 p *= beta;
                 const double vr = act ? sv[row] : 0.0;
-                const double kk = subt_wave_sum((par == 0 && act) ? vr * p : 0.0);
+                const double kk = subt_wave_sum<SH>(vr * p);   // (every lane of a row holds the row's term; vr = 0 off the block)
                 const double wr = p - 0.5 * beta * kk * vr;
                 if (par == 0 && row < 32) swv[row] = act ? wr : 0.0;
                 wave_sync_lds2();
@@ -641,7 +643,11 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
         const int grp = lane >> 4, t = lane & 15;
         const int want = r - 1 - grp;                     // ascending index of this group's eigenvalue
         const unsigned rmask = (1u << r) - 1u;            // r <= 31
-        const subt_d2* de = reinterpret_cast<const subt_d2*>(sde);
+        // (the table's LDS address kept in a vector register - the opaque zero - or it is re-made from a scalar one by a
+        // v_mov in front of every read: one of a step's five vector instructions)
+        int vzero = 0;
+        asm volatile("" : "+v"(vzero));
+        const subt_d2* de = reinterpret_cast<const subt_d2*>(sde) + vzero;
         for (int pass = 0; pass < SUBT_PASSES; ++pass) {
             const double sigma = lo + (hi - lo) * ((double)(t + 1) * (1.0 / 17.0));
             double pp = 1.0, pc = sde[0] - sigma;
