@@ -367,11 +367,11 @@ __global__ __launch_bounds__(SUB_WAVES * 64) void k_subscore(const void* __restr
 
 // Sum over the 64 lanes, returned to all of them: two quad steps and two row shifts on the DPP path (no LDS crossbar),
 // then the four row totals through scalar registers.  Fixed order.
-template <int CTRL>
-__device__ __forceinline__ double subt_dpp(double x) {
+template <int CTRL, int ROWS = 0xF>
+__device__ __forceinline__ double subt_dpp(double x) {   // (rows outside the mask ROWS receive 0)
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWS, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWS, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double subt_readlane(double x, int l) {
@@ -382,9 +382,11 @@ template <int SKIP = 0>
 __device__ __forceinline__ double subt_wave_sum(double x) {
     if (SKIP < 1) x += subt_dpp<0xB1>(x);    // quad_perm [1,0,3,2]
     if (SKIP < 2) x += subt_dpp<0x4E>(x);    // quad_perm [2,3,0,1]
-    x += subt_dpp<0x114>(x);   // row_shr:4
-    x += subt_dpp<0x118>(x);   // row_shr:8  -> lanes 12..15 of every row hold the row total
-    return (subt_readlane(x, 15) + subt_readlane(x, 31)) + (subt_readlane(x, 47) + subt_readlane(x, 63));
+    x += subt_dpp<0x114>(x);        // row_shr:4
+    x += subt_dpp<0x118>(x);        // row_shr:8  -> lanes 12..15 of every row hold the row total
+    x += subt_dpp<0x142, 0xA>(x);   // row_bcast:15 into rows 1 and 3: lane 31 = rows 0 + 1, lane 63 = rows 2 + 3
+    x += subt_dpp<0x143, 0xC>(x);   // row_bcast:31 into rows 2 and 3: lane 63 = the total
+    return subt_readlane(x, 63);    // (8 instructions instead of the 15 of four readlanes and their sum)
 }
 
 // Per-wave LDS: de (32 pairs {d_i, e2_(i-1)}: diagonal and squared sub-diagonal of the tridiagonal matrix, one 16-byte
@@ -431,11 +433,24 @@ __device__ __forceinline__ double subt_half_sum(double x) {
     x += subt_dpp<0x4E>(x);
     x += subt_dpp<0x114>(x);
     x += subt_dpp<0x118>(x);
-    return subt_readlane(x, 15) + subt_readlane(x, 31);
+    x += subt_dpp<0x142, 0xA>(x);
+    return subt_readlane(x, 31);
 }
 
 // M32: count table with fewer than 2^31 sites - every moment fits an int32, the staged matrix takes half the LDS and a
 // third workgroup fits the CU (3 waves per SIMD instead of 2: the eigenvalue steps are dependency chains).
+#ifdef SUBT_STAMPS
+// diagnostic build (tools/gpu_subflat_stamps.sh): s_memtime of wave 0 of workgroup 0 at the phase boundaries of its last split
+// (the splits come in ascending size classes: one of the longest)
+__device__ long long g_subt_stamps[16];
+extern "C" int sp_debug_subt_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_subt_stamps), sizeof(long long) * 16) == hipSuccess ? 0 : 2;
+}
+#define TSTAMP(i) do { if (blockIdx.x == 0 && w == 0 && lane == 0) g_subt_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i)
+#endif
+
 template <bool EXACT, bool M32>
 __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void* __restrict__ Mv, int n, int rmax,
                                                                      const int8_t* __restrict__ split_taxa,
@@ -462,6 +477,7 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
     const int wpb = nthreads >> 6;
     const int64_t nwaves = (int64_t)gridDim.x * wpb;
     for (int64_t sid = (int64_t)blockIdx.x * wpb + w; sid < S; sid += nwaves) {
+        TSTAMP(0);
         const int8_t* taxa = split_taxa + sid * n;
         const int a = split_a[sid], b = n - a;
         const bool swap = a > b;   // rows = smaller side
@@ -473,6 +489,7 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
         if (lane < r) urow[lane] = (unsigned short)(sub_index(rt, nr, n, lane) * m);
         if (lane < c) vcol[lane] = (unsigned char)sub_index(ct, nc, n, lane);
         wave_sync_lds2();
+        TSTAMP(1);
         // Gram over the rows on the matrix cores: G = B B^T, B[i][k] = M[urow_i + vcol_k] gathered straight from the
         // staged moment matrix.  v_mfma_f64_16x16x4: lane (fr = lane & 15, fk = lane >> 4) supplies B[16 I + fr][4 s + fk]
         // as A and B[16 J + fr][4 s + fk] as B operand of tile (I, J); accumulator q holds G[16 I + fk + 4 q][16 J + fr].
@@ -529,6 +546,7 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
             }
             continue;
         }
+        TSTAMP(2);
         // ---- Householder tridiagonalisation: d (diagonal), e2 (squared off-diagonal) -----------------------------------
         // step k annihilates column k below the sub-diagonal with H = I - beta v v^T on the trailing block A (L x L):
         // A <- H A H = A - v w^T - w v^T,  p = beta A v,  w = p - (beta v^T p / 2) v.   Lane pair (2i, 2i+1) owns row i.
@@ -546,8 +564,8 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
             }
             // sqrt and reciprocal by the hardware seeds + Newton steps (an IEEE fp64 sqrt and division are ~25 and ~30
             // instructions, and this kernel is VALU-issue bound: 75 % of the issue slots, profiles/r03a_pmc_binding_config4.json)
+            // (v_rsq_f64 is good to 2^-24: one Newton step gives 2^-47, the correction of sq = sig * ry squares that again)
             double ry = __builtin_amdgcn_rsq(sig);
-            ry = ry * fma(-0.5 * sig * ry, ry, 1.5);
             ry = ry * fma(-0.5 * sig * ry, ry, 1.5);
             double sq = sig * ry;
             sq = fma(0.5 * ry, fma(-sq, sq, sig), sq);        // sqrt(sig) to the last bit or two
@@ -607,6 +625,7 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
             sde[2 * (r - 1) + 1] = eo * eo;
         }
         wave_sync_lds2();
+        TSTAMP(3);
         // ---- four largest eigenvalues of the tridiagonal matrix by multisection on the Sturm count ---------------------
         // The count of eigenvalues below a shift is the number of sign changes in the sequence of leading principal minors
         // P_0 = 1, P_1 = d_0 - s, P_(i+1) = (d_i - s) P_i - e2_(i-1) P_(i-1): three full-rate fp64 instructions and one
@@ -665,6 +684,7 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
             lo = nlo;
             hi = nhi;
         }
+        TSTAMP(4);
         const double lam = 0.5 * (lo + hi);
         double top = (t == 0) ? fmax(lam, 0.0) : 0.0;
         top += __shfl_xor(top, 16, 64);
@@ -674,6 +694,7 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
             scores[sid] = sqrt(op > 0 ? op : 0.0);
             status[sid] = SUBT_PASSES << 8;
         }
+        TSTAMP(5);
     }
 }
 
