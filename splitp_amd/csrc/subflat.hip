@@ -569,14 +569,14 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
             ry = ry * fma(-0.5 * sig * ry, ry, 1.5);
             double sq = sig * ry;
             sq = fma(0.5 * ry, fma(-sq, sq, sig), sq);        // sqrt(sig) to the last bit or two
-            const double alpha = x0 >= 0 ? -sq : sq;
+            const double alpha = __builtin_copysign(sq, -x0);  // -sign(x0) sqrt(sig)   (x0 = -0.0 counts as negative: either sign is a valid reflector)
             const double den = sig - alpha * x0;
             double beta = __builtin_amdgcn_rcp(den);          // 2 / (v^T v)
             beta = fma(fma(-den, beta, 1.0), beta, beta);
             beta = fma(fma(-den, beta, 1.0), beta, beta);
             const double vi = (lane == 0) ? x0 - alpha : x;   // v (lane < L)
             if (lane == 0) sde[2 * k + 3] = sig;              // alpha^2
-            if (lane < 32) sv[lane] = lane < L ? vi : 0.0;
+            if (lane < 32) sv[lane] = vi;                     // (x = 0 from lane L on, and L >= 2)
             wave_sync_lds2();
             // rows of the trailing block: 2 lanes a row, 4 once the block has <= 16 rows (half the trips of both loops).
             // Both loops are unrolled over wave-uniform trips (constant LDS offsets, one scalar test a trip): the product
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
                 const double vr = act ? sv[row] : 0.0;
                 const double kk = subt_wave_sum<SH>(vr * p);   // (every lane of a row holds the row's term; vr = 0 off the block)
                 const double wr = p - 0.5 * beta * kk * vr;
-                if (par == 0 && row < 32) swv[row] = act ? wr : 0.0;
+                if (par == 0 && row < 32) swv[row] = wr;      // (p = vr = 0 off the block: wr = 0 there)
                 wave_sync_lds2();
                 if (act) {
 #pragma unroll
