@@ -550,9 +550,12 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
         // ---- Householder tridiagonalisation: d (diagonal), e2 (squared off-diagonal) -----------------------------------
         // step k annihilates column k below the sub-diagonal with H = I - beta v v^T on the trailing block A (L x L):
         // A <- H A H = A - v w^T - w v^T,  p = beta A v,  w = p - (beta v^T p / 2) v.   Lane pair (2i, 2i+1) owns row i.
+        // (lane * P and the row offsets of the two row layouts once a split: a 32-bit vector multiply takes four issue slots,
+        // and the compiler redid three of them every step)
+        const int laneP = lane * P, row2P = (lane >> 1) * P + (lane & 1), row4P = (lane >> 2) * P + (lane & 3);
         for (int k = 0; k < r - 2; ++k) {
             const int L = r - k - 1, o = k + 1;
-            const double x = (lane < L) ? G[(o + lane) * P + k] : 0.0;
+            const double x = (lane < L) ? G[laneP + (o * P + k)] : 0.0;
             const double sig = subt_half_sum(x * x);          // (L <= 30: lanes 32.. hold 0)
             const double x0 = subt_readlane(x, 0);
             if (lane == 0) sde[2 * k] = G[k * P + k];
@@ -586,17 +589,19 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
                 constexpr int SH = decltype(shc)::value, LPR = 1 << SH, TRIPS = SH == 2 ? 4 : 15;
                 const int row = lane >> SH, par = lane & (LPR - 1);
                 const bool act = row < L;
-                double* const g = G + (o + row) * P + o + par;   // this lane's first entry of its row
+                double* const g = G + (SH == 2 ? row4P : row2P) + (o * P + o);   // this lane's first entry of its row
                 const double* const vp = sv + par;
                 const double* const wp = swv + par;
-                double p = 0;
+                double p = 0, p1 = 0;   // (two chains: the sum is a dependent sequence of up to 15 fused multiply-adds otherwise)
                 if (act) {
 #pragma unroll
                     for (int tq = 0; tq < TRIPS; ++tq) {
                         if (tq * LPR >= L) break;
-                        p = fma(g[tq * LPR], vp[tq * LPR], p);
+                        if (tq & 1) p1 = fma(g[tq * LPR], vp[tq * LPR], p1);
+                        else p = fma(g[tq * LPR], vp[tq * LPR], p);
                     }
                 }
+                p += p1;
                 p += subt_dpp<0xB1>(p);   // the partner lane(s) of the row
                 if (SH == 2) p += subt_dpp<0x4E>(p);
                 p *= beta;
