@@ -427,6 +427,46 @@ __device__ __forceinline__ void subt_minor_steps(int r, const subt_d2* de, doubl
         }
     }
 }
+// The same recurrence with the table read through the SCALAR cache: every lane of the wave needs the same pair {d_i,
+// e2_(i-1)} at step i, and as a broadcast LDS read that is 1 KB of LDS bandwidth a step - with 13 passes a third of the
+// kernel's LDS time, the unit that bounds it (profiles/r03_pmc_binding_config4_auto.json: LDS 77 % busy, vector issue 58 %).
+// The scaled table is therefore also written to a per-wave slot in global memory (SUBT_SLOT doubles, k_subscore_tri) and
+// fetched here with s_load_dwordx8 - two steps a load, straight into scalar registers, which the vector instructions
+// take as operands: no LDS, no vector instruction.  The compiler knows nothing of these loads, so each is waited for
+// (s_waitcnt lgkmcnt(0), tied to the registers by the "+s" operand) on every path before its registers can be reused.
+// cur = {d_I, e2_(I-1), d_(I+1), e2_I}, I odd.
+#define SUBT_SLOT 80   // doubles per wave: 32 pairs + the pairs a load past the end touches
+typedef double subt_d4 __attribute__((ext_vector_type(4)));
+template <int I>
+__device__ __forceinline__ void subt_minor_steps_s(int r, const double* gde, double sigma, double pp, double pc, subt_d4 cur,
+                                                   unsigned& mask) {
+    if constexpr (I < 31) {
+        if (I < r) {
+            subt_d4 nxt;
+            asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(nxt) : "s"(gde), "n"((I + 2) * 16));
+            __builtin_amdgcn_sched_barrier(0);   // (the request goes out before this pair of steps, not behind the first)
+            double pn = fma(cur.x - sigma, pc, -(cur.y * pp));
+            mask = __builtin_amdgcn_alignbit(mask, (unsigned)__double2hiint(pn), 31);   // (mask << 1) | sign
+            if ((I & 7) == 0) {
+                const int ex = __builtin_amdgcn_frexp_exp(subt_max_abs(pn, pc));
+                pn = ldexp(pn, -ex);
+                pc = ldexp(pc, -ex);
+            }
+            double pq = pn;
+            if (I + 1 < r) {
+                pq = fma(cur.z - sigma, pn, -(cur.w * pc));
+                mask = __builtin_amdgcn_alignbit(mask, (unsigned)__double2hiint(pq), 31);
+                if (((I + 1) & 7) == 0) {
+                    const int ex = __builtin_amdgcn_frexp_exp(subt_max_abs(pq, pn));
+                    pq = ldexp(pq, -ex);
+                    pn = ldexp(pn, -ex);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nxt));
+            if (I + 1 < r) subt_minor_steps_s<I + 2>(r, gde, sigma, pn, pq, nxt, mask);
+        }
+    }
+}
 // sum over the lanes when lanes 32..63 hold 0 (a column of <= 31 entries): rows 0 and 1 only
 __device__ __forceinline__ double subt_half_sum(double x) {
     x += subt_dpp<0xB1>(x);
@@ -455,7 +495,8 @@ template <bool EXACT, bool M32>
 __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void* __restrict__ Mv, int n, int rmax,
                                                                      const int8_t* __restrict__ split_taxa,
                                                                      const int* __restrict__ split_a, int64_t S,
-                                                                     double* __restrict__ scores, int* __restrict__ status) {
+                                                                     double* __restrict__ scores, int* __restrict__ status,
+                                                                     double* __restrict__ slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_t[];
     const int m = 3 * n + 1;
     typedef typename std::conditional<M32, int, double>::type MsT;
@@ -658,25 +699,32 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
         // (tr > 0, so gu > 0; an interval of length 0 - a multiple of the identity - is scaled by its position instead)
         const int E = __builtin_amdgcn_frexp_exp(fmax(gu - gl, fmax(fabs(gl), fabs(gu)) * 0x1p-40));
         wave_sync_lds2();   // every lane has read its neighbours' entries
+        double* const gde = slots + ((size_t)blockIdx.x * wpb + w) * SUBT_SLOT;   // this wave's slot (subt_minor_steps_s)
         if (lane < r) {
-            sde[2 * lane] = ldexp(sde[2 * lane], -E);
-            sde[2 * lane + 1] = lane > 0 ? fmax(ldexp(sde[2 * lane + 1], -2 * E), 0x1p-120) : 0.0;
+            const double ds = ldexp(sde[2 * lane], -E);
+            const double es = lane > 0 ? fmax(ldexp(sde[2 * lane + 1], -2 * E), 0x1p-120) : 0.0;
+            sde[2 * lane] = ds;
+            subt_d2 pr;
+            pr.x = ds;
+            pr.y = es;
+            reinterpret_cast<subt_d2*>(gde)[lane] = pr;
         }
+        // stores acknowledged by L2, then this CU's scalar cache dropped: it may hold the slot's previous contents
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         wave_sync_lds2();
         double lo = ldexp(gl, -E) - 0x1p-44, hi = ldexp(gu, -E) + 0x1p-44;   // (per group of 16 lanes)
         const int grp = lane >> 4, t = lane & 15;
         const int want = r - 1 - grp;                     // ascending index of this group's eigenvalue
         const unsigned rmask = (1u << r) - 1u;            // r <= 31
-        // (the table's LDS address kept in a vector register - the opaque zero - or it is re-made from a scalar one by a
-        // v_mov in front of every read: one of a step's five vector instructions)
-        int vzero = 0;
-        asm volatile("" : "+v"(vzero));
-        const subt_d2* de = reinterpret_cast<const subt_d2*>(sde) + vzero;
+        const double d0 = subt_readlane(sde[0], 0);
         for (int pass = 0; pass < SUBT_PASSES; ++pass) {
+            subt_d4 cur;
+            asm volatile("s_load_dwordx8 %0, %1, 16" : "=s"(cur) : "s"(gde));
             const double sigma = lo + (hi - lo) * ((double)(t + 1) * (1.0 / 17.0));
-            double pp = 1.0, pc = sde[0] - sigma;
+            double pp = 1.0, pc = d0 - sigma;
             unsigned mask = (unsigned)__double2hiint(pc) >> 31;
-            subt_minor_steps<1>(r, de, sigma, pp, pc, de[1], mask);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cur));
+            subt_minor_steps_s<1>(r, gde, sigma, pp, pc, cur, mask);
             // bit j of mask = sign of P_(r-j), bit r = 0 = sign of P_0: sign changes = eigenvalues below sigma
             const int cnt = __popc((mask ^ (mask >> 1)) & rmask);
             // cnt = eigenvalues below sigma; the wanted one is below sigma iff cnt > want
@@ -938,15 +986,16 @@ static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da,
         const int64_t want_blocks = (S + waves - 1) / waves;
         // as many workgroups as are resident at once: persistent waves, grid-stride over the splits
         const unsigned blocks_t = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want_blocks, (int64_t)dev_cus * per_cu));
+        SP_CHECK(ctx->eigws.ensure((size_t)blocks_t * waves * SUBT_SLOT * 8));   // per-wave slots of the scaled tridiagonal tables
         if (m32)
             hipLaunchKernelGGL((k_subscore_tri<true, true>), dim3(blocks_t), dim3(waves * 64), lds_t, ctx->stream,
-                               al->moments.p, n, rt, dtaxa, da, S, scores_out, status_out);
+                               al->moments.p, n, rt, dtaxa, da, S, scores_out, status_out, ctx->eigws.as<double>());
         else if (al->exact)
             hipLaunchKernelGGL((k_subscore_tri<true, false>), dim3(blocks_t), dim3(waves * 64), lds_t, ctx->stream,
-                               al->moments.p, n, rt, dtaxa, da, S, scores_out, status_out);
+                               al->moments.p, n, rt, dtaxa, da, S, scores_out, status_out, ctx->eigws.as<double>());
         else
             hipLaunchKernelGGL((k_subscore_tri<false, false>), dim3(blocks_t), dim3(waves * 64), lds_t, ctx->stream,
-                               al->moments.p, n, rt, dtaxa, da, S, scores_out, status_out);
+                               al->moments.p, n, rt, dtaxa, da, S, scores_out, status_out, ctx->eigws.as<double>());
         SP_HIP(hipGetLastError());
         return SP_OK;
     }
