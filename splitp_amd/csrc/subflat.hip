@@ -467,7 +467,15 @@ __device__ __forceinline__ void subt_minor_steps_s(int r, const double* gde, dou
         }
     }
 }
-// sum over the lanes when lanes 32..63 hold 0 (a column of <= 31 entries): rows 0 and 1 only
+// sum over lanes 0 .. 15 (whatever the others hold)
+__device__ __forceinline__ double subt_row0_sum(double x) {
+    x += subt_dpp<0xB1>(x);
+    x += subt_dpp<0x4E>(x);
+    x += subt_dpp<0x114>(x);
+    x += subt_dpp<0x118>(x);
+    return subt_readlane(x, 15);
+}
+// sum over lanes 0 .. 31 (whatever the others hold): DPP rows 0 and 1 only
 __device__ __forceinline__ double subt_half_sum(double x) {
     x += subt_dpp<0xB1>(x);
     x += subt_dpp<0x4E>(x);
@@ -593,7 +601,7 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
         // A <- H A H = A - v w^T - w v^T,  p = beta A v,  w = p - (beta v^T p / 2) v.   Lane pair (2i, 2i+1) owns row i.
         // (lane * P and the row offsets of the two row layouts once a split: a 32-bit vector multiply takes four issue slots,
         // and the compiler redid three of them every step)
-        const int laneP = lane * P, row2P = (lane >> 1) * P + (lane & 1), row4P = (lane >> 2) * P + (lane & 3);
+        const int laneP = lane * P, row2P = (lane & 31) * P + (lane >> 5), row4P = (lane & 15) * P + (lane >> 4);
         for (int k = 0; k < r - 2; ++k) {
             const int L = r - k - 1, o = k + 1;
             const double x = (lane < L) ? G[laneP + (o * P + k)] : 0.0;
@@ -626,9 +634,13 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
             // Both loops are unrolled over wave-uniform trips (constant LDS offsets, one scalar test a trip): the product
             // runs whole trips - v_j = w_j = 0 for L <= j < 32 -, the update masks its last partial trip (an entry past the
             // row can be a live entry of the next one).
+            // Lanes of a row are 32 (16) lanes apart - row = lane & 31, part = lane >> 5 -, not neighbours: the 16 lanes one
+            // LDS cycle serves then read 16 different rows, whose odd pitch puts them on 16 different bank pairs.  With
+            // neighbouring lanes on one row, lane (row, 1) met lane (row - 1, 0) on the same bank pair in every access
+            // (29 % of the LDS cycles were conflict replays, profiles/r03_pmc_binding_config4_auto.json before this).
             auto rows = [&](auto shc) {
-                constexpr int SH = decltype(shc)::value, LPR = 1 << SH, TRIPS = SH == 2 ? 4 : 15;
-                const int row = lane >> SH, par = lane & (LPR - 1);
+                constexpr int SH = decltype(shc)::value, LPR = 1 << SH, TRIPS = SH == 2 ? 4 : 15, NROW = 64 >> SH;
+                const int row = lane & (NROW - 1), par = lane >> (6 - SH);
                 const bool act = row < L;
                 double* const g = G + (SH == 2 ? row4P : row2P) + (o * P + o);   // this lane's first entry of its row
                 const double* const vp = sv + par;
@@ -643,13 +655,14 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
                     }
                 }
                 p += p1;
-                p += subt_dpp<0xB1>(p);   // the partner lane(s) of the row
-                if (SH == 2) p += subt_dpp<0x4E>(p);
+                if (SH == 2) p += __shfl_xor(p, 16, 64);   // the partner lanes of the row
+                p += __shfl_xor(p, 32, 64);
                 p *= beta;
                 const double vr = act ? sv[row] : 0.0;
-                const double kk = subt_wave_sum<SH>(vr * p);   // (every lane of a row holds the row's term; vr = 0 off the block)
+                // (lanes 0 .. NROW - 1 hold one row's term each, the others copies; vr = 0 off the block)
+                const double kk = SH == 2 ? subt_row0_sum(vr * p) : subt_half_sum(vr * p);
                 const double wr = p - 0.5 * beta * kk * vr;
-                if (par == 0 && row < 32) swv[row] = wr;      // (p = vr = 0 off the block: wr = 0 there)
+                if (lane < NROW) swv[row] = wr;               // (p = vr = 0 off the block: wr = 0 there)
                 wave_sync_lds2();
                 if (act) {
 #pragma unroll
