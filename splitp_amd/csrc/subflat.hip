@@ -365,8 +365,9 @@ __global__ __launch_bounds__(SUB_WAVES * 64) void k_subscore(const void* __restr
 #endif
 #define SPK_LDS_TOTAL 163840   // LDS of a CU
 
-// Sum over the 64 lanes, returned to all of them: two quad steps and two row shifts on the DPP path (no LDS crossbar),
-// then the four row totals through scalar registers.  Fixed order.
+// Sums over lanes of a wave, returned to all of them (subt_row0_sum, subt_half_sum below): two quad steps and two row shifts
+// on the DPP path (no LDS crossbar), a row_bcast step where two DPP rows are summed, the total through scalar registers.
+// Fixed order.
 template <int CTRL, int ROWS = 0xF>
 __device__ __forceinline__ double subt_dpp(double x) {   // (rows outside the mask ROWS receive 0)
     int lo = __double2loint(x), hi = __double2hiint(x);
@@ -377,18 +378,6 @@ __device__ __forceinline__ double subt_dpp(double x) {   // (rows outside the ma
 __device__ __forceinline__ double subt_readlane(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
-// SKIP = 1: lanes 2i and 2i + 1 hold the same addend (it is counted once), SKIP = 2: all four lanes of a quad do.
-template <int SKIP = 0>
-__device__ __forceinline__ double subt_wave_sum(double x) {
-    if (SKIP < 1) x += subt_dpp<0xB1>(x);    // quad_perm [1,0,3,2]
-    if (SKIP < 2) x += subt_dpp<0x4E>(x);    // quad_perm [2,3,0,1]
-    x += subt_dpp<0x114>(x);        // row_shr:4
-    x += subt_dpp<0x118>(x);        // row_shr:8  -> lanes 12..15 of every row hold the row total
-    x += subt_dpp<0x142, 0xA>(x);   // row_bcast:15 into rows 1 and 3: lane 31 = rows 0 + 1, lane 63 = rows 2 + 3
-    x += subt_dpp<0x143, 0xC>(x);   // row_bcast:31 into rows 2 and 3: lane 63 = the total
-    return subt_readlane(x, 63);    // (8 instructions instead of the 15 of four readlanes and their sum)
-}
-
 // Per-wave LDS: de (32 pairs {d_i, e2_(i-1)}: diagonal and squared sub-diagonal of the tridiagonal matrix, one 16-byte
 // read per step of the Sturm recurrence), G (rmax rows of pitch P = rmax | 1 doubles: an odd pitch keeps a column walk off
 // one bank), v, w (32 doubles each), urow (32 x u16: row offset u * m into the staged matrix, < 61 * 61) and vcol
