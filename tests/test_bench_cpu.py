@@ -31,7 +31,7 @@ def test_gpus_flag_spawns_ranks_and_fails_loudly_without_devices():
 
 
 def test_world_size_must_match_gpus_flag():
-    r = _run(["--gpus", "1", "--no-cpu-baseline"], env_extra={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"}, timeout=60)
+    r = _run(["--gpus", "1", "--no-cpu-baseline"], env_extra={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"}, timeout=240)
     assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr
 
 
