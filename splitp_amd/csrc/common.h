@@ -17,6 +17,25 @@ typedef unsigned int u32;
 // branch on the scalar unit instead of taking a vector register and an exec-mask sequence each.
 __device__ __forceinline__ int sp_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// a / b and sqrt(x) to the last bit or two from the hardware seeds (v_rcp_f64 / v_rsq_f64, good to 2^-24) and Newton steps:
+// 8 and 7 instructions.  The IEEE forms the compiler emits for `/` and sqrt() are ~30 and ~25 (v_div_scale / v_div_fmas /
+// v_div_fixup around the same seed) - and in a 1024-thread workgroup every instruction of block-wide code costs 16 cycles,
+// in a section one wave runs alone while 15 wait at the barrier ~8.  For stop rules, conditioning estimates and start
+// scalings; b and x must be normal, finite and non-zero (callers guard with a select: the discarded NaN is harmless).
+__device__ __forceinline__ double sp_fdiv(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    y = fma(fma(-b, y, 1.0), y, y);
+    y = fma(fma(-b, y, 1.0), y, y);
+    const double q = a * y;
+    return fma(fma(-b, q, a), y, q);
+}
+__device__ __forceinline__ double sp_fsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    const double s = x * r;
+    return fma(0.5 * r, fma(-s, s, x), s);
+}
+
 void sp_set_error(const char* fmt, ...);
 
 #define SP_HIP(call)                                                                              \

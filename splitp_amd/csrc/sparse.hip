@@ -1380,7 +1380,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
         spk_chol_factor(sh);
         spk_orth(V, R, v_rs, v_cs, sh);
     } else {
-        const double nscale = 0.01 * spk_rsqrt((double)Kc / 3.0);
+        const double nscale = 0.01 * spk_rsqrt((double)Kc * (1.0 / 3.0));
         double amp[SPK_NB];
 #pragma unroll
         for (int k = 0; k < SPK_NB; ++k) amp[k] = nscale * (double)top_cnt[k];
@@ -1559,7 +1559,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
             // round 2's rule)
             constexpr bool EARLY = !GP_STABLE;
             spk_chol_factor(sh, it >= (EARLY ? 3 : 4), rest_s > 0 ? rest_s * rest_s * (1.0 / 0.3) : 0.0);
-            if (spk_converged<EARLY>(top4, sqrt(sh.L[11]), trace, it, prev_sum, prev_delta, prev_ratio)) {
+            if (spk_converged<EARLY>(top4, sh.L[11] > 0 ? sp_fsqrt(sh.L[11]) : 0.0, trace, it, prev_sum, prev_delta, prev_ratio)) {
                 conv = 1;
                 break;
             }

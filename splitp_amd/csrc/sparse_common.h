@@ -192,7 +192,7 @@ __device__ __forceinline__ void spk_chol_factor(SpkShared& sh, bool want_lam = t
         // estimate sharpened by inverse iteration.
         const double tr4 = (s00 + s11) + (s22 + s33);
         const double cheap = (d0 > tiny && d1 > tiny && d2 > tiny && d3 > tiny && tr4 > 0)
-                                 ? ((d0 * d1) * (d2 * d3)) * (27.0 / (tr4 * tr4 * tr4)) : 0.0;
+                                 ? sp_fdiv(27.0 * ((d0 * d1) * (d2 * d3)), tr4 * tr4 * tr4) : 0.0;
         double lam_min = cheap;
         if (want_lam && !(rest <= 0.3 * cheap)) {   // (uniform; only the convergence test reads it, from its 4th sum on)
             double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0, mu = 0.0;
@@ -209,7 +209,7 @@ __device__ __forceinline__ void spk_chol_factor(SpkShared& sh, bool want_lam = t
                 const double z0 = fma(-l30, z3, fma(-l20, z2, fma(-l10, z1, y0))) * i0;
                 const double xx = x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
                 const double xz = x0 * z0 + x1 * z1 + x2 * z2 + x3 * z3;      // x^T S^-1 x
-                mu = xz > 0 ? xx / xz : 0.0;                                   // Rayleigh quotient of S at x
+                mu = xz > 0 ? sp_fdiv(xx, xz) : 0.0;                                  // Rayleigh quotient of S at x
                 const double nz = spk_rsqrt(z0 * z0 + z1 * z1 + z2 * z2 + z3 * z3 + 1e-300);
                 x0 = z0 * nz; x1 = z1 * nz; x2 = z2 * nz; x3 = z3 * nz;
             }
@@ -225,16 +225,16 @@ __device__ __forceinline__ void spk_chol_factor(SpkShared& sh, bool want_lam = t
                 const double t = 0.9 * mu;
                 const double a00 = s00 - t, a11 = s11 - t, a22 = s22 - t, a33 = s33 - t;
                 bool pd = a00 > 0;
-                const double r0 = pd ? 1.0 / a00 : 0.0;
+                const double r0 = pd ? sp_fdiv(1.0, a00) : 0.0;
                 const double g10 = s10 * r0, g20 = s20 * r0, g30 = s30 * r0;
                 const double p1 = a11 - g10 * s10;
                 pd = pd && p1 > 0;
-                const double r1 = pd ? 1.0 / p1 : 0.0;
+                const double r1 = pd ? sp_fdiv(1.0, p1) : 0.0;
                 const double u21 = s21 - g20 * s10, u31 = s31 - g30 * s10;
                 const double g21 = u21 * r1, g31 = u31 * r1;
                 const double p2 = a22 - g20 * s20 - g21 * u21;
                 pd = pd && p2 > 0;
-                const double r2 = pd ? 1.0 / p2 : 0.0;
+                const double r2 = pd ? sp_fdiv(1.0, p2) : 0.0;
                 const double u32 = s32 - g30 * s20 - g31 * u21;
                 const double p3 = a33 - g30 * s30 - g31 * u31 - (u32 * r2) * u32;
                 pd = pd && p3 > 0;
@@ -242,11 +242,11 @@ __device__ __forceinline__ void spk_chol_factor(SpkShared& sh, bool want_lam = t
             }
         }
         const bool full = i0 > 0 && i1 > 0 && i2 > 0 && i3 > 0;
-        const double tinv = full ? 1.0 / lam_min : 0.0;
+        const double tinv = full ? sp_fdiv(1.0, lam_min) : 0.0;
         if (threadIdx.x == 0) {
             sh.L[0] = i0; sh.L[1] = i1; sh.L[2] = i2; sh.L[3] = i3;
             sh.L[4] = l10; sh.L[5] = l20; sh.L[6] = l30; sh.L[7] = l21; sh.L[8] = l31; sh.L[9] = l32;
-            sh.L[10] = dmax > 0 ? pmin / dmax : 1.0;
+            sh.L[10] = dmax > 0 ? sp_fdiv(pmin, dmax) : 1.0;
             sh.L[11] = full && tinv > 0 ? lam_min : 0.0;
         }
     }
@@ -311,16 +311,16 @@ __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double t
     const double delta = fabs(s4 - prev_sum);
     double ratio = 1.0;
     if (k >= 3) {   // delta_2 is the first real difference, so ratios exist from k = 3 on
-        ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
+        ratio = prev_delta > 0 ? sp_fdiv(delta, prev_delta) : 0.0;
         ratio = fmin(fmax(ratio, 0.0), 0.9999);
         if (k >= 4 || dense_g) {
             const double rest = trace - s4;                    // >= lambda_5 + lambda_6 + ...
             const double r = k >= 4 ? fmax(ratio, prev_ratio) : ratio;
-            const double tail = (k >= 4 ? 1.0 : 100.0) * delta * r / (1.0 - r);
+            const double tail = sp_fdiv((k >= 4 ? 1.0 : 100.0) * delta * r, 1.0 - r);
             const bool gap = rest <= 0.6 * lam_lb || rest <= 1e-13 * trace;
             // Tolerance on s: 1e-13 relative, tightened for tiny scores (d score = d s / (2 score trace): keep it
             // below 2e-11) down to the rounding floor of the Ritz sum (~2e-15 relative, so 4e-15 is the least asked).
-            const double sx = sqrt(fmax(rest, 0.0) * trace);   // = score * trace
+            const double sx = rest > 0 ? sp_fsqrt(rest * trace) : 0.0;   // = score * trace
             const double tol = fmax(fmin(SPK_TOL_REL * s4, 4e-11 * sx), 4e-15 * s4);
             // Measured ratios can hide a slow component of small amplitude behind fast ones (a rank-5 flattening
             // stopped 3e-8 early in the randomised tests).  No component is slower than lambda_5 / lambda_4 <= rho_b =
@@ -328,8 +328,8 @@ __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double t
             // the error left.  rest overestimates lambda_5 ~10x on real alignments, so asking the bound to meet `tol`
             // would cost every split a half product; it is asked to keep the SCORE within 5e-11 instead
             // (d s <= 1e-10 score trace), which the estimate-based stop already implies unless rho_b >> r.
-            const double rho_b = lam_lb > 0 ? fmin(rest / lam_lb, 0.9999) : 0.9999;
-            const bool bounded = delta * rho_b / (1.0 - rho_b) <= fmax(1e-10 * sx, 4e-15 * s4);
+            const double rho_b = lam_lb > 0 ? fmin(sp_fdiv(rest, lam_lb), 0.9999) : 0.9999;
+            const bool bounded = sp_fdiv(delta * rho_b, 1.0 - rho_b) <= fmax(1e-10 * sx, 4e-15 * s4);
             if (gap && bounded && ((k >= 4 && delta <= 0.2 * tol) || tail <= tol)) conv = true;
         }
     }
