@@ -48,6 +48,27 @@ __device__ __forceinline__ int spk_class(int c) {
 }
 
 #define SPK_MAXQ 20   // entries per lane whose counts pass B fetches up front when they live in global memory
+// The counts of a lane's SPK_MAXQ consecutive table entries from global memory, as five 16-byte loads (4-byte aligned:
+// global memory takes them).  As SPK_MAXQ predicated 4-byte loads - lanes 68 bytes apart, so every one of them touched 64
+// cache lines - they kept the texture addresser busy for ~15 k cycles of a list build (tools/gpu_stamps_lists.sh).  Words
+// past the lane's share, or past the table, are loaded and never used: the table's buffers carry DevBuf's slack (>= 512
+// bytes) behind their last entry, and a start beyond the table is pulled back to its end.
+typedef u32 spk_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <typename CT>
+__device__ __forceinline__ void spk_prefetch_counts(const CT* cnt, int first, int D, u32 (&cpre)[SPK_MAXQ]) {
+    static_assert(SPK_MAXQ % 4 == 0, "whole 16-byte loads");
+    if constexpr (sizeof(CT) == 4) {
+        const u32* cb = reinterpret_cast<const u32*>(cnt) + min(first, D);
+#pragma unroll
+        for (int t4 = 0; t4 < SPK_MAXQ / 4; ++t4) {
+            const spk_u32x4_a4 v = *reinterpret_cast<const spk_u32x4_a4*>(cb + 4 * t4);
+            cpre[4 * t4] = v.x; cpre[4 * t4 + 1] = v.y; cpre[4 * t4 + 2] = v.z; cpre[4 * t4 + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < SPK_MAXQ; ++t) cpre[t] = first + t < D ? (u32)cnt[first + t] : 0u;
+    }
+}
 
 // counts of the q entries lane `lane` walks in pass B (i = first + t): from the LDS / slab copy, or - plain LDS form,
 // which keeps no copy - straight from the table in global memory, all loads issued before the first use
@@ -231,13 +252,7 @@ __device__ __forceinline__ void spk_build_list(const u32* pc, const CT* cnt, int
     constexpr bool CNT_GLOBAL = !std::is_same<CT, unsigned short>::value;   // counts read from the table in global memory
     u32 cpre[SPK_MAXQ];
     const bool pre = CNT_GLOBAL && q <= SPK_MAXQ;
-    if (pre) {
-#pragma unroll
-        for (int t = 0; t < SPK_MAXQ; ++t) {
-            const int i = lo + lane * q + t;
-            cpre[t] = (t < q && i < hi) ? (u32)cnt[i] : 0u;
-        }
-    }
+    if (pre) spk_prefetch_counts(cnt, lo + lane * q, D, cpre);
     auto place = [&](int i, u32 c) {
         const u32 v = pc[i];
         const int mj = MAJOR_IS_COL ? (int)(v & 0xFFFF) : (int)(v >> 16);
@@ -328,6 +343,7 @@ __device__ __forceinline__ void spk_build_pair(const u32* pc, const CT* cnt, int
     for (int i = th; i < SPK_HALF_WAVES * stride; i += SPK_HALF_THREADS) cw[i] = 0;
     if (th < 16) bucket[th] = 0;
     __syncthreads();
+    SSTAMP(42);
     u32* const myrow = cw + wh * stride;
     for (int t = 0; t < q; ++t) {                         // pass A: per-chunk group sizes
         const int i = lo + lane * q + t;
@@ -340,14 +356,9 @@ __device__ __forceinline__ void spk_build_pair(const u32* pc, const CT* cnt, int
     constexpr bool CNT_GLOBAL = !std::is_same<CT, unsigned short>::value;
     u32 cpre[SPK_MAXQ];
     const bool pre = CNT_GLOBAL && q <= SPK_MAXQ;
-    if (pre) {
-#pragma unroll
-        for (int t = 0; t < SPK_MAXQ; ++t) {
-            const int i = lo + lane * q + t;
-            cpre[t] = (t < q && i < hi) ? (u32)cnt[i] : 0u;
-        }
-    }
+    if (pre) spk_prefetch_counts(cnt, lo + lane * q, D, cpre);
     __syncthreads();
+    SSTAMP(43);
     for (int qq = th; qq < stride; qq += SPK_HALF_THREADS) {   // exclusive prefix over the 8 chunks; totals -> ptr
         u32 run0 = 0, run1 = 0;
         u32 words[SPK_HALF_WAVES];
@@ -363,6 +374,7 @@ __device__ __forceinline__ void spk_build_pair(const u32* pc, const CT* cnt, int
         if (qq * 2 + 1 < nmajor) ptr[qq * 2 + 1] = (unsigned short)run1;
     }
     __syncthreads();
+    SSTAMP(46);
     // size classes (spk_class), largest first; wave-aggregated class counters of the half
     const int rounds = (nmajor + SPK_HALF_THREADS - 1) / SPK_HALF_THREADS;
     constexpr int KEEP = 4;
@@ -392,6 +404,7 @@ __device__ __forceinline__ void spk_build_pair(const u32* pc, const CT* cnt, int
         if (lane < SPK_NCLASS && mine) atomicAdd(&bucket[lane], mine);
     }
     __syncthreads();
+    SSTAMP(47);
     if (th == 0) {
         int* const nwave = is_col ? Lc.nwave : Lr.nwave;
         int* const nrow = is_col ? Lc.nrow : Lr.nrow;
@@ -410,6 +423,7 @@ __device__ __forceinline__ void spk_build_pair(const u32* pc, const CT* cnt, int
         *nquad -= *nwave + *nrow;
     }
     __syncthreads();
+    SSTAMP(48);
 #pragma unroll
     for (int r = 0; r < KEEP; ++r) {
         if (r >= rounds) break;
@@ -430,6 +444,7 @@ __device__ __forceinline__ void spk_build_pair(const u32* pc, const CT* cnt, int
         if (cls >= 0) perm[base + rank] = (unsigned short)m;
     }
     __syncthreads();
+    SSTAMP(49);
     {   // entry offsets in permutation order, then ptr[m] = start of group m in that layout
         const int per = (nmajor + SPK_HALF_THREADS - 1) / SPK_HALF_THREADS;
         const int l0 = min(nmajor, th * per), h0 = min(nmajor, l0 + per);
@@ -446,6 +461,7 @@ __device__ __forceinline__ void spk_build_pair(const u32* pc, const CT* cnt, int
         for (int i = th; i < nmajor; i += SPK_HALF_THREADS) ptr[perm[i]] = ptrp[i];
         __syncthreads();
     }
+    SSTAMP(52);
     auto place = [&](int i, u32 c) {                      // pass B: placement (same walk as pass A)
         const u32 v = pc[i];
         const int mj = is_col ? (int)(v & 0xFFFF) : (int)(v >> 16);
@@ -507,8 +523,7 @@ __device__ __forceinline__ void spk_group_cols(const u32* pc, const CT* cnt, int
     }
     u32 cpre[SPK_MAXQ];
     if (CNT_GLOBAL) {   // counts of this thread's first entries for pass B: issued now, used after the scans
-#pragma unroll
-        for (int t = 0; t < SPK_MAXQ; ++t) cpre[t] = (t < q && lo + t < hi) ? (u32)cnt[lo + t] : 0u;
+        spk_prefetch_counts(cnt, lo, D, cpre);
     }
     __syncthreads();
     SSTAMP(50);
@@ -595,8 +610,7 @@ __device__ __forceinline__ void spk_group_cols(const u32* pc, const CT* cnt, int
     if (CNT_GLOBAL) {
         for (int t0 = 0; t0 < q; t0 += SPK_MAXQ) {
             if (t0 > 0) {
-#pragma unroll
-                for (int t = 0; t < SPK_MAXQ; ++t) cpre[t] = (t0 + t < q && lo + t0 + t < hi) ? (u32)cnt[lo + t0 + t] : 0u;
+                spk_prefetch_counts(cnt, lo + t0, D, cpre);
             }
 #pragma unroll
             for (int t = 0; t < SPK_MAXQ; ++t)
