@@ -509,9 +509,13 @@ __device__ __forceinline__ bool spk_wide_converged(double s4, double th4, double
             // missing, amplitude ~1e-8 in the guard columns) changes nothing for dozens of half products - every test
             // above passes, bound included, with the sum 3e-6 of the score short - and then grows out of the guard columns
             // by th4 / thmin per half product.  So the rule has to hold for as many consecutive half products as that
-            // growth needs to lift an amplitude of 1e-8 into view (at most 60), restarting whenever it fails.
+            // growth needs to lift an amplitude of 1e-8 into view, restarting whenever it fails.  (Round 3: that count used to
+            // be capped at 60.  On a nearly flat spectrum - random 3-letter tables of 12 - 14 taxa, th4 / thmin = 1.02 - the
+            // growth needs hundreds of half products, the capped rule let two blocks of 230 k randomised checks through
+            // with the score 1e-3 off and status "converged" (seeds 71002 / 71004).  Uncapped, such a block runs into the
+            // half-product cap and is reported as what it is: not certified, status bit 0.)
             const double g = thmin > 0 && thmin < th4 ? log(th4 / thmin) : 0.0;
-            const int need = g > 0 ? (int)fmin(60.0, fmax(2.0, ceil(18.4 / g))) : 60;
+            const int need = g > 0 ? (int)fmin((double)SPK_MAXHALF_WIDE, fmax(2.0, ceil(18.4 / g))) : SPK_MAXHALF_WIDE;
             settled = conv ? settled + 1 : 0;
             conv = conv && settled >= need;
 #ifdef SPK_DEBUG_CONV
