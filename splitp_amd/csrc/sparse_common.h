@@ -512,10 +512,14 @@ __device__ __forceinline__ bool spk_wide_converged(double s4, double th4, double
             // growth needs to lift an amplitude of 1e-8 into view, restarting whenever it fails.  (Round 3: that count used to
             // be capped at 60.  On a nearly flat spectrum - random 3-letter tables of 12 - 14 taxa, th4 / thmin = 1.02 - the
             // growth needs hundreds of half products, the capped rule let two blocks of 230 k randomised checks through
-            // with the score 1e-3 off and status "converged" (seeds 71002 / 71004).  Uncapped, such a block runs into the
-            // half-product cap and is reported as what it is: not certified, status bit 0.)
+            // with the score 1e-3 off and status "converged" after 103 and 392 half products (seeds 71002 / 71004).  The cap
+            // is now half the block's half-product budget: a verdict reached in the first half of the budget can still be
+            // confirmed inside it - uncapped, the clustered-spectrum tables of the suite's sweep slice, whose verdicts were
+            // right, ran out of budget instead -, one reached later runs into the budget and is reported as what it is:
+            // not certified, status bit 0.)
             const double g = thmin > 0 && thmin < th4 ? log(th4 / thmin) : 0.0;
-            const int need = g > 0 ? (int)fmin((double)SPK_MAXHALF_WIDE, fmax(2.0, ceil(18.4 / g))) : SPK_MAXHALF_WIDE;
+            const int need_cap = SPK_MAXHALF_WIDE / 2;
+            const int need = g > 0 ? (int)fmin((double)need_cap, fmax(2.0, ceil(18.4 / g))) : need_cap;
             settled = conv ? settled + 1 : 0;
             conv = conv && settled >= need;
 #ifdef SPK_DEBUG_CONV
