@@ -274,8 +274,8 @@ def roofline_block(m):
         roof.update({"bound": "fp64-valu", "achieved": flops / sec / 1e12, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops / sec / 1e12 / FP64_MFMA_PEAK_TF, "algorithmic_flops_per_launch": flops,
                      "note": "one wave per split; wave-uniform scalar work (norms, reciprocals, reflector coefficients) and the "
-                             "reductions are done by all 64 lanes, so the useful-flop fraction is small by construction while the "
-                             "vector issue slots are ~75 % used (binding.valu_issue_frac) (SURVEY 8d: 'fp64 VALU / launch "
+                             "reductions are done by all 64 lanes, so the useful-flop fraction is small by construction; what the "
+                             "units do is in `binding` (vector issue, LDS, waves parked) (SURVEY 8d: 'fp64 VALU / launch "
                              "latency; report splits/s and achieved fp64 FLOP/s'); peak = the fp64 vector rate (= the fp64 "
                              "matrix rate on this part)"})
         if pmc:
