@@ -48,7 +48,7 @@ extern "C" {
 #define SP_ELIMIT 4   /* size outside what this build supports (see message) */
 #define SP_ENOCONV 5  /* eigen iteration did not converge (score still written, flagged) */
 
-#define SP_ABI_VERSION 3   /* 3: sp_score_plan_steps */
+#define SP_ABI_VERSION 4   /* 3: sp_score_plan_steps; 4: sp_finish_flagged, status bit 2 (direct solver) */
 
 typedef struct sp_ctx sp_ctx;             /* device + stream + workspace arena */
 typedef struct sp_alignment sp_alignment; /* device-resident pattern table */
@@ -189,12 +189,13 @@ int sp_divergence_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, int64_t
  *                             (flattening + flattening_rank_1_approximation_divergence instead of split_score)
  *   scores_host               may be NULL; if given, the stream is synchronised
  *   scores_dev                may be NULL; device buffer of n_splits doubles
- *   status_host               may be NULL; per-split flags (bit 0: eigen iteration hit its cap - the score is then
- *                             an upper estimate; bits 8..: number of operator applications).
+ *   status_host               may be NULL; per-split flags (bit 0: no certificate - the score is then an upper
+ *                             estimate; bit 2: scored by the direct solver; bits 8..: number of operator
+ *                             applications, or the rows of the solved Gram matrix when bit 2 is set).
  * Hand-back chain of SP_METHOD_FLATTENING on a count table (every stage bit-reproducible): in-LDS kernel -> the same
  * kernel with its entry lists in global memory -> with all arrays in global memory (tables beyond ~9 k patterns) ->
- * for a split whose 4-wide block finds no certified spectral gap in 40 half products: the dense route (smaller side
- * <= 1024 rows) or the kernel's 8-wide fallback block (larger sides, 12+ taxa).
+ * for a split whose 4-wide block finds no certified spectral gap in 40 half products: the kernel's 8-wide block, which
+ * certifies (gap behind the 8th value) or flags -> flagged splits: the direct solver (sp_finish_flagged, run here).
  * Tables with more than 65535 patterns and float-weight tables: the dense route up to 11 taxa, from 12 taxa on the
  * big-table form of the sparse route (segmented sorts + global-memory products, same block iteration and stop rule). */
 #define SP_METHOD_FLATTENING 0
@@ -259,8 +260,8 @@ int sp_plan_info(const sp_plan* plan, int* n_taxa, int64_t* n_splits);
  * The whole hand-back chain runs on the device: behind the in-LDS kernel a second kernel of persistent workgroups
  * picks - from the status words the first one left - the splits that did not fit (re-run in the lists-in-global form,
  * then the all-global form) and those whose 4-wide block found no certified spectral gap (8-wide block).  On completion
- * of the stream work every score is final: status bit 0 = the last resort hit its iteration cap (score = upper
- * estimate), bits 8.. = operator applications, bit 1 never set.  scores_dev / status_dev: n_al * n_splits entries,
+ * of the stream work every score is certified or flagged: status bit 0 = no certificate (score = upper estimate; finish
+ * it with sp_finish_flagged), bits 8.. = operator applications, bit 1 never set.  scores_dev / status_dev: n_al * n_splits entries,
  * alignment-major.  The first call for an alignment prepares its split-independent metadata (synchronously, once). */
 int sp_score_plan_async(sp_ctx* lane, sp_alignment* const* als, int n_al, sp_plan* plan, void* scores_dev,
                         void* status_dev);
@@ -273,6 +274,21 @@ int sp_score_plan_async(sp_ctx* lane, sp_alignment* const* als, int n_al, sp_pla
  * trip per pass: two kernel launches of host time per pass.  Same argument checks and errors as sp_score_plan_async. */
 int sp_score_plan_steps(sp_ctx* lane, sp_alignment* const* als, int n_al, sp_plan* plan, int n_steps, void* scores_dev,
                         int64_t scores_step_bytes, void* status_dev, int64_t status_step_bytes);
+
+/* ---------------------------------------------------------------- direct solver (ABI 4) --- */
+/* The iterative routes CERTIFY a score (a spectral gap behind the block bounds what the Ritz sum still lacks) or FLAG it
+ * (status bit 0: an upper estimate).  Flagged splits are finished by a direct method - fp64 Gram matrix over the split's
+ * smaller side, Householder tridiagonalisation, Sturm-count multisection: no start vector, no stop rule, the counterpart of
+ * the LAPACK gesdd call the reference's dense path makes for EVERY matrix (phylogenetics.py:281-285).  The synchronous
+ * entry points (sp_score_splits, sp_score_all_splits[_shard], sp_score_matrix_f64, sp_score_coo_f64) run it themselves;
+ * this is the host step behind the asynchronous ones: scores_host / status_host are the fetched results of a pass over
+ * (al, the n_splits splits); every split whose status word has bit 0 or bit 1 set is re-scored and both arrays are patched
+ * in place.  A finished split's status word: bit 2 set, bits 0 / 1 clear, bits 8.. = rows of the solved Gram matrix.
+ * Limits: smaller side of at most `direct_max_rows` compact rows (context option, default 16384: 2 GB of Gram matrix, ~10 s)
+ * and sides of at most 14 taxa; a split beyond them keeps its flagged estimate.  n_finished: may be NULL.
+ * Context option `direct_finish` = 0 switches the finisher off everywhere (flagged splits then surface as SP_ENOCONV). */
+int sp_finish_flagged(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
+                      double* scores_host, int32_t* status_host, int64_t* n_finished);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ SP_METHOD_MUTUAL_INFORMATION = 4
 SP_N_PHASES = 11
 PHASE_NAMES = ("reindex", "scatter", "gram", "eigen", "moment", "subscore", "hist", "dense", "sparse", "divergence", "chain")
 SP_OK, SP_EINVAL, SP_EHIP, SP_ENOMEM, SP_ELIMIT, SP_ENOCONV = 0, 1, 2, 3, 4, 5
-SP_ABI_VERSION = 3
+SP_ABI_VERSION = 4
 
 # every symbol include/splitp_hip.h declares
 SYMBOLS = (
@@ -37,6 +37,7 @@ SYMBOLS = (
     "sp_score_matrix_f64", "sp_score_coo_f64", "sp_divergence_matrix_f64", "sp_score_splits", "sp_score_splits_async",
     "sp_score_splits_multi_async", "sp_score_all_splits", "sp_score_all_splits_shard",
     "sp_plan_create", "sp_plan_retain", "sp_plan_release", "sp_plan_info", "sp_score_plan_async", "sp_score_plan_steps",
+    "sp_finish_flagged",
 )
 
 
@@ -130,6 +131,7 @@ def load():
         "sp_plan_info": [vp, P(i32), P(i64)],
         "sp_score_plan_async": [vp, P(vp), i32, vp, vp, vp],
         "sp_score_plan_steps": [vp, P(vp), i32, vp, i32, vp, i64, vp, i64],
+        "sp_finish_flagged": [vp, P(C.c_int32), P(C.c_int32), i64, P(dbl), P(C.c_int32), P(i64)],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

@@ -210,16 +210,27 @@ def score_encoded_multi_async(als, split_taxa, split_a, scores_dev_ptr, status_d
 
 
 def finish_async(al, split_taxa, split_a, scores_host, status_host):
-    """Second opinion for the asynchronous form: the device chain leaves no status bit 1 behind, but its last resort (the
-    8-wide block) can hit its cap on gapless spectra (status bit 0: upper estimate).  Such splits are re-scored with the
-    synchronous entry point, whose hand-back also has the dense route's 16-wide block for sides of up to 1024 rows.
-    scores_host / status_host are NumPy views of the fetched results, patched in place; returns how many were redone."""
-    redo = np.nonzero(np.asarray(status_host) & 3)[0]
-    if len(redo):
-        sc, st = score_encoded(al, split_taxa[redo], split_a[redo], _lib.SP_METHOD_FLATTENING)
-        scores_host[redo] = sc
-        status_host[redo] = st
-    return len(redo)
+    """Host step behind the asynchronous form: the device chain certifies a score or flags it (status bit 0: the 8-wide
+    block found no certificate - a spectrum without a gap behind its 4th value).  Flagged splits are re-scored by the
+    library's direct solver (sp_finish_flagged: Householder tridiagonalisation + Sturm counts on the split's Gram matrix,
+    no stop rule) and patched in place; their status word then has bit 2 set and bits 0 / 1 clear.
+    scores_host / status_host are NumPy arrays of the fetched results; returns how many splits were finished."""
+    status_host = np.asarray(status_host)
+    if not np.any(status_host & 3):
+        return 0
+    sc = np.ascontiguousarray(scores_host, dtype=np.float64)
+    st = np.ascontiguousarray(status_host, dtype=np.int32)
+    split_taxa = np.ascontiguousarray(split_taxa, dtype=np.int32)
+    split_a = np.ascontiguousarray(split_a, dtype=np.int32)
+    done = C.c_int64(0)
+    _lib.check(al.ctx._lib.sp_finish_flagged(al.handle, _lib._ptr(split_taxa, C.c_int32), _lib._ptr(split_a, C.c_int32),
+                                             len(split_a), _lib._ptr(sc, C.c_double), _lib._ptr(st, C.c_int32),
+                                             C.byref(done)))
+    if sc is not scores_host:
+        scores_host[...] = sc
+    if st is not status_host:
+        status_host[...] = st
+    return int(done.value)
 
 
 def _send_buffer(width):

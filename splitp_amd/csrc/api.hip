@@ -132,6 +132,8 @@ extern "C" int sp_ctx_create(int device, void* stream, sp_ctx** out) {
     c->opt.eigen_one_stream = env_flag("SPLITP_EIGEN_ONE_STREAM");
     if (const char* hs = getenv("SPLITP_HIST_SORT")) c->opt.hist_sort = hs[0] == '1' ? 1 : (hs[0] == '0' ? 0 : -1);
     if (const char* lc = getenv("SPLITP_DEBUG_LDS_CAP")) c->opt.lds_cap = atoll(lc);
+    if (const char* df = getenv("SPLITP_DIRECT_FINISH")) c->opt.direct_finish = df[0] != '0';
+    c->opt.direct_all = env_flag("SPLITP_DIRECT_ALL");
     *out = c;
     return SP_OK;
     });
@@ -148,6 +150,9 @@ static long long* option_slot(sp_ctx* c, const char* name, int** as_int) {
     else if (!strcmp(name, "wide_cap")) *as_int = &c->opt.wide_cap;
     else if (!strcmp(name, "gram_tile64")) *as_int = &c->opt.gram_tile64;
     else if (!strcmp(name, "eigen_one_stream")) *as_int = &c->opt.eigen_one_stream;
+    else if (!strcmp(name, "direct_finish")) *as_int = &c->opt.direct_finish;
+    else if (!strcmp(name, "direct_max_rows")) *as_int = &c->opt.direct_max_rows;
+    else if (!strcmp(name, "direct_all")) *as_int = &c->opt.direct_all;
     else if (!strcmp(name, "lds_cap")) return &c->opt.lds_cap;
     return nullptr;
 }
@@ -657,6 +662,16 @@ static int run_dense_route(sp_alignment* al, const Plan& plan, bool plan_on_devi
         SP_CHECK(launch_gram<double>(ctx, sdev, ctx->gram_items.as<GramItem>(), (int64_t)plan.gram_items.size(), dims,
                                      ctx->mats.as<double>(), ctx->grams.as<double>()));
     }
+    if (ctx->opt.direct_all && !g_i32) {   // test switch: every split through the direct solver (fp64 G: the caller planned nl = 0)
+        std::vector<int2> hd(S);
+        SP_HIP(hipMemcpyAsync(hd.data(), dims, S * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(hipStreamSynchronize(ctx->stream));
+        int mmax = 0;
+        for (size_t k = 0; k < S; ++k) mmax = std::max(mmax, std::min<int>(hd[k].x, plan.splits[k].rcap));
+        SP_CHECK(ctx->eigws.ensure(direct_ws_doubles((int64_t)S, mmax) * 8));
+        return launch_direct_top4(ctx, sdev, dims, (int64_t)S, mmax, ctx->grams.as<double>(), ctx->eigws.as<double>(), nullptr,
+                                  ctx->scores.as<double>(), ctx->status.as<int>());
+    }
     SP_CHECK(launch_eigen(ctx, sdev, plan.splits, dims, ctx->grams.p, g_i32,
                           ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
                           reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
@@ -665,14 +680,31 @@ static int run_dense_route(sp_alignment* al, const Plan& plan, bool plan_on_devi
     return SP_OK;
 }
 
-__global__ void k_patch_scores(const int* __restrict__ idx, int n, const double* __restrict__ src,
-                               const int* __restrict__ src_status, double* __restrict__ dst,
-                               int* __restrict__ dst_status) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        dst[idx[i]] = src[i];
-        dst_status[idx[i]] = src_status[i];
+// One generic matrix whose fp64 Gram matrix is in ctx->grams (plan.splits[0], dims on the device): the block iteration
+// where it fits the eigen kernels (smaller side <= EIG_MAXR rows) and certifies its sum, the direct solver otherwise -
+// a matrix without a spectral gap behind its 4th singular value, or with a longer smaller side (up to direct_max_rows).
+static int score_single_gram(sp_ctx* ctx, const Plan& plan, int64_t R) {
+    const int64_t max_rows = ctx->opt.direct_max_rows > 0 ? ctx->opt.direct_max_rows : 16384;
+    bool direct = ctx->opt.direct_all != 0 || plan.splits[0].rcap > EIG_MAXR;
+    SP_REQUIRE(!direct || R <= max_rows, SP_ELIMIT,
+               "matrix with a smaller side of %lld rows: the eigen kernels hold %d rows in LDS, the direct solver takes %lld",
+               (long long)R, EIG_MAXR, (long long)max_rows);
+    if (!direct) {
+        SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.p, false,
+                              ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
+                              reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
+                                                           plan.row_items.size()),
+                              ctx->scores.as<double>(), ctx->status.as<int>(), (int64_t)plan.n_row_a, (int64_t)plan.n_order_a));
+        if (!ctx->opt.direct_finish) return SP_OK;
+        int st = 0;
+        SP_HIP(hipMemcpyAsync(&st, ctx->status.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(hipStreamSynchronize(ctx->stream));
+        if (!(st & 3)) return SP_OK;
+        direct = true;   // (the eigen kernels only read G)
     }
+    SP_CHECK(ctx->eigws.ensure(direct_ws_doubles(1, R) * 8));
+    return launch_direct_top4(ctx, ctx->splits.as<SplitDev>(), ctx->dims.as<int2>(), 1, (int)R, ctx->grams.as<double>(),
+                              ctx->eigws.as<double>(), nullptr, ctx->scores.as<double>(), ctx->status.as<int>());
 }
 
 // Rows of the table the sparse kernel sees: D, plus one row per further 65535 of every count >= 2^16 (common.h).  The
@@ -929,93 +961,117 @@ static int cached_sparse_plan(sp_ctx* ctx, int n, const int32_t* split_taxa, con
     return SP_OK;
 }
 
-// Host step of the synchronous sparse route, after the device chain has run and its status words `st` are on the host:
-// splits whose 4-wide block found no certified gap and whose smaller side fits the dense route's 1024 rows are re-scored
-// there and patched into ctx->scores / ctx->status.
-static int sparse_handback(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S,
-                           std::vector<int>& st, bool strict) {
+// ------------------------------------------------------------------ direct finisher -----------
+// Splits the iterative routes could not certify (status bit 0: budget spent or given up; bit 1: handed back) are scored
+// by the direct solver (finish.hip): compact matrix of the split -> fp64 Gram over its smaller side -> Householder
+// tridiagonalisation + Sturm multisection.  Host-driven (2 m launches, dims fetched once per chunk); the chunks keep the
+// compact matrices + Gram matrices of one batch under ~24 GB.  Splits whose smaller side has more compact rows than
+// `direct_max_rows` (default 16384: 2 GB of G, ~23 TB of traffic - about 10 s) or a side of more than 14 taxa (bitmap
+// compaction) keep their flagged estimate.  scores_dev / status_dev: the S-entry device arrays to patch; st: their
+// host copy (patched too).  Returns the number of splits finished in *n_done.
+static int finish_flagged(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S, std::vector<int>& st,
+                          double* scores_dev, int* status_dev, int64_t* n_done) {
     sp_ctx* ctx = al->ctx;
     const int n = al->n_taxa;
-    std::vector<int> redo;
-    for (int64_t i = 0; i < S; ++i)
-        if (st[i] & 2) redo.push_back((int)i);
-    if (redo.empty()) return SP_OK;
-    SP_REQUIRE(!strict, SP_ELIMIT,
-               "sparse route: %zu of %lld splits are left to the dense route (first: split %d, status 0x%x: %s)",
-               redo.size(), (long long)S, redo[0], st[redo[0]],
-               (st[redo[0]] >> 8) ? "no convergence with the 4-wide block" : "does not fit any form of the kernel");
-    // dense route on the handed-back subset (overwrites the context pools, hence the parking buffers)
-    std::vector<int32_t> t2(redo.size() * (size_t)n), a2(redo.size());
-    for (size_t k = 0; k < redo.size(); ++k) {
-        memcpy(&t2[k * n], split_taxa + (size_t)redo[k] * n, (size_t)n * 4);
-        a2[k] = split_a[redo[k]];
+    const int64_t D = al->D;
+    if (n_done) *n_done = 0;
+    if (!ctx->opt.direct_finish || D == 0) return SP_OK;
+    const int64_t max_rows = ctx->opt.direct_max_rows > 0 ? ctx->opt.direct_max_rows : 16384;
+    const size_t elt = al->exact ? 4 : 8;
+    struct Cand { int idx; int64_t rcap, pitch; };
+    std::vector<Cand> cand;
+    for (int64_t i = 0; i < S; ++i) {
+        if (!(st[i] & 3)) continue;
+        const int a = split_a[i], b = n - a;
+        if (a < 1 || b < 1 || std::max(a, b) > 14) continue;
+        const int64_t rmax = std::min<int64_t>(pow4(std::min(a, b)), D), cmax = std::min<int64_t>(pow4(std::max(a, b)), D);
+        if (rmax > max_rows) continue;
+        cand.push_back({(int)i, round_up(rmax, 64), round_up(cmax, 32)});
     }
-    DevBuf keep_scores, keep_status, idx;
-    int rc = SP_OK;
-    auto bail = [&](int code) {
-        keep_scores.release(); keep_status.release(); idx.release();
-        return code;
-    };
-    if ((rc = keep_scores.ensure((size_t)S * 8)) || (rc = keep_status.ensure((size_t)S * 4)) ||
-        (rc = idx.ensure(redo.size() * 4)))
-        return bail(rc);
-    if (hipMemcpyAsync(keep_scores.p, ctx->scores.p, (size_t)S * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(keep_status.p, ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(idx.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-        sp_set_error("sparse route hand-back: device copy failed");
-        return bail(SP_EHIP);
-    }
-    Plan sub;
-    const int nl = limbs_for(al);
-    PlanCache tmp_pc;
-    tmp_pc.nl = nl;
-    PlanCache* saved = ctx->cache;
-    ctx->cache = &tmp_pc;  // run_dense_route reads the limb count from the context's cache slot
-    rc = plan_splits(n, al->D, t2.data(), a2.data(), (int64_t)redo.size(), true, true, true, sub, nl > 0 ? nl : 0);
-    if (rc == SP_OK) rc = run_dense_route(al, sub, false);
-    ctx->cache = saved;
-    if (ctx->cache) ctx->cache->valid = false;  // the dense route's pools were re-planned
-    if (rc == SP_ELIMIT) {
-        // The dense route cannot take this shape.  Splits the sparse kernel iterated on keep its last Ritz estimate (an
-        // upper estimate of the score), flagged with status bit 0 = "iteration cap hit, not certified"; a split that
-        // never ran has nothing to keep.
-        for (int i : redo)
-            if ((st[i] >> 8) == 0) return bail(rc);
-        for (int i : redo) st[i] = (st[i] & ~2) | 1;
-        if (hipMemcpyAsync(ctx->scores.p, keep_scores.p, (size_t)S * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(ctx->status.p, st.data(), (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            sp_set_error("sparse route hand-back: restoring the estimates failed");
-            return bail(SP_EHIP);
+    if (cand.empty()) return SP_OK;
+    if (ctx->cache) ctx->cache->valid = false;   // the plan pools are overwritten
+    const size_t budget = (size_t)24 << 30;
+    size_t pos = 0;
+    int64_t done = 0;
+    while (pos < cand.size()) {
+        size_t end = pos, bytes = 0;
+        while (end < cand.size() && end - pos < 4096) {
+            const size_t need = (size_t)cand[end].rcap * cand[end].pitch * elt + (size_t)cand[end].rcap * cand[end].rcap * 8;
+            if (end > pos && bytes + need > budget) break;
+            bytes += need;
+            ++end;
         }
-        return bail(SP_OK);
+        const int64_t cnt = (int64_t)(end - pos);
+        std::vector<int32_t> t2((size_t)cnt * n), a2((size_t)cnt);
+        std::vector<int> idx((size_t)cnt);
+        for (int64_t k = 0; k < cnt; ++k) {
+            const int i = cand[pos + k].idx;
+            memcpy(&t2[(size_t)k * n], split_taxa + (size_t)i * n, (size_t)n * 4);
+            a2[k] = split_a[i];
+            idx[k] = i;
+        }
+        Plan plan;
+        SP_CHECK(plan_splits(n, D, t2.data(), a2.data(), cnt, true, true, true, plan, 0));
+        SP_CHECK(upload_plan(ctx, plan, D));
+        SP_CHECK(ctx->grams.ensure(plan.g_elems * 8));
+        SP_CHECK(ctx->mats.ensure(plan.mat_elems * elt));
+        SP_CHECK(ctx->misc2.ensure((size_t)cnt * 4));
+        const SplitDev* sdev = ctx->splits.as<SplitDev>();
+        int2* dims = ctx->dims.as<int2>();
+        SP_HIP(hipMemcpyAsync(ctx->misc2.p, idx.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, ctx->stream));
+        SP_CHECK(launch_reindex(ctx, al->keys.as<u64>(), D, n, sdev, plan.splits, bm_ptr(ctx), pf_ptr(ctx, plan), dims,
+                                rr_ptr(ctx), cc_ptr(ctx, (size_t)cnt, D)));
+        if (al->exact) {
+            SP_CHECK(launch_zero_scatter<u32>(ctx, sdev, plan.splits, D, dims, rr_ptr(ctx), cc_ptr(ctx, (size_t)cnt, D),
+                                              al->counts.as<u32>(), ctx->mats.as<u32>()));
+            SP_CHECK(launch_gram<u32>(ctx, sdev, ctx->gram_items.as<GramItem>(), (int64_t)plan.gram_items.size(), dims,
+                                      ctx->mats.as<u32>(), ctx->grams.as<double>()));
+        } else {
+            SP_CHECK(launch_zero_scatter<double>(ctx, sdev, plan.splits, D, dims, rr_ptr(ctx), cc_ptr(ctx, (size_t)cnt, D),
+                                                 al->weights.as<double>(), ctx->mats.as<double>()));
+            SP_CHECK(launch_gram<double>(ctx, sdev, ctx->gram_items.as<GramItem>(), (int64_t)plan.gram_items.size(), dims,
+                                         ctx->mats.as<double>(), ctx->grams.as<double>()));
+        }
+        std::vector<int2> hd((size_t)cnt);
+        SP_HIP(hipMemcpyAsync(hd.data(), dims, (size_t)cnt * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(hipStreamSynchronize(ctx->stream));   // (idx / t2 / a2 die with this iteration)
+        int mmax = 0;
+        for (int64_t k = 0; k < cnt; ++k) mmax = std::max(mmax, std::min<int>(hd[k].x, plan.splits[k].rcap));
+        SP_CHECK(ctx->eigws.ensure(direct_ws_doubles(cnt, mmax) * 8));
+        SP_CHECK(launch_direct_top4(ctx, sdev, dims, cnt, mmax, ctx->grams.as<double>(), ctx->eigws.as<double>(),
+                                    ctx->misc2.as<int>(), scores_dev, status_dev));
+        SP_HIP(hipStreamSynchronize(ctx->stream));
+        for (int64_t k = 0; k < cnt; ++k) st[idx[k]] = 4 | (std::min<int>(hd[k].x, 0x7FFFFF) << 8);
+        done += cnt;
+        pos = end;
     }
-    if (rc != SP_OK) return bail(rc);
-    hipLaunchKernelGGL(k_patch_scores, dim3((unsigned)((redo.size() + 255) / 256)), dim3(256), 0, ctx->stream,
-                       idx.as<int>(), (int)redo.size(), ctx->scores.as<double>(), ctx->status.as<int>(),
-                       keep_scores.as<double>(), keep_status.as<int>());
-    if (hipMemcpyAsync(ctx->scores.p, keep_scores.p, (size_t)S * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(ctx->status.p, keep_status.p, (size_t)S * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        sp_set_error("sparse route hand-back: patch failed");
-        return bail(SP_EHIP);
-    }
-    return bail(SP_OK);
+    if (n_done) *n_done = done;
+    return SP_OK;
+}
+
+// After any flattening route has left its scores / status words in the context's buffers: fetch the status words and, if
+// any split is flagged, finish it with the direct solver (patching ctx->scores / ctx->status).
+static int finish_context_results(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S) {
+    sp_ctx* ctx = al->ctx;
+    if (!ctx->opt.direct_finish || S == 0) return SP_OK;
+    std::vector<int> st((size_t)S);
+    SP_HIP(hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    bool any = false;
+    for (int v : st) any |= (v & 3) != 0;
+    if (!any) return SP_OK;
+    return finish_flagged(al, split_taxa, split_a, S, st, ctx->scores.as<double>(), ctx->status.as<int>(), nullptr);
 }
 
 // Synchronous sparse route: the device chain (in-LDS kernel -> lists in global memory -> all arrays in global memory ->
-// 8-wide fallback block for sides beyond the dense route), then - the only host step - sparse_handback.
-static int run_sparse_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S, bool strict) {
+// 8-wide fallback block); whatever leaves it flagged is the direct solver's (finish_context_results, at the caller).
+static int run_sparse_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S) {
     sp_ctx* ctx = al->ctx;
     sp_plan* plan = nullptr;
     SP_CHECK(cached_sparse_plan(ctx, al->n_taxa, split_taxa, split_a, S, &plan));
     SP_CHECK(ctx->scores.ensure((size_t)S * 8));
     SP_CHECK(ctx->status.ensure((size_t)S * 4));
-    SP_CHECK(enqueue_sparse_plan(ctx, &al, 1, plan, ctx->scores.as<double>(), ctx->status.as<int>(), false));
-    std::vector<int> st((size_t)S);
-    SP_HIP(hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SP_HIP(hipStreamSynchronize(ctx->stream));
-    return sparse_handback(al, split_taxa, split_a, S, st, strict);
+    return enqueue_sparse_plan(ctx, &al, 1, plan, ctx->scores.as<double>(), ctx->status.as<int>(), true);
 }
 
 // ---- every split of the taxa, flattening + score, planned on the device ---------------------------------------------
@@ -1117,15 +1173,16 @@ static int run_flat_all_splits(sp_alignment* al, int method, int trivial, int si
     SP_CHECK(aldescs_for(ctx, als1, 1, &descs));
     SP_CHECK(launch_sparse_chain(ctx, descs, host_aldesc(al), 1, n, ctx->splits.as<SplitDev>(),
                                  ctx->splits_launch.as<SplitDev>(), total, ctx->scores.as<double>(), ctx->status.as<int>(),
-                                 srows, bmw, false));
+                                 srows, bmw, true));
+    if (!ctx->opt.direct_finish) return SP_OK;
     std::vector<int> st((size_t)total);
     SP_HIP(hipMemcpyAsync(st.data(), ctx->status.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     bool any = false;
-    for (int v : st) any |= (v & 2) != 0;
+    for (int v : st) any |= (v & 3) != 0;
     if (!any) return SP_OK;
-    SP_CHECK(fetch_list());
-    return sparse_handback(al, h_taxa.data(), h_a.data(), total, st, method == SP_METHOD_FLATTENING_SPARSE);
+    SP_CHECK(fetch_list());   // (rare: the split list crosses the boundary only when the direct solver is needed)
+    return finish_flagged(al, h_taxa.data(), h_a.data(), total, st, ctx->scores.as<double>(), ctx->status.as<int>(), nullptr);
 }
 
 int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S);  // subflat.hip
@@ -1231,12 +1288,12 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
         const bool use_sparse = method == SP_METHOD_FLATTENING_SPARSE ||
                                 (method == SP_METHOD_FLATTENING && sparse_ok && ctx->gram_mode == 0);
         if (use_sparse) {
-            SP_CHECK(run_sparse_route(al, split_taxa, split_a, n_splits, method == SP_METHOD_FLATTENING_SPARSE));
+            SP_CHECK(run_sparse_route(al, split_taxa, split_a, n_splits));
         } else {
             if (!ctx->cache) ctx->cache = new PlanCache();
             PlanCache& pc = *ctx->cache;
             const size_t nt = (size_t)n_splits * al->n_taxa;
-            const int nl = limbs_for(al);
+            const int nl = ctx->opt.direct_all ? 0 : limbs_for(al);   // (the direct solver reads an fp64 G)
             const bool hit = pc.valid && pc.nl == nl && pc.n == al->n_taxa && pc.D == al->D &&
                              pc.a.size() == (size_t)n_splits &&
                              memcmp(pc.a.data(), split_a, n_splits * 4) == 0 &&
@@ -1262,6 +1319,9 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
         sp_set_error("unknown method %d", method);
         return SP_EINVAL;
     }
+    // whatever an iterative flattening route could not certify goes to the direct solver (status bit 2 afterwards)
+    if (method == SP_METHOD_FLATTENING || method == SP_METHOD_FLATTENING_DENSE || method == SP_METHOD_FLATTENING_SPARSE)
+        SP_CHECK(finish_context_results(al, split_taxa, split_a, n_splits));
     if (scores_dev)
         SP_HIP(hipMemcpyAsync(scores_dev, ctx->scores.p, n_splits * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (scores_host)
@@ -1287,6 +1347,39 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
             return SP_ENOCONV;
         }
     }
+    return SP_OK;
+    });
+}
+
+// ABI 4: the host step behind the asynchronous entry points.  scores_host / status_host hold the fetched results of an
+// asynchronous pass over (al, these splits); every split whose status word has bit 0 or bit 1 set is re-scored by the
+// direct solver and patched in place (status then: bit 2 set, bits 8.. = rows of the solved Gram matrix).
+extern "C" int sp_finish_flagged(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
+                                 double* scores_host, int32_t* status_host, int64_t* n_finished) {
+    return sp_guard("sp_finish_flagged", [&]() -> int {
+    SP_REQUIRE(al && split_taxa && split_a && scores_host && status_host, SP_EINVAL, "NULL argument");
+    SP_REQUIRE(n_splits >= 0, SP_EINVAL, "n_splits < 0");
+    if (n_finished) *n_finished = 0;
+    sp_ctx* ctx = al->ctx;
+    SP_HIP(hipSetDevice(ctx->device));
+    std::vector<int> st(status_host, status_host + n_splits);
+    bool any = false;
+    for (int v : st) any |= (v & 3) != 0;
+    if (!any) return SP_OK;
+    for (int64_t s = 0; s < n_splits; ++s)
+        if (st[s] & 3)
+            SP_CHECK(check_split(al->n_taxa, split_taxa + s * al->n_taxa, split_a[s], split_taxa + s * al->n_taxa + split_a[s],
+                                 al->n_taxa - split_a[s]));
+    SP_CHECK(ctx->scores.ensure((size_t)n_splits * 8));
+    SP_CHECK(ctx->status.ensure((size_t)n_splits * 4));
+    SP_HIP(hipMemcpyAsync(ctx->scores.p, scores_host, (size_t)n_splits * 8, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipMemcpyAsync(ctx->status.p, status_host, (size_t)n_splits * 4, hipMemcpyHostToDevice, ctx->stream));
+    int64_t done = 0;
+    SP_CHECK(finish_flagged(al, split_taxa, split_a, n_splits, st, ctx->scores.as<double>(), ctx->status.as<int>(), &done));
+    SP_HIP(hipMemcpyAsync(scores_host, ctx->scores.p, (size_t)n_splits * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipMemcpyAsync(status_host, ctx->status.p, (size_t)n_splits * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_finished) *n_finished = done;
     return SP_OK;
     });
 }
@@ -1404,11 +1497,7 @@ extern "C" int sp_score_matrix_f64(sp_ctx* ctx, const double* m, int64_t rows, i
     SP_CHECK(launch_gram<double>(ctx, ctx->splits.as<SplitDev>(), ctx->gram_items.as<GramItem>(),
                                  (int64_t)plan.gram_items.size(), ctx->dims.as<int2>(), ctx->mats.as<double>(),
                                  ctx->grams.as<double>()));
-    SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.p, false,
-                          ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
-                          reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
-                                                       plan.row_items.size()),
-                          ctx->scores.as<double>(), ctx->status.as<int>(), (int64_t)plan.n_row_a, (int64_t)plan.n_order_a));
+    SP_CHECK(score_single_gram(ctx, plan, R));
     SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;
@@ -1496,11 +1585,7 @@ extern "C" int sp_score_coo_f64(sp_ctx* ctx, const int64_t* ri, const int64_t* c
     SP_CHECK(launch_gram<double>(ctx, ctx->splits.as<SplitDev>(), ctx->gram_items.as<GramItem>(),
                                  (int64_t)plan.gram_items.size(), ctx->dims.as<int2>(), ctx->mats.as<double>(),
                                  ctx->grams.as<double>()));
-    SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.p, false,
-                          ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
-                          reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
-                                                       plan.row_items.size()),
-                          ctx->scores.as<double>(), ctx->status.as<int>(), (int64_t)plan.n_row_a, (int64_t)plan.n_order_a));
+    SP_CHECK(score_single_gram(ctx, plan, R));
     SP_HIP(hipMemcpyAsync(score, ctx->scores.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     SP_HIP(hipStreamSynchronize(ctx->stream));
     return SP_OK;

@@ -129,6 +129,9 @@ struct CtxOptions {
     int gram_tile64 = 0;        // int8 Gram of the dense route on the 64 x 64-tile kernel instead of 128 x 128
     int eigen_one_stream = 0;   // dense route's eigen phase on the context's stream only (no side stream for the short sides)
     long long lds_cap = 0;      // pretend the LDS is this small (plain LDS form of the sparse kernel)
+    int direct_finish = 1;      // flagged splits (status bit 0 / 1) end in the direct solver (finish.hip); 0: they stay flagged (SP_ENOCONV)
+    int direct_max_rows = 0;    // largest smaller side (compact rows) the direct solver takes (0 = 16384)
+    int direct_all = 0;         // dense route / generic matrices: the direct solver instead of the block iteration (test switch)
 };
 
 struct sp_ctx {
@@ -324,6 +327,9 @@ template <typename T>
 int launch_gram(sp_ctx* ctx, const SplitDev* splits_dev, const GramItem* items_dev, int64_t n_items, const int2* dims,
                 const T* mats, double* grams);
 void build_gram_items(Plan& plan);
+size_t direct_ws_doubles(int64_t n_mats, int64_t max_rows);   // finish.hip
+int launch_direct_top4(sp_ctx* ctx, const SplitDev* splits_dev, const int2* dims_dev, int64_t n_mats, int max_rows,
+                       double* grams, double* ws_dev, const int* out_idx_dev, double* scores, int* status);
 int launch_eigen(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits, const int2* dims,
                  const void* grams, bool g_i32, const GramItem* rowblocks_dev, int64_t n_rowblocks,
                  const int* order_dev, double* scores, int* status, int64_t n_rowblocks_a = -1, int64_t n_splits_a = -1);

@@ -1380,7 +1380,7 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
     // been formed (no eigen-decomposition, no polar factor).  Small row side: dense G instead of the two sparse halves.
     // Start: unit vectors on the 4 rows picked above.  General path: C^T of unit vectors is just those 4 rows of C, so
     // the first half product is a scatter of 4 CSR rows into W (plus 1 % hash noise for the directions they miss).
-    double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0, prev_th5 = 0, prev_d5 = 0;
+    double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0, prev_th5 = 0, prev_d5 = 0, prev_sum8 = 0;
     int wide_settled = 0;
     int it = 0, conv = 0;
     if (small) {
@@ -1599,8 +1599,10 @@ __device__ __forceinline__ int spk_score_one(unsigned char* __restrict__ smem, c
                 double th4, sum8;
                 double th5, thmin;
                 spk_wide_ritz_orth(X, rows, xcs, esh, top4, th4, sum8, &th5, &thmin);
-                if (spk_wide_converged(top4, th4, sum8, trace, it - 1, prev_sum, prev_delta, prev_ratio, th5, prev_th5, prev_d5, thmin, wide_settled)) {
-                    conv = 1;
+                const int verdict = spk_wide_converged(top4, th4, sum8, trace, it - 1, prev_sum, prev_delta, prev_ratio, th5, prev_th5,
+                                                       prev_d5, thmin, wide_settled, prev_sum8);
+                if (verdict) {   // 1: certified; 2: nothing will certify this block - flagged (status bit 0), the direct solver's
+                    conv = verdict == 1;
                     break;
                 }
                 continue;

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
         spk_gram(V, R, 4, 1, sh);
         spk_chol_factor(sh, false);
         spk_orth(V, R, 4, 1, sh);
-        double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0, prev_th5 = 0, prev_d5 = 0;
+        double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0, prev_th5 = 0, prev_d5 = 0, prev_sum8 = 0;
         int wide_settled = 0;
         int it = 0, conv = 0;
         for (it = 1; it <= SPKB_MAXHALF; ++it) {
@@ -313,8 +313,10 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
                 }
                 double th5, thmin;
                 spk_wide_ritz_orth(X, rows, xcs, esh, top4, th4, sum8, &th5, &thmin);
-                if (spk_wide_converged(top4, th4, sum8, trace, wit, prev_sum, prev_delta, prev_ratio, th5, prev_th5, prev_d5, thmin, wide_settled)) {
-                    conv = 1;
+                const int verdict = spk_wide_converged(top4, th4, sum8, trace, wit, prev_sum, prev_delta, prev_ratio, th5, prev_th5, prev_d5,
+                                                       thmin, wide_settled, prev_sum8);
+                if (verdict) {   // 1: certified; 2: given up - flagged (status bit 0), the direct solver's (finish.hip)
+                    conv = verdict == 1;
                     break;
                 }
             }

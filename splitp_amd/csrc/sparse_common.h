@@ -463,24 +463,40 @@ __device__ __forceinline__ void spk_wide_ritz_orth(double* X, int rows, int cs, 
     }
 }
 
-// Stop rule of the wide block.  The slowest error component decays by lambda_9 / lambda_4 <= (trace - sum8) / th4 per half
-// product; where that bound is useful (< 0.9) it certifies the score to 5e-11 as in spk_converged, otherwise (heavy
-// tails: thousands of small eigenvalues outweigh lambda_4) the two-ratio estimate has to meet a ten times tighter tolerance.
-// The sum of the four largest Ritz values is not smooth: when the block's 4th vector is (almost exactly) the 5th
-// eigenvector of a close pair lambda_4 ~ lambda_5 - which is what the 4-wide phase hands over after a stall - the sum
-// sits on a plateau while the direction of lambda_4 is still growing out of the guard columns as the 5th Ritz value, and
-// jumps only when that value overtakes the 4th (found by the randomised tests: 1.9e-8 in a score).  So the 5th Ritz value
-// must be out of reach: either it has settled, or even four more steps of its current growth leave it below the 4th.
-__device__ __forceinline__ bool spk_wide_converged(double s4, double th4, double sum8, double trace, int k, double& prev_sum,
-                                                   double& prev_delta, double& prev_ratio, double th5, double& prev_th5,
-                                                   double& prev_d5, double thmin, int& settled) {
-    bool conv = false;
+// Stop rule of the wide block: CERTIFIED, or not at all (round 4).  Returns 1 = converged and certified, 2 = give up (the
+// caller flags the split with status bit 0 and the host hands it to the direct solver, finish.hip), 0 = go on.
+// Certificate.  Every Ritz value is a lower bound of the eigenvalue of its rank (Cauchy interlacing), so th4 <= lambda_4 and
+// everything the block does NOT hold weighs trace - sum8 >= lambda_9 (+ whatever part of lambda_1..8 is still missing).
+// rho_b = (trace - sum8) / th4 < 0.8 therefore says two things at once: (i) there is a real gap lambda_9 <= 0.8 lambda_4
+// behind the block, so no error component decays slower than rho_b per half product and delta rho_b / (1 - rho_b) bounds
+// what the sum still lacks; (ii) NO wanted direction can be hidden from the block: a direction of eigenvalue lambda_u that
+// the block barely sees (amplitude 1e-8 in the guard columns: nothing moves for dozens of half products - the failure of
+// the randomised sweeps of rounds 2 and 3, seeds 51000 / 71002 / 71004) leaves its whole lambda_u in trace - sum8, i.e.
+// rho_b >= lambda_u / th4, which is >= 1 for any direction that belongs in front of the 4th value.  (0.8 and not more: with a
+// PARTLY missing direction at angle phi, trace - sum8 >= (lambda_4 - lambda_9) sin^2 phi + lambda_9, and the premise of the
+// bound - the sum's error contracts by rho per step - holds once tan^2 phi <= 1 / rho; rho_b < c implies that for every
+// rho iff c <= 2 sqrt 2 - 2 = 0.828.)
+// Where the tail behind the block outweighs the 4th value (rho_b >= 0.8: flat spectra - random tables of 12 - 14 taxa with
+// th4 / th8 = 1.02 -, thousands of small eigenvalues) NOTHING the block can measure certifies its sum: rounds 2 and 3 accepted
+// such sums on settled ratios plus a verdict that had to persist for 18.4 / ln(th4 / thmin) half products, and twice in
+// 230 k randomised checks that was a score 1e-3 off with status "converged".  Such splits now leave as what they are - an
+// upper estimate, status bit 0 - as soon as the block can tell: the 8 Ritz values have settled (the missing mass is not
+// going to come in) and rho_b is still beyond 0.8, or the budget is spent.
+// The 5th Ritz value must still be out of reach of the 4th (a plateau of the sum while the direction of lambda_4 grows in
+// 5th place, seed 37000), and the verdict has to hold twice in a row.
+__device__ __forceinline__ int spk_wide_converged(double s4, double th4, double sum8, double trace, int k, double& prev_sum,
+                                                  double& prev_delta, double& prev_ratio, double th5, double& prev_th5,
+                                                  double& prev_d5, double thmin, int& settled, double& prev_sum8) {
+    int verdict = 0;
     const double d5 = fabs(th5 - prev_th5);
     const double r5 = prev_d5 > 0 ? fmin(d5 / prev_d5, 0.995) : 0.995;   // how fast the 5th Ritz value is settling
     prev_th5 = th5;
     prev_d5 = d5;
+    const double d8 = fabs(sum8 - prev_sum8);
+    prev_sum8 = sum8;
     const double delta = fabs(s4 - prev_sum);
     double ratio = 1.0;
+    (void)thmin;
     if (k >= 3) {
         ratio = prev_delta > 0 ? delta / prev_delta : 0.0;
         ratio = fmin(fmax(ratio, 0.0), 0.9999);
@@ -490,48 +506,35 @@ __device__ __forceinline__ bool spk_wide_converged(double s4, double th4, double
             const double tail = delta * r / (1.0 - r);
             const double sx = sqrt(fmax(rest, 0.0) * trace);
             const double tol = fmax(fmin(1e-13 * s4, 4e-11 * sx), 4e-15 * s4);
-            const double rho_b = th4 > 0 ? fmax(trace - sum8, 0.0) / th4 : 1.0;
-            if (rho_b < 0.9) {
+            const double rest8 = fmax(trace - sum8, 0.0);
+            const double rho_b = th4 > 0 ? rest8 / th4 : 1.0;
+            bool conv = false;
+            if (rho_b < 0.8) {
                 const bool bounded = delta * rho_b / (1.0 - rho_b) <= fmax(1e-10 * sx, 4e-15 * s4);
                 conv = bounded && (delta <= 0.2 * tol || tail <= tol);
+                // what the 5th value can still gain is the geometric tail of its own steps (at least 4 d5)
+                const double reach5 = d5 * fmax(4.0, r5 / (1.0 - r5));
+                const bool fifth_out_of_reach = d5 <= tol || th5 + reach5 < th4;
+                conv = conv && fifth_out_of_reach && s4 > 0 && th4 > 0;   // (a block that collapsed to zeros / nan is never a result)
+                settled = conv ? settled + 1 : 0;
+                if (settled >= 2) verdict = 1;
             } else {
-                conv = k >= 6 && (delta <= 0.1 * tol || tail <= 0.1 * tol);
+                settled = 0;
+                // hopeless: what the 8 Ritz values still gain per half product would need more than the remaining budget
+                // to bring rho_b under 0.8 (k >= 8: the first steps of a fresh block say nothing)
+                const double need = rest8 - 0.8 * th4;
+                if (k >= 8 && !(d8 * (double)SPK_MAXHALF_WIDE > need)) verdict = 2;
             }
-            // The 5th Ritz value must be out of reach of the 4th: what it can still gain is the geometric tail of its own
-            // steps, d5 r5 / (1 - r5) with the measured ratio (at least 4 d5).  A fixed 4 d5 let a block through whose 4th
-            // value sat on lambda_5 while the direction of lambda_4 - 1e-4 above it - was still creeping up in 5th place
-            // (forced big-table form, randomised sweep of round 2, seed 37000: scores 3e-6 off).
-            const double reach5 = d5 * fmax(4.0, r5 / (1.0 - r5));
-            const bool fifth_out_of_reach = d5 <= tol || th5 + reach5 < th4;
-            conv = conv && fifth_out_of_reach && s4 > 0 && th4 > 0;   // (a block that collapsed to zeros / nan is never a result)
-            // ... and the verdict has to LAST.  A wanted direction the block barely sees (the 4-wide phase hands over a
-            // stalled block; seed 51000 of the randomised sweep: lambda_4 / lambda_5 = 1.0003, one direction of the pair
-            // missing, amplitude ~1e-8 in the guard columns) changes nothing for dozens of half products - every test
-            // above passes, bound included, with the sum 3e-6 of the score short - and then grows out of the guard columns
-            // by th4 / thmin per half product.  So the rule has to hold for as many consecutive half products as that
-            // growth needs to lift an amplitude of 1e-8 into view, restarting whenever it fails.  (Round 3: that count used to
-            // be capped at 60.  On a nearly flat spectrum - random 3-letter tables of 12 - 14 taxa, th4 / thmin = 1.02 - the
-            // growth needs hundreds of half products, the capped rule let two blocks of 230 k randomised checks through
-            // with the score 1e-3 off and status "converged" after 103 and 392 half products (seeds 71002 / 71004).  The cap
-            // is now half the block's half-product budget: a verdict reached in the first half of the budget can still be
-            // confirmed inside it - uncapped, the clustered-spectrum tables of the suite's sweep slice, whose verdicts were
-            // right, ran out of budget instead -, one reached later runs into the budget and is reported as what it is:
-            // not certified, status bit 0.)
-            const double g = thmin > 0 && thmin < th4 ? log(th4 / thmin) : 0.0;
-            const int need_cap = SPK_MAXHALF_WIDE / 2;
-            const int need = g > 0 ? (int)fmin((double)need_cap, fmax(2.0, ceil(18.4 / g))) : need_cap;
-            settled = conv ? settled + 1 : 0;
-            conv = conv && settled >= need;
 #ifdef SPK_DEBUG_CONV
             if (threadIdx.x == 0)
-                printf("wide k %d s4/trace %.12f th4/s %.4e th5/s %.4e sum8/trace %.12f delta/s %.3e rho_b %.4f conv %d\n", k, s4 / trace,
-                       th4 / s4, th5 / s4, sum8 / trace, delta / s4, rho_b, (int)conv);
+                printf("wide k %d s4/trace %.12f th4/s %.4e th5/s %.4e sum8/trace %.12f delta/s %.3e rho_b %.4f verdict %d\n", k, s4 / trace,
+                       th4 / s4, th5 / s4, sum8 / trace, delta / s4, rho_b, verdict);
 #endif
         }
     }
     prev_ratio = ratio;
     prev_delta = delta;
     prev_sum = s4;
-    return conv;
+    return verdict;
 }
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.sp_abi_version() == _lib.SP_ABI_VERSION == 3
+    assert lib.sp_abi_version() == _lib.SP_ABI_VERSION == 4
     assert isinstance(lib.sp_last_error(), bytes)
 
 

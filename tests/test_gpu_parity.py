@@ -32,7 +32,8 @@ def _reset_context_options(sp):
     yield
     ctx = sp.get_context()
     for name, val in (("force_big", 0), ("big_by_keys", 0), ("subscore_jacobi", 0), ("divergence_global", 0),
-                      ("hist_sort", -1), ("lds_cap", 0), ("wide_cap", 0)):
+                      ("hist_sort", -1), ("lds_cap", 0), ("wide_cap", 0), ("direct_finish", 1), ("direct_all", 0),
+                      ("direct_max_rows", 0)):
         ctx.set_option(name, val)
 
 
@@ -456,7 +457,10 @@ def test_async_entry_and_handback(sp, golden):
     s_h, st_h = sc.cpu().numpy(), st.cpu().numpy()
     assert not np.any(st_h & 3) and batch.finish_async(dev, taxa_arr, a_arr, s_h, st_h) == 0
     assert np.abs(s_h - g["scores"]).max() <= SCORE_TOL
-    # a gapless table: the 4-wide block certifies nothing, the chain's wide block finishes every split on the device
+    # a gapless table (uniform random patterns): no block certifies anything.  The chain runs on the device to its end - no
+    # status bit 1 - and FLAGS what it cannot certify (bit 0, an upper estimate: the wide block gives up as soon as its 8
+    # Ritz values have settled with the tail behind them still outweighing the 4th); finish_async hands exactly those to the
+    # direct solver
     rng = np.random.default_rng(3)
     rk = np.unique(rng.integers(0, 4 ** 10, size=3000).astype(np.uint64))
     rc = rng.integers(1, 40, size=len(rk)).astype(np.int64)
@@ -467,17 +471,14 @@ def test_async_entry_and_handback(sp, golden):
     batch.score_encoded_async(flat, sub_t, sub_a, _lib.SP_METHOD_FLATTENING, sc2.data_ptr(), st2.data_ptr())
     torch.cuda.synchronize()
     s2, t2 = sc2.cpu().numpy(), st2.cpu().numpy()
-    assert not np.any(t2 & 2) and (t2 >> 8).max() > 40          # past the 4-wide block's 40 half products
+    assert not np.any(t2 & 2)
     ref = sp.score_splits(flat, [splits[i] for i in range(0, 501, 50)], route="dense")
     done = (t2 & 1) == 0
-    assert done.sum() > 0 and np.abs(s2 - ref)[done].max() <= 1e-9
-    # (a flat random spectrum on a SMALL side is where even the 8-wide block can run into its cap: flagged with status
-    # bit 0, an upper estimate - finish_async re-scores those through the synchronous entry point, whose hand-back goes
-    # to the dense route's 16-wide block for sides of up to 1024 rows)
+    assert np.all(np.abs(s2 - ref)[done] <= 1e-9)
     assert np.all(s2[~done] >= ref[~done] - 1e-9)
     assert batch.finish_async(flat, sub_t, sub_a, s2, t2) == int((~done).sum())
     assert not np.any(t2 & 3) and np.abs(s2 - ref).max() <= 1e-9
-    # the synchronous entry point on the same table: small sides go to the dense route instead - same scores
+    # the synchronous entry point on the same table finishes its flagged splits itself - same scores
     assert np.abs(sp.score_splits(flat, [splits[i] for i in range(0, 501, 50)]) - ref).max() <= 1e-9
 
 
@@ -617,6 +618,7 @@ def test_enoconv_is_reported(sp):
     t2, a2 = np.ascontiguousarray(taxa_arr[wide]), np.ascontiguousarray(a_arr[wide])
     dev.ctx.set_option("wide_cap", 6)
     assert dev.ctx.get_option("wide_cap") == 6
+    dev.ctx.set_option("direct_finish", 0)      # (with the direct solver on - the default - nothing stays flagged: below)
     scores = np.zeros(len(wide))
     status = np.zeros(len(wide), dtype=np.int32)
     rc = dev.ctx._lib.sp_score_splits(dev.handle, _lib._ptr(t2, C.c_int32), _lib._ptr(a2, C.c_int32), len(wide),
@@ -629,6 +631,12 @@ def test_enoconv_is_reported(sp):
         warnings.simplefilter("always")
         est, st = batch.score_encoded(dev, t2, a2, _lib.SP_METHOD_FLATTENING)
     assert any(issubclass(w.category, RuntimeWarning) for w in caught) and np.all(st & 1) and np.array_equal(est, scores)
+    dev.ctx.set_option("direct_finish", 1)      # same cap, direct solver on: every flagged split is finished, no warning
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        fin, st_fin = batch.score_encoded(dev, t2, a2, _lib.SP_METHOD_FLATTENING)
+    assert not any(issubclass(w.category, RuntimeWarning) for w in caught)
+    assert np.all((st_fin & 7) == 4) and np.abs(fin - good[wide]).max() <= SCORE_TOL
     dev.ctx.set_option("wide_cap", 0)
     back, st_back = batch.score_encoded(dev, t2, a2, _lib.SP_METHOD_FLATTENING)
     assert np.array_equal(back, good[wide]) and not np.any(st_back & 3)
