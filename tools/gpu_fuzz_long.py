@@ -10,7 +10,7 @@ seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 ntr = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 rng = np.random.default_rng(seed0)
-bad = 0; checked = 0; t0 = time.time()
+bad = 0; checked = 0; t0 = time.time(); flagged = 0; direct = 0
 def close(a, b):
     # score within 1e-10, or 1 - top4/trace within 8e-15 (the fp64 floor of that difference: it decides scores below ~2e-5;
     # 4e-15 until round 2 - tables whose counts are split into 16-bit pieces reach 5.4e-15)
@@ -32,6 +32,7 @@ for trial in range(ntr):
         got, st = sp.score_splits(dev, splits, return_status=True)
     except Exception as e:
         print("EXC", trial, n, length, letters, len(keys), str(e)[:200]); bad += 1; continue
+    flagged += int(np.count_nonzero(st & 3)); direct += int(np.count_nonzero(st & 4))
     dn = None
     if n <= 10:
         dn = sp.score_splits(dev, splits, route="dense")
@@ -46,4 +47,5 @@ for trial in range(ntr):
             if not close(want, val):
                 bad += 1
                 print("BAD", name, "trial", trial, "n", n, "L", length, "letters", letters, "D", len(keys), "split", i, M.shape, "want", want, "got", val, hex(st[i]))
-print("seed", seed0, "trials", ntr, "checked", checked, "bad", bad, "%.0f s" % (time.time() - t0))
+print("seed", seed0, "trials", ntr, "checked", checked, "bad", bad, "flagged(status bit 0/1)", flagged, "finished by the direct solver", direct,
+      "%.0f s" % (time.time() - t0))
