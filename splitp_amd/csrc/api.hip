@@ -134,6 +134,7 @@ extern "C" int sp_ctx_create(int device, void* stream, sp_ctx** out) {
     if (const char* lc = getenv("SPLITP_DEBUG_LDS_CAP")) c->opt.lds_cap = atoll(lc);
     if (const char* df = getenv("SPLITP_DIRECT_FINISH")) c->opt.direct_finish = df[0] != '0';
     c->opt.direct_all = env_flag("SPLITP_DIRECT_ALL");
+    c->opt.eigen_block16 = env_flag("SPLITP_EIGEN_BLOCK16");
     *out = c;
     return SP_OK;
     });
@@ -153,6 +154,7 @@ static long long* option_slot(sp_ctx* c, const char* name, int** as_int) {
     else if (!strcmp(name, "direct_finish")) *as_int = &c->opt.direct_finish;
     else if (!strcmp(name, "direct_max_rows")) *as_int = &c->opt.direct_max_rows;
     else if (!strcmp(name, "direct_all")) *as_int = &c->opt.direct_all;
+    else if (!strcmp(name, "eigen_block16")) *as_int = &c->opt.eigen_block16;
     else if (!strcmp(name, "lds_cap")) return &c->opt.lds_cap;
     return nullptr;
 }
@@ -317,7 +319,7 @@ extern "C" int sp_alignment_create(sp_ctx* ctx, const uint64_t* keys, const doub
     al->max_count = maxc;
     int rc = SP_OK;
     const size_t d1 = (size_t)std::max<int64_t>(D, 1);
-    if ((rc = al->keys.ensure(d1 * 8)) || (rc = al->weights.ensure(d1 * 8)) || (rc = al->counts.ensure(d1 * 4))) {
+    if ((rc = al->keys.ensure(d1 * 8)) || (rc = al->weights.ensure(d1 * 8)) || (rc = al->counts.ensure(d1 * 4 + SP_COUNTS_PAD))) {
         sp_alignment_destroy(al);
         return rc;
     }
@@ -672,10 +674,12 @@ static int run_dense_route(sp_alignment* al, const Plan& plan, bool plan_on_devi
         return launch_direct_top4(ctx, sdev, dims, (int64_t)S, mmax, ctx->grams.as<double>(), ctx->eigws.as<double>(), nullptr,
                                   ctx->scores.as<double>(), ctx->status.as<int>());
     }
+    const int* order_dev = reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() + plan.row_items.size());
+    if (!ctx->opt.eigen_block16)   // certified 4-wide block, one workgroup per split (heaviest first); what it flags is the direct solver's
+        return launch_eigen4(ctx, sdev, plan.splits, dims, ctx->grams.p, g_i32, order_dev, ctx->scores.as<double>(),
+                             ctx->status.as<int>());
     SP_CHECK(launch_eigen(ctx, sdev, plan.splits, dims, ctx->grams.p, g_i32,
-                          ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
-                          reinterpret_cast<const int*>(ctx->gram_items.as<GramItem>() + plan.gram_items.size() +
-                                                       plan.row_items.size()),
+                          ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(), order_dev,
                           ctx->scores.as<double>(), ctx->status.as<int>(), (int64_t)plan.n_row_a, (int64_t)plan.n_order_a));
     return SP_OK;
 }
@@ -689,6 +693,16 @@ static int score_single_gram(sp_ctx* ctx, const Plan& plan, int64_t R) {
     SP_REQUIRE(!direct || R <= max_rows, SP_ELIMIT,
                "matrix with a smaller side of %lld rows: the eigen kernels hold %d rows in LDS, the direct solver takes %lld",
                (long long)R, EIG_MAXR, (long long)max_rows);
+    if (!direct && !ctx->opt.eigen_block16) {
+        SP_CHECK(launch_eigen4(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.p, false, nullptr,
+                               ctx->scores.as<double>(), ctx->status.as<int>()));
+        if (!ctx->opt.direct_finish) return SP_OK;
+        int st = 0;
+        SP_HIP(hipMemcpyAsync(&st, ctx->status.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SP_HIP(hipStreamSynchronize(ctx->stream));
+        if (!(st & 3)) return SP_OK;
+        direct = true;   // (the kernel only reads G)
+    }
     if (!direct) {
         SP_CHECK(launch_eigen(ctx, ctx->splits.as<SplitDev>(), plan.splits, ctx->dims.as<int2>(), ctx->grams.p, false,
                               ctx->gram_items.as<GramItem>() + plan.gram_items.size(), (int64_t)plan.row_items.size(),
@@ -756,7 +770,7 @@ static int prepare_sparse_table(sp_ctx* ctx, sp_alignment* al) {
         SP_REQUIRE((int64_t)ek.size() == rows, SP_EINVAL, "expanded table has %zu rows, expected %lld", ek.size(),
                    (long long)rows);
         SP_CHECK(al->spk_keys.ensure((size_t)rows * 8));
-        SP_CHECK(al->spk_counts.ensure((size_t)rows * 4));
+        SP_CHECK(al->spk_counts.ensure((size_t)rows * 4 + SP_COUNTS_PAD));
         SP_HIP(hipMemcpy(al->spk_keys.p, ek.data(), (size_t)rows * 8, hipMemcpyHostToDevice));
         SP_HIP(hipMemcpy(al->spk_counts.p, ec.data(), (size_t)rows * 4, hipMemcpyHostToDevice));
         keys = al->spk_keys.as<u64>();
@@ -1049,22 +1063,8 @@ static int finish_flagged(sp_alignment* al, const int32_t* split_taxa, const int
     return SP_OK;
 }
 
-// After any flattening route has left its scores / status words in the context's buffers: fetch the status words and, if
-// any split is flagged, finish it with the direct solver (patching ctx->scores / ctx->status).
-static int finish_context_results(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S) {
-    sp_ctx* ctx = al->ctx;
-    if (!ctx->opt.direct_finish || S == 0) return SP_OK;
-    std::vector<int> st((size_t)S);
-    SP_HIP(hipMemcpyAsync(st.data(), ctx->status.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
-    SP_HIP(hipStreamSynchronize(ctx->stream));
-    bool any = false;
-    for (int v : st) any |= (v & 3) != 0;
-    if (!any) return SP_OK;
-    return finish_flagged(al, split_taxa, split_a, S, st, ctx->scores.as<double>(), ctx->status.as<int>(), nullptr);
-}
-
 // Synchronous sparse route: the device chain (in-LDS kernel -> lists in global memory -> all arrays in global memory ->
-// 8-wide fallback block); whatever leaves it flagged is the direct solver's (finish_context_results, at the caller).
+// 8-wide fallback block); whatever leaves it flagged is the direct solver's (finish_flagged, at the caller).
 static int run_sparse_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S) {
     sp_ctx* ctx = al->ctx;
     sp_plan* plan = nullptr;
@@ -1319,31 +1319,47 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
         sp_set_error("unknown method %d", method);
         return SP_EINVAL;
     }
-    // whatever an iterative flattening route could not certify goes to the direct solver (status bit 2 afterwards)
-    if (method == SP_METHOD_FLATTENING || method == SP_METHOD_FLATTENING_DENSE || method == SP_METHOD_FLATTENING_SPARSE)
-        SP_CHECK(finish_context_results(al, split_taxa, split_a, n_splits));
-    if (scores_dev)
-        SP_HIP(hipMemcpyAsync(scores_dev, ctx->scores.p, n_splits * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    if (scores_host)
-        SP_HIP(hipMemcpyAsync(scores_host, ctx->scores.p, n_splits * 8, hipMemcpyDeviceToHost, ctx->stream));
+    // Results out.  Scores and status words travel to the host in ONE batch of copies behind one synchronisation; only when
+    // a status word is flagged (bit 0 / 1: an iterative flattening route found no certificate) does the direct solver run
+    // (status bit 2 afterwards) and the patched results are copied again.
+    const bool flat_method = method == SP_METHOD_FLATTENING || method == SP_METHOD_FLATTENING_DENSE || method == SP_METHOD_FLATTENING_SPARSE;
+    const bool may_finish = flat_method && ctx->opt.direct_finish != 0;
     std::vector<int32_t> st_tmp;
     int32_t* st_out = status_host;
-    if (scores_host && !status_host) {   // the return code reports unconverged splits either way
+    if ((scores_host || may_finish) && !status_host) {   // the return code reports unconverged splits either way
         st_tmp.resize((size_t)n_splits);
         st_out = st_tmp.data();
     }
+    if (scores_host) SP_HIP(hipMemcpyAsync(scores_host, ctx->scores.p, n_splits * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (st_out) SP_HIP(hipMemcpyAsync(st_out, ctx->status.p, n_splits * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (scores_host || st_out) SP_HIP(hipStreamSynchronize(ctx->stream));
+    if (may_finish && st_out) {
+        bool any = false;
+        for (int64_t i = 0; i < n_splits && !any; ++i) any = (st_out[i] & 3) != 0;
+        if (any) {
+            std::vector<int> st(st_out, st_out + n_splits);
+            int64_t done = 0;
+            SP_CHECK(finish_flagged(al, split_taxa, split_a, n_splits, st, ctx->scores.as<double>(), ctx->status.as<int>(), &done));
+            if (done) {
+                if (scores_host) SP_HIP(hipMemcpyAsync(scores_host, ctx->scores.p, n_splits * 8, hipMemcpyDeviceToHost, ctx->stream));
+                SP_HIP(hipMemcpyAsync(st_out, ctx->status.p, n_splits * 4, hipMemcpyDeviceToHost, ctx->stream));
+                SP_HIP(hipStreamSynchronize(ctx->stream));
+            }
+        }
+    }
+    if (scores_dev)
+        SP_HIP(hipMemcpyAsync(scores_dev, ctx->scores.p, n_splits * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (st_out) {
         int64_t bad = 0, first = -1;
         for (int64_t i = 0; i < n_splits; ++i)
-            if (st_out[i] & 1) {
+            if (st_out[i] & 3) {
                 if (first < 0) first = i;
                 ++bad;
             }
         if (bad) {
-            sp_set_error("%lld of %lld splits hit the iteration cap of their eigen-solver (first: split %lld): their scores "
-                         "are upper estimates (status bit 0)", (long long)bad, (long long)n_splits, (long long)first);
+            sp_set_error("%lld of %lld splits left their eigen-solver without a certificate (first: split %lld) and are beyond "
+                         "the direct solver's limits or it is switched off: their scores are upper estimates (status bit 0 / 1)",
+                         (long long)bad, (long long)n_splits, (long long)first);
             return SP_ENOCONV;
         }
     }

@@ -91,6 +91,12 @@ struct DevBuf {
     T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Every counts buffer of an alignment (sp_alignment::counts, ::spk_counts) is allocated with this many bytes behind its last
+// entry: the sparse kernels fetch a lane's counts as whole 16-byte loads starting anywhere up to the table's end
+// (sparse.hip: spk_prefetch_counts reads up to SPK_MAXQ * 4 = 80 bytes past it and ignores them) - a contract of the
+// allocation sites, not an accident of DevBuf's growth slack.
+#define SP_COUNTS_PAD 128
+
 struct PhaseTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[SP_N_PHASES];
     std::vector<hipEvent_t> pool;
@@ -132,6 +138,8 @@ struct CtxOptions {
     int direct_finish = 1;      // flagged splits (status bit 0 / 1) end in the direct solver (finish.hip); 0: they stay flagged (SP_ENOCONV)
     int direct_max_rows = 0;    // largest smaller side (compact rows) the direct solver takes (0 = 16384)
     int direct_all = 0;         // dense route / generic matrices: the direct solver instead of the block iteration (test switch)
+    int eigen_block16 = 0;      // dense route / generic matrices: rounds 1 - 3's 16-wide block pipeline (eigen.hip) instead of the
+                                // certified 4-wide kernel (eig4.hip) - kept as a cross-check
 };
 
 struct sp_ctx {
@@ -327,6 +335,8 @@ template <typename T>
 int launch_gram(sp_ctx* ctx, const SplitDev* splits_dev, const GramItem* items_dev, int64_t n_items, const int2* dims,
                 const T* mats, double* grams);
 void build_gram_items(Plan& plan);
+int launch_eigen4(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<SplitDev>& splits, const int2* dims,
+                  const void* grams, bool g_i32, const int* order_dev, double* scores, int* status);   // eig4.hip
 size_t direct_ws_doubles(int64_t n_mats, int64_t max_rows);   // finish.hip
 int launch_direct_top4(sp_ctx* ctx, const SplitDev* splits_dev, const int2* dims_dev, int64_t n_mats, int max_rows,
                        double* grams, double* ws_dev, const int* out_idx_dev, double* scores, int* status);

@@ -314,7 +314,7 @@ static int build_sorted(sp_ctx* ctx, const KT* dkeys, int64_t L, int n_taxa, sp_
     al->N = L - dropped;
     al->exact = true;
     const size_t d1 = (size_t)std::max<int64_t>(D, 1);
-    if ((rc = al->keys.ensure(d1 * 8)) || (rc = al->weights.ensure(d1 * 8)) || (rc = al->counts.ensure(d1 * 4))) {
+    if ((rc = al->keys.ensure(d1 * 8)) || (rc = al->weights.ensure(d1 * 8)) || (rc = al->counts.ensure(d1 * 4 + SP_COUNTS_PAD))) {
         sp_alignment_destroy(al);
         return fail(rc);
     }
@@ -421,7 +421,7 @@ static int build_from_device_keys(sp_ctx* ctx, const void* dkeys, bool keys32, i
     al->exact = true;
     al->max_count = meta[1];
     const size_t d1 = (size_t)std::max<int64_t>(D, 1);
-    if ((rc = al->keys.ensure(d1 * 8)) || (rc = al->weights.ensure(d1 * 8)) || (rc = al->counts.ensure(d1 * 4))) {
+    if ((rc = al->keys.ensure(d1 * 8)) || (rc = al->weights.ensure(d1 * 8)) || (rc = al->counts.ensure(d1 * 4 + SP_COUNTS_PAD))) {
         cleanup();
         sp_alignment_destroy(al);
         return rc;

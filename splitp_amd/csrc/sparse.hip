@@ -51,12 +51,14 @@ __device__ __forceinline__ int spk_class(int c) {
 // The counts of a lane's SPK_MAXQ consecutive table entries from global memory, as five 16-byte loads (4-byte aligned:
 // global memory takes them).  As SPK_MAXQ predicated 4-byte loads - lanes 68 bytes apart, so every one of them touched 64
 // cache lines - they kept the texture addresser busy for ~15 k cycles of a list build (tools/gpu_stamps_lists.sh).  Words
-// past the lane's share, or past the table, are loaded and never used: the table's buffers carry DevBuf's slack (>= 512
-// bytes) behind their last entry, and a start beyond the table is pulled back to its end.
+// past the lane's share, or past the table, are loaded and never used: every counts buffer is allocated with SP_COUNTS_PAD
+// (128) bytes behind its last entry (common.h; api.hip / hist.hip allocation sites), and a start beyond the table is pulled
+// back to its end.
 typedef u32 spk_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 template <typename CT>
 __device__ __forceinline__ void spk_prefetch_counts(const CT* cnt, int first, int D, u32 (&cpre)[SPK_MAXQ]) {
     static_assert(SPK_MAXQ % 4 == 0, "whole 16-byte loads");
+    static_assert(SPK_MAXQ * 4 <= SP_COUNTS_PAD, "the over-read must stay inside the pad of the counts buffers");
     if constexpr (sizeof(CT) == 4) {
         const u32* cb = reinterpret_cast<const u32*>(cnt) + min(first, D);
 #pragma unroll

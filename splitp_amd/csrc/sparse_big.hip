@@ -519,7 +519,7 @@ int launch_sparse_big_keys(sp_ctx* ctx, const u64* keys, int64_t D, int n, const
     const unsigned bits = (unsigned)(2 * max_side);
     int* dimp = reinterpret_cast<int*>(dims.p);
     // stable sort of every split's (raw side key, pattern index) pairs by key: S segments of D entries (radix_sort.h)
-    DevBuf &altk = ctx->big[12], &altv = ctx->big[13];
+    DevBuf &altk = ctx->big[22], &altv = ctx->big[23];   // (slots of their own: 12 / 13 are d_taxa / d_a of this function)
     if ((rc = altk.ensure(total * 8)) || (rc = altv.ensure(total * 4))) return fail(rc);
     const unsigned passes = (bits + RS_BITS - 1) / RS_BITS;
     auto sort_side = [&](const u64* side_keys, DevBuf& permb) -> int {

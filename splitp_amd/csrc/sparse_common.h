@@ -329,8 +329,15 @@ __device__ __forceinline__ bool spk_converged(double s4, double lam_lb, double t
             // would cost every split a half product; it is asked to keep the SCORE within 5e-11 instead
             // (d s <= 1e-10 score trace), which the estimate-based stop already implies unless rho_b >> r.
             const double rho_b = lam_lb > 0 ? fmin(sp_fdiv(rest, lam_lb), 0.9999) : 0.9999;
-            const bool bounded = sp_fdiv(delta * rho_b, 1.0 - rho_b) <= fmax(1e-10 * sx, 4e-15 * s4);
-            if (gap && bounded && ((k >= 4 && delta <= 0.2 * tol) || tail <= tol)) conv = true;
+            // dense_g (round 4): a step is a product with the exact G, i.e. TWO half products - the Ritz sum's error contracts
+            // by (lambda_5 / lambda_4)^2 <= rho_b^2 per step, and the bound may say so.  Where the bound ALONE keeps the
+            // score within 1e-11 (d s <= 2e-11 score trace) nothing estimated is needed on top of it: the split stops on
+            // its certificate (the dense route's eigen kernel, eig4.hip: third streamed product instead of the fourth).
+            const double rb = dense_g ? rho_b * rho_b : rho_b;
+            const double left = sp_fdiv(delta * rb, 1.0 - rb);
+            const bool bounded = left <= fmax(1e-10 * sx, 4e-15 * s4);
+            const bool certified_tight = dense_g && left <= fmax(2e-11 * sx, 4e-15 * s4);
+            if (gap && bounded && (certified_tight || (k >= 4 && delta <= 0.2 * tol) || tail <= tol)) conv = true;
         }
     }
 #ifdef SPK_DEBUG_CONV

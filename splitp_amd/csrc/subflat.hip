@@ -740,9 +740,13 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
             const double nlo = first > 0 ? s_lo : lo, nhi = first < 16 ? s_hi : hi;
             lo = nlo;
             hi = nhi;
-            // After 11 passes the brackets are 3e-14 of the interval wide: 1 - top4 / trace is known to ~2e-13, the score
-            // sqrt(.) to 2e-13 / (2 score) - where that is below 3e-12 (score >= 0.05: every split that is not nearly
-            // tree-like) the last two passes cannot move the score by more, and are skipped.
+            // After 11 passes each of the four brackets is 3e-14 of the (unit-length) Gershgorin interval wide, so the sum of
+            // their midpoints is good to 4 x 1.5e-14 and 1 - top4 / trace to 6e-14 / tr_s, the trace in the scaled units
+            // (<= 1 per row, ~0.1 at worst on count tables); the score sqrt(.) then moves by at most that over 2 score.
+            // Where the score is >= 0.05 (1 - top4 / trace >= 2.5e-3: every split that is not nearly tree-like) that is
+            // <= 6e-12 in the worst case and ~1e-12 typically - inside the 1e-10 parity bar (SCORE_TOL), and the reason
+            // the self-consistency bar between two kernel shapes (PROP_TOL 5e-12) is asserted on builds that skip alike -
+            // so the last two passes are skipped there.
             if (pass == SUBT_PASSES - 3) {
                 double tq = (t == 0) ? fmax(0.5 * (lo + hi), 0.0) : 0.0;
                 tq += __shfl_xor(tq, 16, 64);

@@ -625,7 +625,7 @@ def test_enoconv_is_reported(sp):
                                       _lib.SP_METHOD_FLATTENING, _lib._ptr(scores, C.c_double), None,
                                       _lib._ptr(status, C.c_int32))
     assert rc == _lib.SP_ENOCONV and np.all(status & 1) and not np.any(status & 2)
-    assert b"iteration cap" in dev.ctx._lib.sp_last_error()
+    assert b"without a certificate" in dev.ctx._lib.sp_last_error()
     assert np.all(np.isfinite(scores)) and np.all(scores >= good[wide] - 1e-9)      # upper estimates of the scores
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
