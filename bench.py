@@ -354,10 +354,18 @@ def dense_route_fractions(phases_per_step, pmc_all, pmc_file, pmc_why):
                             "hbm_bytes_per_launch_pmc": sc_bytes or None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "achieved": sc_bytes / sc_s / 1e9 if sc_bytes and sc_s else None,
                             "frac": sc_bytes / sc_s / 1e9 / HBM_PEAK_GBS if sc_bytes and sc_s else None}
-    out["eigen_phase"] = {"ms": phases_per_step.get("eigen"),
-                          "note": "16-wide block iteration: G V products (k_eig_gv: G streamed from HBM once per "
-                                  "product) + per-split Rayleigh-Ritz (k_eig_rr: one wave's 16 x 16 Jacobi, latency-"
-                                  "bound); long and short sides as two concurrent pipelines"}
+    # k_eig4 streams every split's int32 Gram matrix once per product, 3 products per split at this workload (certified
+    # stop): 501 splits x R^2 x 4 bytes x 3 - bound by that stream (HBM / Infinity Cache), one workgroup per split
+    g_bytes = (pmc_all or {}).get("eig4", {}).get("hbm_bytes_per_launch")
+    eig_s = phases_per_step.get("eigen", 0.0) * 1e-3
+    out["eigen_phase"] = {"ms": phases_per_step.get("eigen"), "kernel": "k_eig4<int>", "bound": "hbm",
+                          "hbm_bytes_per_launch_pmc": g_bytes, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "achieved": g_bytes / eig_s / 1e9 if g_bytes and eig_s else None,
+                          "frac": g_bytes / eig_s / 1e9 / HBM_PEAK_GBS if g_bytes and eig_s else None,
+                          "note": "certified 4-wide block iteration on the exact Gram matrix, one 1024-thread workgroup per "
+                                  "split streaming G (thread = row, V broadcast from LDS), MFMA 4 x 4 Gram + Cholesky-QR, "
+                                  "stop on a certificate (gap + error bound); what it cannot certify goes to the direct "
+                                  "solver (Householder + Sturm)"}
     return out
 
 
@@ -659,7 +667,8 @@ def north_star_pipeline(env, main_scores):
     diff = float(np.max(np.abs(m["scores"][0] - main_scores[0]))) if main_scores is not None else None
     return {"what": "30 steps of the dense route on the same 10-taxon 100k-bp table, timed after the main region: k_reindex "
                     "(bitmaps + ranks per split) -> k_zero_i8 + k_scatter_i8 (compact int8-limb matrices) -> k_gram_i8_big "
-                    "(int8 MFMA Gram, exact) -> k_eig_* (16-wide block iteration, one-wave Jacobi); all 501 splits per step",
+                    "(int8 MFMA Gram, exact) -> k_eig4 (certified 4-wide block iteration, one workgroup per split streaming G); "
+                    "all 501 splits per step",
             "value": m["value"], "unit": "splits/s", "ms_per_step": m["ms_per_step"], "steps": m["steps"],
             "phase_ms_per_step": m["phases_per_step"],
             "gram_phase": {k: frac.get(k) for k in ("kernel", "launch_ms", "bound", "achieved", "peak", "unit", "frac",
@@ -787,6 +796,9 @@ def main():
             "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": m["scaling"],
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "host_us_per_step": m["host_us_per_step"],
+            # how many ranks the collective library really saw (1 = no process group: nothing was gathered)
+            "rccl_ranks": int(dist.get_world_size()) if dist is not None else 1,
+            "collective_backend": (str(dist.get_backend()) + " (RCCL over xGMI)") if dist is not None else None,
             "config": config_block(m),
             "roofline": roofline_block(m) if m["dom"] else None,
         }

@@ -197,7 +197,7 @@ extern "C" int sp_ctx_destroy(sp_ctx* c) {
     for (auto e : c->timer.pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->splits, &c->bitmaps, &c->coords, &c->dims, &c->mats,  &c->grams,  &c->eigws,
                       &c->scores, &c->status,  &c->misc,   &c->misc2, &c->gram_items, &c->aldescs, &c->slabs, &c->chain,
-                      &c->splits_launch, &c->hist_bins, &c->hist_blk, &c->hist_off};
+                      &c->splits_launch, &c->hist_bins, &c->hist_blk, &c->hist_off, &c->enum_buf};
     if (c->cache && c->cache->sparse) (void)sp_plan_release(c->cache->sparse);
     delete c->cache;
     for (auto* b : bufs) b->release();
@@ -252,6 +252,17 @@ extern "C" int sp_ctx_enable_timing(sp_ctx* c, int on) {
     return sp_guard("sp_ctx_enable_timing", [&]() -> int {
     SP_REQUIRE(c, SP_EINVAL, "ctx is NULL");
     c->timing = on != 0;
+    // Events are created HERE, not lazily inside the first timed launches: a 20-step measurement right after the switch
+    // (the driver's bench command) otherwise paid a hipEventCreate x 4 per step - host_us_per_step 63 against 30 us of a
+    // long run.  A phase scope takes two events; they return to the pool when the times are read.
+    if (c->timing) {
+        SP_HIP(hipSetDevice(c->device));
+        while (c->timer.pool.size() < 1024) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            c->timer.pool.push_back(e);
+        }
+    }
     return SP_OK;
     });
 }

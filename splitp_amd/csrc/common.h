@@ -179,6 +179,10 @@ struct sp_ctx {
     // ALL ZERO by the pass that reads it (no allocation, no memset per alignment); hist_clean = that invariant holds
     DevBuf hist_bins, hist_blk, hist_off;
     bool hist_clean = false;
+    // all-splits enumeration (subflat.hip: enumerate_all_splits) of the last (n, trivial, size, shard): kept between calls
+    DevBuf enum_buf;
+    long long enum_key[6] = {0, 0, 0, 0, 0, 0};
+    bool enum_valid = false;
 };
 
 struct sp_alignment {

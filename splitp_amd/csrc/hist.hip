@@ -255,7 +255,7 @@ __global__ void k_counts_to_weights(const u32* __restrict__ counts, int64_t D, d
 // ---- sort-based histogram: any number of taxa ---------------------------------------------------------------------------
 // The direct bin array costs 3 passes over 4 * 4^n bytes (16 GiB at 16 taxa: 16 ms for a 1 M-site alignment) and does not
 // exist beyond 16 taxa.  When the bins outweigh the sites (4^n > 32 L) or n > 16 the site words are radix-sorted on the
-// bits in use (rocPRIM) and run-length encoded instead: unique keys come out ascending like the bins' compaction, the
+// bits in use (csrc/radix_sort.h, hand-written since round 3) and run-length encoded instead: unique keys come out ascending like the bins' compaction, the
 // invalid-site marker (all ones: bit 2n set) sorts last and is cut off.
 template <typename KT>
 __global__ void k_widen_keys(const KT* __restrict__ in, int64_t D, u64* __restrict__ out) {

@@ -9,7 +9,7 @@
 // Big-table form: count tables with more than 65535 patterns (the 16-bit ids / offsets of the list kernels above end
 // there; 12 taxa beyond ~1 M sites, long branches), any side size, everything in global memory.
 // Per split the dense route's reindex kernel has already produced compact (row, col) for every pattern.  The two list
-// orders come from ONE stable segmented radix sort each (rocPRIM; segments = splits; keys = col resp. row, values =
+// orders come from ONE stable segmented radix sort each (csrc/radix_sort.h; segments = splits; keys = col resp. row, values =
 // pattern index), so every group is in table order like the counting sort above: reproducible bit for bit.
 // Products walk a sorted order in 1024 thread-chunks: a thread sums the runs inside its chunk; a run that crosses chunk
 // borders leaves partial sums (first / last run of a chunk) in LDS and its head's owner adds them up in chunk order.

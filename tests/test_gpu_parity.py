@@ -1366,6 +1366,18 @@ def test_config4_size_subflattening(sp):
         m_gpu = sp.subflattening(splits[i], dev)
         assert np.array_equal(np.rint(m_gpu * length), np.rint(S * length))
         assert abs(O.dense_split_score(S) - got[i]) <= SCORE_TOL
+    # the full enumeration (`every`, all_splits order) against the oracle on at least four splits of EVERY size class -
+    # first, last and two inside - like config 3 (every 17th of 360 random splits was 22 checks of 524 267)
+    ta, aa = batch.encode_all_splits(n)
+    checked = 0
+    for k in range(2, 11):
+        idx = np.nonzero(np.minimum(aa, n - aa) == k)[0]
+        for i in sorted({int(idx[0]), int(idx[len(idx) // 3]), int(idx[2 * len(idx) // 3]), int(idx[-1])}):
+            oa, ob = ta[i][:aa[i]].tolist(), ta[i][aa[i]:].tolist()
+            S = M[np.ix_(O.subflattening_index(oa, n), O.subflattening_index(ob, n))] / float(length)
+            assert abs(O.dense_split_score(S) - every[i]) <= SCORE_TOL, (k, i)
+            checked += 1
+    assert checked >= 36
 
 
 @pytest.mark.gpu
