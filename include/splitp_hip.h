@@ -290,6 +290,13 @@ int sp_score_plan_steps(sp_ctx* lane, sp_alignment* const* als, int n_al, sp_pla
 int sp_finish_flagged(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
                       double* scores_host, int32_t* status_host, int64_t* n_finished);
 
+/* ---------------------------------------------------------------- test entry --- */
+/* The library's stable segmented LSD radix sort (csrc/radix_sort.h: one-sweep, decoupled look-back) on host arrays, for
+ * tests only: n_seg independent segments of seg_len keys each, sorted on the bits [0, end_bit); keys as 64-bit words
+ * (key_bytes = 4: narrowed to 32 bits on the device), vals_host / vals_out optional 32-bit values carried with the keys. */
+int sp_debug_radix_sort(sp_ctx* ctx, const uint64_t* keys_host, const uint32_t* vals_host, int key_bytes, int64_t seg_len,
+                        int64_t n_seg, unsigned end_bit, uint64_t* keys_out, uint32_t* vals_out);
+
 #ifdef __cplusplus
 }
 #endif

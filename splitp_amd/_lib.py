@@ -37,7 +37,7 @@ SYMBOLS = (
     "sp_score_matrix_f64", "sp_score_coo_f64", "sp_divergence_matrix_f64", "sp_score_splits", "sp_score_splits_async",
     "sp_score_splits_multi_async", "sp_score_all_splits", "sp_score_all_splits_shard",
     "sp_plan_create", "sp_plan_retain", "sp_plan_release", "sp_plan_info", "sp_score_plan_async", "sp_score_plan_steps",
-    "sp_finish_flagged",
+    "sp_finish_flagged", "sp_debug_radix_sort",
 )
 
 
@@ -132,6 +132,7 @@ def load():
         "sp_score_plan_async": [vp, P(vp), i32, vp, vp, vp],
         "sp_score_plan_steps": [vp, P(vp), i32, vp, i32, vp, i64, vp, i64],
         "sp_finish_flagged": [vp, P(C.c_int32), P(C.c_int32), i64, P(dbl), P(C.c_int32), P(i64)],
+        "sp_debug_radix_sort": [vp, P(C.c_uint64), P(C.c_uint32), i32, i64, i64, C.c_uint, P(C.c_uint64), P(C.c_uint32)],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

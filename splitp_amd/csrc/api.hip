@@ -135,6 +135,7 @@ extern "C" int sp_ctx_create(int device, void* stream, sp_ctx** out) {
     if (const char* df = getenv("SPLITP_DIRECT_FINISH")) c->opt.direct_finish = df[0] != '0';
     c->opt.direct_all = env_flag("SPLITP_DIRECT_ALL");
     c->opt.eigen_block16 = env_flag("SPLITP_EIGEN_BLOCK16");
+    c->opt.sort_three_launch = env_flag("SPLITP_SORT_THREE_LAUNCH");
     *out = c;
     return SP_OK;
     });
@@ -155,6 +156,7 @@ static long long* option_slot(sp_ctx* c, const char* name, int** as_int) {
     else if (!strcmp(name, "direct_max_rows")) *as_int = &c->opt.direct_max_rows;
     else if (!strcmp(name, "direct_all")) *as_int = &c->opt.direct_all;
     else if (!strcmp(name, "eigen_block16")) *as_int = &c->opt.eigen_block16;
+    else if (!strcmp(name, "sort_three_launch")) *as_int = &c->opt.sort_three_launch;
     else if (!strcmp(name, "lds_cap")) return &c->opt.lds_cap;
     return nullptr;
 }
@@ -202,6 +204,7 @@ extern "C" int sp_ctx_destroy(sp_ctx* c) {
     delete c->cache;
     for (auto* b : bufs) b->release();
     for (auto& b : c->big) b.release();
+    for (auto& b : c->hist_work) b.release();
     if (c->side) {
         (void)hipStreamSynchronize(c->side);
         (void)hipStreamDestroy(c->side);

@@ -138,6 +138,7 @@ struct CtxOptions {
     int direct_finish = 1;      // flagged splits (status bit 0 / 1) end in the direct solver (finish.hip); 0: they stay flagged (SP_ENOCONV)
     int direct_max_rows = 0;    // largest smaller side (compact rows) the direct solver takes (0 = 16384)
     int direct_all = 0;         // dense route / generic matrices: the direct solver instead of the block iteration (test switch)
+    int sort_three_launch = 0;  // radix sorts (n > 12 histogram, big-table form) in round 3's three-launches-a-pass form instead of one-sweep
     int eigen_block16 = 0;      // dense route / generic matrices: rounds 1 - 3's 16-wide block pipeline (eigen.hip) instead of the
                                 // certified 4-wide kernel (eig4.hip) - kept as a cross-check
 };
@@ -179,6 +180,7 @@ struct sp_ctx {
     // ALL ZERO by the pass that reads it (no allocation, no memset per alignment); hist_clean = that invariant holds
     DevBuf hist_bins, hist_blk, hist_off;
     bool hist_clean = false;
+    DevBuf hist_work[6];   // sort-based histogram: sorted keys (2), runs, run lengths, result words, sort work (grow-only)
     // all-splits enumeration (subflat.hip: enumerate_all_splits) of the last (n, trivial, size, shard): kept between calls
     DevBuf enum_buf;
     long long enum_key[6] = {0, 0, 0, 0, 0, 0};

@@ -263,49 +263,85 @@ __global__ void k_widen_keys(const KT* __restrict__ in, int64_t D, u64* __restri
     if (i < D) out[i] = (u64)in[i];
 }
 
+// info[0] = number of runs (k_rle_write); this adds the last run's key (info[2..3]), its length (info[4]) and whether it is
+// the invalid-site marker (info[5]).  starts[r] = first position of run r, starts[nr] = number of sites.
+template <typename KT>
+__global__ void k_last_run(const KT* __restrict__ uniq, const u32* __restrict__ starts, u32* __restrict__ info) {
+    const u32 nr = info[0];
+    const unsigned long long k = nr ? (unsigned long long)uniq[nr - 1] : 0ull;
+    info[2] = (u32)k;
+    info[3] = (u32)(k >> 32);
+    info[4] = nr ? starts[nr] - starts[nr - 1] : 0u;
+    info[5] = (nr && uniq[nr - 1] == (KT)~(KT)0) ? 1u : 0u;
+}
+// keys widened to 64 bits, counts = lengths of the runs, weights = count / N and the largest count (info[6], zero at launch)
+// of the D kept runs
+template <typename KT>
+__global__ __launch_bounds__(256) void k_table_finish(const KT* __restrict__ uniq, const u32* __restrict__ starts, int64_t D,
+                                                      double n_sites, u64* __restrict__ keys, u32* __restrict__ counts,
+                                                      double* __restrict__ weights, u32* __restrict__ info) {
+    __shared__ u32 wmax[4];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 c = 0;
+    if (i < D) {
+        c = starts[i + 1] - starts[i];
+        keys[i] = (u64)uniq[i];
+        counts[i] = c;
+        weights[i] = (double)c / n_sites;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const u32 o = __shfl_xor(c, d, 64);
+        c = o > c ? o : c;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {   // one atomic per workgroup, and only if its maximum can still matter (one per wave: 30 us)
+        const u32 m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (m > __hip_atomic_load(&info[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&info[6], m);
+    }
+}
+
 template <typename KT>
 static int build_sorted(sp_ctx* ctx, const KT* dkeys, int64_t L, int n_taxa, sp_alignment** out) {
     SP_REQUIRE(L < ((int64_t)1 << 32), SP_ELIMIT, "sort-based histogram: at most 2^32 - 1 sites per call (got %lld)", (long long)L);
-    DevBuf sorted, sorted2, uniq, cnts, nruns, tmp;
-    auto cleanup = [&]() { sorted.release(); sorted2.release(); uniq.release(); cnts.release(); nruns.release(); tmp.release(); };
-    auto fail = [&](int code) { cleanup(); return code; };
+    // work buffers pooled in the context (six hipMalloc / hipFree per alignment cost more than the kernels: 1.7 ms of wall
+    // time for 0.37 ms of device time at 16 taxa x 1 M sites)
+    DevBuf &sorted = ctx->hist_work[0], &sorted2 = ctx->hist_work[1], &uniq = ctx->hist_work[2], &cnts = ctx->hist_work[3],
+           &nruns = ctx->hist_work[4], &tmp = ctx->hist_work[5];
+    auto fail = [&](int code) { return code; };
     const size_t l1 = (size_t)std::max<int64_t>(L, 1);
     int rc;
     if ((rc = sorted.ensure(l1 * sizeof(KT))) || (rc = sorted2.ensure(l1 * sizeof(KT))) || (rc = uniq.ensure(l1 * sizeof(KT))) ||
-        (rc = cnts.ensure(l1 * 4)) || (rc = nruns.ensure(16)))
+        (rc = cnts.ensure(l1 * 4)) || (rc = nruns.ensure(64)))
         return fail(rc);
     const unsigned end_bit = (unsigned)std::min<int>(2 * n_taxa + 1, 8 * (int)sizeof(KT));   // + 1: the marker's bit
-    u32 nr = 0;
+    u32 info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const u32* starts = nullptr;   // run starts (in `tmp`, alive until the table is finished)
     if (L > 0) {
         PhaseScope ps(ctx, SP_PHASE_HIST);
-        // (round 3: radix_sort.h - stable LSD passes of 8 bits by wave match + a run-length encode by head flags; rounds
+        // (radix_sort.h: stable one-sweep LSD passes of 8 bits by wave match + a run-length encode by head flags; rounds
         // 1 - 2 called rocprim::radix_sort_keys / run_length_encode here)
+        SP_HIP(hipMemsetAsync(nruns.p, 0, 32, ctx->stream));
         const KT* skeys = nullptr;
         if ((rc = rs_sort<KT>(ctx, dkeys, sorted.as<KT>(), sorted2.as<KT>(), nullptr, nullptr, nullptr, L, 1, end_bit, tmp, &skeys,
                               nullptr)))
             return fail(rc);
-        if ((rc = rs_run_length_encode<KT>(ctx, skeys, L, uniq.as<KT>(), cnts.as<u32>(), nruns.as<u32>(), tmp))) return fail(rc);
-        hipError_t e = hipMemcpyAsync(&nr, nruns.p, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if ((rc = rs_run_length_encode<KT>(ctx, skeys, L, uniq.as<KT>(), nullptr, nruns.as<u32>(), tmp, &starts))) return fail(rc);
+        hipLaunchKernelGGL(k_last_run<KT>, dim3(1), dim3(1), 0, ctx->stream, uniq.as<KT>(), starts, nruns.as<u32>());
+        hipError_t e = hipMemcpyAsync(info, nruns.p, 32, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             sp_set_error("sort-based histogram failed: %s", hipGetErrorString(e));
             return fail(SP_EHIP);
         }
     }
+    const u32 nr = info[0];
     int64_t D = nr, dropped = 0;
-    if (nr > 0) {   // the last run is the invalid-site marker if there were invalid sites
-        KT lastk = 0;
-        u32 lastc = 0;
-        hipError_t e = hipMemcpy(&lastk, uniq.as<KT>() + (nr - 1), sizeof(KT), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(&lastc, cnts.as<u32>() + (nr - 1), 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            sp_set_error("sort-based histogram: %s", hipGetErrorString(e));
-            return fail(SP_EHIP);
-        }
-        if (lastk == (KT)~(KT)0 && 2 * n_taxa < 8 * (int)sizeof(KT)) {
-            D -= 1;
-            dropped = lastc;
-        }
+    // the last run is the invalid-site marker if there were invalid sites
+    if (nr > 0 && info[5] && 2 * n_taxa < 8 * (int)sizeof(KT)) {
+        D -= 1;
+        dropped = info[4];
     }
     sp_alignment* al = new sp_alignment();
     al->ctx = ctx;
@@ -321,20 +357,14 @@ static int build_sorted(sp_ctx* ctx, const KT* dkeys, int64_t L, int n_taxa, sp_
     hipError_t e = hipSuccess;
     if (D > 0) {
         PhaseScope ps(ctx, SP_PHASE_HIST);
-        hipLaunchKernelGGL(k_widen_keys<KT>, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, uniq.as<KT>(), D,
-                           al->keys.as<u64>());
-        e = hipMemcpyAsync(al->counts.p, cnts.p, (size_t)D * 4, hipMemcpyDeviceToDevice, ctx->stream);
-        hipLaunchKernelGGL(k_counts_to_weights, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream,
-                           al->counts.as<u32>(), D, (double)al->N, al->weights.as<double>());
+        hipLaunchKernelGGL(k_table_finish<KT>, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, uniq.as<KT>(),
+                           starts, D, (double)al->N, al->keys.as<u64>(), al->counts.as<u32>(), al->weights.as<double>(),
+                           nruns.as<u32>());
+        e = hipMemcpyAsync(info, nruns.p, 32, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) {   // largest count -> limb count of the int8 Gram (one-time)
-            std::vector<u32> hc((size_t)D);
-            e = hipMemcpy(hc.data(), al->counts.p, (size_t)D * 4, hipMemcpyDeviceToHost);
-            for (u32 c : hc) al->max_count = std::max(al->max_count, c);
-        }
+        al->max_count = info[6];   // largest count -> limb count of the int8 Gram
     }
-    cleanup();
     if (e != hipSuccess) {
         sp_alignment_destroy(al);
         sp_set_error("sort-based histogram (compaction): %s", hipGetErrorString(e));
@@ -607,5 +637,60 @@ extern "C" int sp_simulate_alignment(sp_ctx* ctx, int n_nodes, const int32_t* pa
     }
     SP_HIP(hipStreamSynchronize(ctx->stream));   // the host arrays may die at return
     return build_from_device_keys(ctx, ctx->misc.p, keys32, L, n_taxa, out);
+    });
+}
+
+// Test entry (tests/test_gpu_direct.py::test_radix_sort_direct): the library's stable segmented radix sort on host
+// arrays - keys as 64-bit words (narrowed to 32 bits when key_bytes == 4), optional 32-bit values carried along - so that
+// segment counts, ragged tile ends and key widths the histogram / big-table callers never produce are checked against a
+// reference sort directly.  n = seg_len * n_seg elements in and out.
+extern "C" int sp_debug_radix_sort(sp_ctx* ctx, const uint64_t* keys_host, const uint32_t* vals_host, int key_bytes,
+                                   int64_t seg_len, int64_t n_seg, unsigned end_bit, uint64_t* keys_out, uint32_t* vals_out) {
+    return sp_guard("sp_debug_radix_sort", [&]() -> int {
+    SP_REQUIRE(ctx && keys_host && keys_out && (key_bytes == 4 || key_bytes == 8) && seg_len >= 0 && n_seg >= 0, SP_EINVAL,
+               "sp_debug_radix_sort: bad argument");
+    SP_REQUIRE(!vals_host == !vals_out, SP_EINVAL, "sp_debug_radix_sort: values in and out go together");
+    SP_HIP(hipSetDevice(ctx->device));
+    const int64_t n = seg_len * n_seg;
+    if (n == 0) return SP_OK;
+    DevBuf kin, ka, kb, vin, va, vb, work;
+    auto bail = [&](int code) {
+        kin.release(); ka.release(); kb.release(); vin.release(); va.release(); vb.release(); work.release();
+        return code;
+    };
+    int rc;
+    if ((rc = kin.ensure((size_t)n * 8)) || (rc = ka.ensure((size_t)n * 8)) || (rc = kb.ensure((size_t)n * 8)) ||
+        (rc = vin.ensure((size_t)n * 4)) || (rc = va.ensure((size_t)n * 4)) || (rc = vb.ensure((size_t)n * 4)))
+        return bail(rc);
+    if (key_bytes == 4) {
+        std::vector<u32> k32((size_t)n);
+        for (int64_t i = 0; i < n; ++i) k32[i] = (u32)keys_host[i];
+        if (hipMemcpy(kin.p, k32.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(SP_EHIP);
+    } else if (hipMemcpy(kin.p, keys_host, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        return bail(SP_EHIP);
+    }
+    if (vals_host && hipMemcpy(vin.p, vals_host, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(SP_EHIP);
+    const u32* sv = nullptr;
+    if (key_bytes == 4) {
+        const u32* sk = nullptr;
+        rc = rs_sort<u32>(ctx, kin.as<u32>(), ka.as<u32>(), kb.as<u32>(), vals_host ? vin.as<u32>() : nullptr, va.as<u32>(),
+                          vb.as<u32>(), seg_len, n_seg, end_bit, work, &sk, vals_host ? &sv : nullptr);
+        if (rc != SP_OK) return bail(rc);
+        std::vector<u32> k32((size_t)n);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+            hipMemcpy(k32.data(), sk, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return bail(SP_EHIP);
+        for (int64_t i = 0; i < n; ++i) keys_out[i] = k32[i];
+    } else {
+        const u64* sk = nullptr;
+        rc = rs_sort<u64>(ctx, kin.as<u64>(), ka.as<u64>(), kb.as<u64>(), vals_host ? vin.as<u32>() : nullptr, va.as<u32>(),
+                          vb.as<u32>(), seg_len, n_seg, end_bit, work, &sk, vals_host ? &sv : nullptr);
+        if (rc != SP_OK) return bail(rc);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+            hipMemcpy(keys_out, sk, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            return bail(SP_EHIP);
+    }
+    if (vals_host && hipMemcpy(vals_out, sv, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return bail(SP_EHIP);
+    return bail(SP_OK);
     });
 }

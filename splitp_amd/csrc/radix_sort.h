@@ -1,19 +1,31 @@
 // Hand-written LSD radix sort + run-length encode for gfx950 (round 3; replaces rocprim::radix_sort_keys /
 // run_length_encode in hist.hip and rocprim::segmented_radix_sort_pairs in sparse_big.hip).
 //
-// Stable least-significant-digit passes of RS_BITS = 8 bits.  One pass = three launches:
-//   k_rs_hist     one workgroup (256 threads, 4 waves) per tile of RS_TILE = 4096 keys: digit histogram of the tile in LDS
-//                 (wave-private rows, LDS atomics), written to hist[(segment * RADIX + digit) * blocks_per_segment + block]
-//   k_rs_scan     exclusive scan of that array in exactly that order - segment-major, then digit, then tile: the offsets of
-//                 an independent sort per segment (segments = equal-length contiguous pieces; 1 segment = a plain sort)
-//   k_rs_scatter  the tile again: every key's rank among the keys of its digit inside the tile, by WAVE MATCH - eight
-//                 ballots give a lane the mask of the lanes holding its digit, the rank inside the wave is a popcount below
-//                 the lane, and the (item, wave) segments of the tile are chained through a table of per-segment digit
-//                 counts in LDS (64 segments x 256 digits x u16 = 32 KB) scanned by digit - then out[offset + rank] = key
-//                 (and value).  Ranks follow the tile order (item-major, then wave, then lane), so the pass is STABLE, which
-//                 is what lets the passes compose into a sort; no atomics decide an order anywhere.
-// Keys are read coalesced (item j of lane t of a tile = base + j * 256 + t).  HBM traffic per pass: 2 reads + 1 write of the
-// key (+ value) arrays; a 1 M-key, 33-bit sort is 5 passes x 12 MB - launch-latency bound (15 launches), not bandwidth bound.
+// Stable least-significant-digit passes of RS_BITS = 8 bits over `segments` equal-length contiguous pieces (1 segment = a
+// plain sort).  ONE-SWEEP form (round 4, rs_sort): 2 + passes launches instead of 3 x passes.
+//   memset        digit totals, tile tickets and the look-back words of all passes
+//   k_os_hist     every key read once: the digit totals of EVERY pass per segment (the multiset of a segment's keys does
+//                 not change from pass to pass), LDS histogram per workgroup of RS_HTILES tiles, flushed by global atomics
+//                 (integers: any order)
+//   k_os_pass     one launch per pass, one workgroup (256 threads, 4 waves) per tile of RS_TILE = 4096 keys.  A tile takes
+//                 its number from a ticket counter (so every tile with a smaller number is already running or done), ranks
+//                 its keys by WAVE MATCH - eight ballots give a lane the mask of the lanes holding its digit, the rank inside
+//                 the wave is a popcount below the lane, and the 64 (item, wave) pieces of the tile are chained through a
+//                 table of per-piece digit counts in LDS (64 x 256 x u16 = 32 KB) scanned by digit - and learns where its
+//                 digits start from the tiles before it in the segment by DECOUPLED LOOK-BACK: thread d publishes
+//                 (AGGREGATE | count of digit d in this tile) in the tile's look-back word, walks back over the
+//                 predecessors' words (spinning on a word that is still empty) adding their aggregates until it meets an
+//                 INCLUSIVE PREFIX, and publishes its own inclusive prefix.  Flag and value share one 32-bit word written
+//                 and read with device-scope atomics: no fence, nothing is ever read that was not published whole.
+//                 The first tile of a segment publishes a prefix at once, so a chain never leaves its segment.
+//   Ranks follow the tile order (item-major, then wave, then lane) and tiles the array order, so every pass is STABLE - which
+//   is what lets the passes compose into a sort; no atomic decides an order anywhere (the ticket only names the tile).
+// Keys are read coalesced (item j of lane t of a tile = base + j * 256 + t).  HBM traffic: one read for the totals, then one
+// read + one write of the key (+ value) arrays per pass.
+// The three-launch form of round 3 (k_rs_hist: tile histograms -> k_rs_offsets: one workgroup per (segment, digit) row turns
+// the tile counts into offsets, per-digit totals accumulated atomically in one of two alternating buffers, the d == 0 block of
+// pass p zeroing the buffer pass p + 1 adds into -> k_rs_scatter) stays selectable (context option `sort_three_launch`) as the
+// cross-check of the look-back form.  k_rs_scan serves the run-length encode only.
 #pragma once
 #include "common.h"
 
@@ -23,6 +35,12 @@
 #define RS_WAVES (RS_THREADS / 64)
 #define RS_ITEMS 16
 #define RS_TILE (RS_THREADS * RS_ITEMS)
+#define RS_MAXPASS 8         // 64-bit keys
+#define RS_HTILES 1          // tiles per workgroup of the one-sweep histogram kernel (8: 31 workgroups for 1 M keys, 180 us)
+#define OS_LB 8              // predecessors whose look-back words a thread requests together
+#define OS_AGG 0x40000000u   // look-back word: flag in the two top bits (0 = not published yet), 30-bit count below
+#define OS_PREF 0x80000000u
+#define OS_MASK 0x3FFFFFFFu
 
 template <typename KT>
 __device__ __forceinline__ u32 rs_digit(KT key, int shift) { return (u32)((key >> shift) & (KT)(RS_RADIX - 1)); }
@@ -179,12 +197,249 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KT* __restrict_
     }
 }
 
+// ---- one-sweep form -------------------------------------------------------------------------------------------------------
+// ghist[(seg * n_pass + p) * RADIX + d] += keys of segment seg whose digit p is d.  Grid = n_seg * bph workgroups.
+// The upper digits of a site-pattern key take few values (33-bit keys: the last digit has two) - as one LDS atomic per key
+// and pass on a shared row the kernel spent 70 us on 1 M keys, 256 threads queueing on a handful of counters.  So the lanes
+// of a wave that hold the same digit are matched first (eight ballots, as in the pass kernel) and the first lane of each
+// group adds the group's size to a wave-private row: one atomic per distinct digit, wave and pass.
+template <typename KT>
+__global__ __launch_bounds__(RS_THREADS) void k_os_hist(const KT* __restrict__ keys, int64_t seg_len, int bph, int n_pass,
+                                                        u32* __restrict__ ghist) {
+    __shared__ u32 cnt[RS_WAVES][RS_MAXPASS][RS_RADIX];   // 32 KB
+    const int seg = blockIdx.x / bph, blk = blockIdx.x % bph;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < RS_WAVES * RS_MAXPASS * RS_RADIX; i += RS_THREADS) (&cnt[0][0][0])[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)seg * seg_len, lo = (int64_t)blk * RS_TILE * RS_HTILES;
+    const int64_t hi = lo + (int64_t)RS_TILE * RS_HTILES < seg_len ? lo + (int64_t)RS_TILE * RS_HTILES : seg_len;
+    for (int64_t t0 = lo; t0 < hi; t0 += RS_TILE) {   // (uniform trip counts: the ballots need whole waves)
+        KT kk[RS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) {   // all of the tile's loads in flight before the first ballot
+            const int64_t i = t0 + j * RS_THREADS + threadIdx.x;
+            kk[j] = i < hi ? keys[base + i] : (KT)0;
+        }
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) {
+            const bool in = t0 + j * RS_THREADS + threadIdx.x < hi;
+            const KT k = kk[j];
+            const unsigned long long inm = __ballot(in);
+#pragma unroll
+            for (int p = 0; p < RS_MAXPASS; ++p) {
+                if (p < n_pass) {
+                    const u32 d = rs_digit(k, p * RS_BITS);
+                    unsigned long long m = inm;
+#pragma unroll
+                    for (int b = 0; b < RS_BITS; ++b) {
+                        const unsigned long long bal = __ballot((d >> b) & 1u);
+                        m &= ((d >> b) & 1u) ? bal : ~bal;
+                    }
+                    if (in && (m & ((1ull << lane) - 1ull)) == 0) atomicAdd(&cnt[w][p][d], (u32)__popcll(m));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_pass * RS_RADIX; e += RS_THREADS) {
+        u32 c = 0;
+#pragma unroll
+        for (int ww = 0; ww < RS_WAVES; ++ww) c += (&cnt[ww][0][0])[e];
+        if (c) atomicAdd(&ghist[(size_t)seg * n_pass * RS_RADIX + e], c);
+    }
+}
+
+// One pass.  lookback: (tiles of all segments) x RADIX words of THIS pass, all zero at launch; ticket: this pass's counter.
+// ITEMS keys per thread: 16 (the 4096-key tile of the other kernels) or 8 - a sort of ~1 M keys has only 245 tiles of 4096, one
+// per CU and each a chain of dependent steps (load, 128 ballots, LDS scan, look-back, scatter); tiles of 2048 give every CU two.
+template <typename KT, bool VALUES, int ITEMS>
+__global__ __launch_bounds__(RS_THREADS) void k_os_pass(const KT* __restrict__ keys, const u32* __restrict__ vals,
+                                                        int64_t seg_len, int bps, int shift, int pass, int n_pass,
+                                                        const u32* __restrict__ ghist, u32* __restrict__ lookback,
+                                                        u32* __restrict__ ticket, KT* __restrict__ out_keys,
+                                                        u32* __restrict__ out_vals) {
+    __shared__ unsigned short segcnt[ITEMS * RS_WAVES][RS_RADIX];
+    __shared__ u32 dbase[RS_RADIX];
+    __shared__ u32 wsum[RS_WAVES];
+    __shared__ u32 s_tile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    for (int i = threadIdx.x; i < ITEMS * RS_WAVES * RS_RADIX / 2; i += RS_THREADS) reinterpret_cast<u32*>(&segcnt[0][0])[i] = 0;
+    __syncthreads();
+    const u32 tile = s_tile;
+    const int seg = (int)(tile / (u32)bps), blk = (int)(tile % (u32)bps);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)seg * seg_len, lo = (int64_t)blk * (RS_THREADS * ITEMS);
+    KT key[ITEMS];
+    u32 val[ITEMS];
+    unsigned short rank[ITEMS];
+    unsigned short dig[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int64_t i = lo + j * RS_THREADS + threadIdx.x;
+        const bool in = i < seg_len;
+        key[j] = in ? keys[base + i] : (KT)0;
+        if (VALUES) val[j] = in ? vals[base + i] : 0u;
+        const u32 d = rs_digit(key[j], shift);
+        unsigned long long m = __ballot(in);   // lanes of this wave with the same digit (and inside the array)
+#pragma unroll
+        for (int b = 0; b < RS_BITS; ++b) {
+            const unsigned long long bal = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        dig[j] = (unsigned short)d;
+        rank[j] = (unsigned short)__popcll(m & ((1ull << lane) - 1ull));
+        if (in && rank[j] == 0) segcnt[j * RS_WAVES + w][d] = (unsigned short)__popcll(m);   // (the first lane of the group)
+    }
+    __syncthreads();
+    // thread d: exclusive prefix of digit d over the 64 pieces (tile order = item-major, then wave); its total = the tile's
+    // count of digit d
+    const int d = threadIdx.x;   // RS_THREADS == RS_RADIX
+    u32 mine = 0;
+    {
+        unsigned int run = 0;
+#pragma unroll 8
+        for (int sgi = 0; sgi < ITEMS * RS_WAVES; ++sgi) {
+            const unsigned int c = segcnt[sgi][d];
+            segcnt[sgi][d] = (unsigned short)run;
+            run += c;
+        }
+        mine = run;
+    }
+    // where digit d starts in the segment: keys of smaller digits (exclusive scan of this pass's totals over the digits)
+    const u32 tot_d = ghist[((size_t)seg * n_pass + pass) * RS_RADIX + d];
+    u32 x = tot_d;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+        const u32 y = __shfl_up(x, k, 64);
+        if (lane >= k) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    u32 below = x - tot_d;
+    for (int i = 0; i < w; ++i) below += wsum[i];
+    // decoupled look-back over the earlier tiles of this segment
+    u32* const lb = lookback + (size_t)tile * RS_RADIX + d;
+    u32 excl = 0;
+    if (blk == 0) {
+        __hip_atomic_store(lb, OS_PREF | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __hip_atomic_store(lb, OS_AGG | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // OS_LB predecessors per round, their words requested together: when all tiles of a pass start at once no tile but
+        // the first holds a prefix yet and tile t walks back ~t / 2 words - one dependent L2 round trip each otherwise
+        const u32* p = lb - RS_RADIX;
+        bool done = false;
+        for (int back = 0; back < blk && !done; back += OS_LB, p -= OS_LB * RS_RADIX) {   // (ends at the segment's first tile)
+            u32 v[OS_LB];
+#pragma unroll
+            for (int u = 0; u < OS_LB; ++u)
+                v[u] = back + u < blk ? __hip_atomic_load(p - u * RS_RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : OS_PREF;
+#pragma unroll
+            for (int u = 0; u < OS_LB; ++u) {
+                if (!done) {
+                    u32 x = v[u];
+                    int spins = 0;
+                    // the tile holds a smaller ticket: it is running and publishes its aggregate without waiting for anybody.
+                    // (The spin is bounded all the same - ~50 ms - so that a defect could only ever produce a wrong order,
+                    // which the tests catch, never a wave that does not finish.)
+                    while ((x >> 30) == 0u && ++spins < (1 << 20)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        x = __hip_atomic_load(p - u * RS_RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    excl += x & OS_MASK;
+                    if (x & OS_PREF) done = true;
+                }
+            }
+        }
+        __hip_atomic_store(lb, OS_PREF | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    dbase[d] = (u32)((int64_t)seg * seg_len) + below + excl;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int64_t i = lo + j * RS_THREADS + threadIdx.x;
+        if (i < seg_len) {
+            const u32 dd = dig[j];
+            const size_t pos = (size_t)dbase[dd] + segcnt[j * RS_WAVES + w][dd] + rank[j];
+            out_keys[pos] = key[j];
+            if (VALUES) out_vals[pos] = val[j];
+        }
+    }
+}
+
+template <typename KT>
+static int rs_sort_three_launch(sp_ctx* ctx, const KT* keys_in, KT* keys_a, KT* keys_b, const u32* vals_in, u32* vals_a, u32* vals_b,
+                                int64_t seg_len, int64_t n_seg, unsigned end_bit, DevBuf& work, const KT** sorted_keys,
+                                const u32** sorted_vals);
+
 // Stable sort of `n_seg` independent segments of `seg_len` keys each (n_seg = 1: one array) on the bits [0, end_bit).
 // keys_in (and vals_in, optional values carried with the keys) are only read; the passes ping-pong between the two work
 // arrays keys_a / keys_b (vals_a / vals_b), n = seg_len * n_seg elements each, and the result ends up in *sorted_keys
-// (*sorted_vals), one of the two.  work: n_seg * RADIX * (tiles + 2) + 16 u32 (grown here).
+// (*sorted_vals), one of the two.  work: grown here (digit totals + tickets + one look-back word per tile, digit and pass).
 template <typename KT>
 static int rs_sort(sp_ctx* ctx, const KT* keys_in, KT* keys_a, KT* keys_b, const u32* vals_in, u32* vals_a, u32* vals_b,
+                   int64_t seg_len, int64_t n_seg, unsigned end_bit, DevBuf& work, const KT** sorted_keys,
+                   const u32** sorted_vals) {
+    if (ctx->opt.sort_three_launch)
+        return rs_sort_three_launch<KT>(ctx, keys_in, keys_a, keys_b, vals_in, vals_a, vals_b, seg_len, n_seg, end_bit, work,
+                                        sorted_keys, sorted_vals);
+    *sorted_keys = keys_in;
+    if (sorted_vals) *sorted_vals = vals_in;
+    if (seg_len <= 0 || n_seg <= 0 || end_bit == 0) return SP_OK;
+    const int n_pass = (int)((end_bit + RS_BITS - 1) / RS_BITS);
+    // (tiles of 2048 keys for sorts with fewer than two 4096-key tiles per CU measured no faster: 25 against 23 us a pass at 1 M keys)
+    const bool small_tiles = false;
+    const int64_t tile = RS_TILE;
+    const int64_t bps = (seg_len + tile - 1) / tile;
+    const int64_t blocks = bps * n_seg;
+    SP_REQUIRE(blocks < ((int64_t)1 << 31) && seg_len * n_seg < ((int64_t)1 << 32) && seg_len < ((int64_t)1 << 30) &&
+                   n_pass <= RS_MAXPASS,
+               SP_ELIMIT, "radix sort: %lld keys in %lld segments, %u key bits (limits: 2^32 keys, 2^30 per segment, 64 bits)",
+               (long long)(seg_len * n_seg), (long long)n_seg, end_bit);
+    const size_t n_tot = (size_t)n_seg * n_pass * RS_RADIX, n_lb = (size_t)blocks * RS_RADIX;
+    const size_t words = n_tot + 16 + (size_t)n_pass * n_lb;
+    SP_CHECK(work.ensure(words * 4));
+    u32* ghist = work.as<u32>();
+    u32* tickets = ghist + n_tot;
+    u32* lookback = tickets + 16;
+    SP_HIP(hipMemsetAsync(ghist, 0, words * 4, ctx->stream));
+    const int64_t bph = (seg_len + (int64_t)RS_TILE * RS_HTILES - 1) / ((int64_t)RS_TILE * RS_HTILES);
+    hipLaunchKernelGGL(k_os_hist<KT>, dim3((unsigned)(bph * n_seg)), dim3(RS_THREADS), 0, ctx->stream, keys_in, seg_len, (int)bph,
+                       n_pass, ghist);
+    const KT* src = keys_in;
+    const u32* vsrc = vals_in;
+    KT* dst = keys_a;
+    u32* vdst = vals_a;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        u32* lb = lookback + (size_t)pass * n_lb;
+        const dim3 grid((unsigned)blocks), blk(RS_THREADS);
+        const u32* nov = nullptr;
+        u32* nov_out = nullptr;
+        if (vals_in && small_tiles)
+            hipLaunchKernelGGL((k_os_pass<KT, true, RS_ITEMS / 2>), grid, blk, 0, ctx->stream, src, vsrc, seg_len, (int)bps,
+                               pass * RS_BITS, pass, n_pass, (const u32*)ghist, lb, tickets + pass, dst, vdst);
+        else if (vals_in)
+            hipLaunchKernelGGL((k_os_pass<KT, true, RS_ITEMS>), grid, blk, 0, ctx->stream, src, vsrc, seg_len, (int)bps,
+                               pass * RS_BITS, pass, n_pass, (const u32*)ghist, lb, tickets + pass, dst, vdst);
+        else if (small_tiles)
+            hipLaunchKernelGGL((k_os_pass<KT, false, RS_ITEMS / 2>), grid, blk, 0, ctx->stream, src, nov, seg_len, (int)bps,
+                               pass * RS_BITS, pass, n_pass, (const u32*)ghist, lb, tickets + pass, dst, nov_out);
+        else
+            hipLaunchKernelGGL((k_os_pass<KT, false, RS_ITEMS>), grid, blk, 0, ctx->stream, src, nov, seg_len, (int)bps,
+                               pass * RS_BITS, pass, n_pass, (const u32*)ghist, lb, tickets + pass, dst, nov_out);
+        SP_HIP(hipGetLastError());
+        src = dst;
+        vsrc = vdst;
+        dst = dst == keys_a ? keys_b : keys_a;
+        vdst = vdst == vals_a ? vals_b : vals_a;
+    }
+    *sorted_keys = src;
+    if (sorted_vals) *sorted_vals = vsrc;
+    return SP_OK;
+}
+
+// The three-launch form of round 3 (cross-check of the one-sweep form: context option `sort_three_launch`).
+template <typename KT>
+static int rs_sort_three_launch(sp_ctx* ctx, const KT* keys_in, KT* keys_a, KT* keys_b, const u32* vals_in, u32* vals_a, u32* vals_b,
                    int64_t seg_len, int64_t n_seg, unsigned end_bit, DevBuf& work, const KT** sorted_keys,
                    const u32** sorted_vals) {
     *sorted_keys = keys_in;
@@ -297,8 +552,10 @@ static __global__ void k_rle_counts(const u32* __restrict__ starts, const u32* _
 
 // uniq[r], counts[r] for the runs of the sorted array s[0 .. n); n_runs_dev[0] = number of runs (device word).
 // work: (tiles + n + 32) u32.  n < 2^32.
+// counts == nullptr: the run lengths are left to the caller, who finds the run starts (+ the sentinel n) at *starts_out.
 template <typename KT>
-static int rs_run_length_encode(sp_ctx* ctx, const KT* s, int64_t n, KT* uniq, u32* counts, u32* n_runs_dev, DevBuf& work) {
+static int rs_run_length_encode(sp_ctx* ctx, const KT* s, int64_t n, KT* uniq, u32* counts, u32* n_runs_dev, DevBuf& work,
+                                const u32** starts_out = nullptr) {
     if (n <= 0) {
         SP_HIP(hipMemsetAsync(n_runs_dev, 0, 4, ctx->stream));
         return SP_OK;
@@ -311,8 +568,10 @@ static int rs_run_length_encode(sp_ctx* ctx, const KT* s, int64_t n, KT* uniq, u
     hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, ctx->stream, heads, tiles);
     hipLaunchKernelGGL(k_rle_write<KT>, dim3((unsigned)tiles), dim3(RS_THREADS), 0, ctx->stream, s, n, (const u32*)heads, tiles, uniq,
                        starts, n_runs_dev);
-    hipLaunchKernelGGL(k_rle_counts, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const u32*)starts, (const u32*)n_runs_dev, counts);
+    if (starts_out) *starts_out = starts;
+    if (counts)
+        hipLaunchKernelGGL(k_rle_counts, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const u32*)starts, (const u32*)n_runs_dev, counts);
     SP_HIP(hipGetLastError());
     return SP_OK;
 }

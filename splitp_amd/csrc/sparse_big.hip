@@ -110,28 +110,64 @@ __device__ __forceinline__ void spkb_product(const u32* __restrict__ keys, const
 
 // Sorted order of every split -> chunk-interleaved streams for spkb_product: position j of a segment (thread j / chunk,
 // element j % chunk) goes to (j % chunk) * SPK_THREADS + j / chunk of the segment's padded block of chunk * SPK_THREADS.
+// That is the transpose of a [SPK_THREADS][chunk] matrix, done in 32 x 32 tiles through LDS (round 4): a workgroup reads 32
+// runs of 32 consecutive sorted positions (coalesced: key, pattern index), fetches the pattern's other coordinate and count
+// (the two gathers nothing avoids) and writes 32 runs of 32 consecutive destination words.  (Round 3's form - one thread per
+// destination word, every one of its four reads 122 words from its neighbour's - took 1.5 ms per 84 M entries, 9 of the
+// 48 ms of a 2035-split call on a 124 k-pattern table.)
+#define GS_T 32
 template <typename CT>
-__global__ void k_gather_sorted(const u32* __restrict__ key_sorted, const u32* __restrict__ perm,
-                                const u32* __restrict__ other_by_pattern, const CT* __restrict__ counts, int64_t D,
-                                int64_t total, u32* __restrict__ key_i, u32* __restrict__ minor_i, CT* __restrict__ cnt_i) {
-    // (one thread per DESTINATION word: the three stores of a wave are consecutive; scattered 4-byte stores - one thread
-    // per source position - made this kernel as expensive as the iteration itself)
+__global__ __launch_bounds__(256) void k_gather_sorted(const u32* __restrict__ key_sorted, const u32* __restrict__ perm,
+                                                       const u32* __restrict__ other_by_pattern, const CT* __restrict__ counts,
+                                                       int64_t D, int n_ct, int64_t S, u32* __restrict__ key_i,
+                                                       u32* __restrict__ minor_i, CT* __restrict__ cnt_i) {
+    __shared__ u32 tk[GS_T][GS_T + 1], tm[GS_T][GS_T + 1];
+    __shared__ CT tc[GS_T][GS_T + 1];
     const int64_t chunk = (D + SPK_THREADS - 1) / SPK_THREADS;
     const int64_t dpad = chunk * SPK_THREADS;
-    const int64_t dst = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (dst >= total) return;   // total = segments * dpad here
-    const int64_t seg = dst / dpad, r = dst % dpad;
-    const int64_t j = (r % SPK_THREADS) * chunk + r / SPK_THREADS;
-    if (j >= D) return;         // padding: never read
-    const int64_t g = seg * D + j;
-    const u32 p = perm[g];
-    key_i[dst] = key_sorted[g];
-    minor_i[dst] = other_by_pattern[seg * D + p];
-    cnt_i[dst] = counts[p];
+    // grid: x = tile of the chunk axis (n_ct = ceil(chunk / 32)) + 32-thread tile (SPK_THREADS / 32) * n_ct, y = segment
+    const int ct = (int)(blockIdx.x % (unsigned)n_ct), tt = (int)(blockIdx.x / (unsigned)n_ct);
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8
+    for (int64_t seg = blockIdx.y; seg < S; seg += gridDim.y) {
+#pragma unroll
+    for (int r = 0; r < GS_T; r += 8) {
+        const int64_t thr = (int64_t)tt * GS_T + ly + r, c = (int64_t)ct * GS_T + lx;   // sorted position j = thr * chunk + c
+        const int64_t j = thr * chunk + c;
+        u32 k = 0, m = 0;
+        CT cv = (CT)0;
+        if (c < chunk && j < D) {
+            const int64_t g = seg * D + j;
+            const u32 pidx = perm[g];
+            k = key_sorted[g];
+            m = other_by_pattern[seg * D + pidx];
+            cv = counts[pidx];
+        }
+        tk[ly + r][lx] = k;
+        tm[ly + r][lx] = m;
+        tc[ly + r][lx] = cv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < GS_T; r += 8) {
+        const int64_t c = (int64_t)ct * GS_T + ly + r, thr = (int64_t)tt * GS_T + lx;   // destination (c, thr): c * SPK_THREADS + thr
+        if (c < chunk && thr * chunk + c < D) {
+            const int64_t dst = seg * dpad + c * SPK_THREADS + thr;
+            key_i[dst] = tk[lx][ly + r];
+            minor_i[dst] = tm[lx][ly + r];
+            cnt_i[dst] = tc[lx][ly + r];
+        }
+    }
+    __syncthreads();   // (the tiles are reused by the next segment of this workgroup)
+    }
 }
 
 // CT = u32: count table (trace exact in u64);  CT = double: float-weight table (trace summed in a fixed tree).
-template <typename CT>
+// WIDE = false: the 4-wide certified iteration; a split without a certified gap after SPKB_MAXHALF half products leaves
+// with status bit 1.  WIDE = true: the second launch - the 8-wide fallback block for exactly those splits (a workgroup whose
+// splits all certified returns at once).  Two kernels instead of one body (round 4): with the wide block's Jacobi and 8-column
+// passes inlined next to the hot loop the kernel spilled 585 vector registers (1.1 KB of scratch per lane); apart, the
+// 4-wide kernel spills none in its loops.
+template <typename CT, bool WIDE>
 __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, const u32* __restrict__ rr_all,
                                                             const u32* __restrict__ keyc_all, const u32* __restrict__ minc_all,
                                                             const CT* __restrict__ cntc_all,
@@ -149,6 +185,11 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
                               ((sizeof(EigShared) + 15) & ~(size_t)15) + 16;
     const int D = (int)D64;
     double* slab = slabs + (size_t)blockIdx.x * slab_doubles;
+    if (WIDE) {   // anything to do?  (uniform: every thread reads the same status words)
+        bool any = false;
+        for (int sid = blockIdx.x; sid < S; sid += gridDim.x) any = any || (status[sid] & 2) != 0;
+        if (!any) return;
+    }
     // trace = sum count^2 (exact in u64 for counts) and the 4 heaviest patterns, once per workgroup
     double trace;
     if (std::is_same<CT, u32>::value) {
@@ -214,6 +255,12 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
     }
     for (int sid = blockIdx.x; sid < S; sid += gridDim.x) {
         const int R = dims[sid].x, C = dims[sid].y;
+        int it_before = 0;
+        if (WIDE) {
+            const int st_in = status[sid];
+            if (!(st_in & 2)) continue;
+            it_before = st_in >> 8;
+        }
         if (min(R, C) <= 4 || !(trace > 0)) {
             if (threadIdx.x == 0) {
                 scores[sid] = trace > 0 ? 0.0 : __builtin_nan("");
@@ -269,7 +316,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
         double prev_sum = 0, prev_delta = 0, prev_ratio = 1.0, top4 = 0, prev_th5 = 0, prev_d5 = 0, prev_sum8 = 0;
         int wide_settled = 0;
         int it = 0, conv = 0;
-        for (it = 1; it <= SPKB_MAXHALF; ++it) {
+        for (it = 1; !WIDE && it <= SPKB_MAXHALF; ++it) {
             const bool odd = it & 1;   // odd: W = C^T V (column order)   even: V = C W (row order)
             double* X = odd ? W : V;
             const int rows = odd ? C : R;
@@ -286,10 +333,11 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
             }
             spk_orth(X, rows, 4, 1, sh);
         }
-        if (!conv) {
+        if (WIDE) {
             // no certified gap behind the 4th value after SPKB_MAXHALF half products (clustered / slowly decaying
             // spectrum): the 8-wide fallback block of the list kernels, on the same sorted orders (two 4-column passes)
-            for (int i = threadIdx.x; i < Vp; i += SPK_THREADS) {   // columns 0..3: the block so far, 4..7: noise
+            it = it_before;
+            for (int i = threadIdx.x; i < Vp; i += SPK_THREADS) {   // columns 0..3: the start block again, 4..7: noise
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     V8[(size_t)k * Vp + i] = i < R ? V[(size_t)i * 4 + k] : 0.0;
@@ -325,7 +373,8 @@ __global__ __launch_bounds__(SPK_THREADS) void k_sparse_big(int64_t D64, int S, 
         if (threadIdx.x == 0) {
             const double op = 1.0 - top4 / trace;
             scores[sid] = sqrt(op > 0 ? op : 0.0);
-            status[sid] = (conv ? 0 : 1) | (it << 8);
+            // 4-wide kernel: bit 1 = for the wide kernel queued behind; wide kernel: bit 0 = no certificate (direct solver)
+            status[sid] = (conv ? 0 : (WIDE ? 1 : 2)) | (it << 8);
         }
         __syncthreads();
     }
@@ -359,18 +408,25 @@ static int big_run_kernel(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, cons
         (rc = cntr.ensure(padded * sizeof(CT))) || (rc = kci.ensure(padded * 4)) || (rc = kri.ensure(padded * 4)) ||
         (rc = slabs.ensure((size_t)grid * slab_doubles * 8)))
         return fail(rc);
-    const dim3 gg((unsigned)((padded + 255) / 256));
-    hipLaunchKernelGGL(k_gather_sorted<CT>, gg, dim3(256), 0, ctx->stream, keyc, permc, rr, counts, D, (int64_t)padded,
-                       kci.as<u32>(), minc.as<u32>(), cntc.as<CT>());   // column order: the minor index is the row
-    hipLaunchKernelGGL(k_gather_sorted<CT>, gg, dim3(256), 0, ctx->stream, keyr, permr, cc, counts, D, (int64_t)padded,
-                       kri.as<u32>(), minr.as<u32>(), cntr.as<CT>());   // row order: the minor index is the column
+    const int64_t chunk_g = (D + SPK_THREADS - 1) / SPK_THREADS;
+    const int n_ct = (int)((chunk_g + GS_T - 1) / GS_T);
+    const dim3 gg((unsigned)(n_ct * (SPK_THREADS / GS_T)), (unsigned)std::min<int64_t>(S, 65535));
+    hipLaunchKernelGGL(k_gather_sorted<CT>, gg, dim3(256), 0, ctx->stream, keyc, permc, rr, counts, D, n_ct, S, kci.as<u32>(),
+                       minc.as<u32>(), cntc.as<CT>());   // column order: the minor index is the row
+    hipLaunchKernelGGL(k_gather_sorted<CT>, gg, dim3(256), 0, ctx->stream, keyr, permr, cc, counts, D, n_ct, S, kri.as<u32>(),
+                       minr.as<u32>(), cntr.as<CT>());   // row order: the minor index is the column
     const size_t lds = SPK_LDS_BYTES;   // shared structs + one or both 4-wide blocks of short sides
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_big<CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_big<CT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_big<CT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
         sp_set_error("big-table form: cannot reserve %zu bytes of LDS", lds);
         return fail(SP_EHIP);
     }
-    hipLaunchKernelGGL(k_sparse_big<CT>, dim3(grid), dim3(SPK_THREADS), lds, ctx->stream, D, (int)S, rr, kci.as<u32>(),
+    hipLaunchKernelGGL((k_sparse_big<CT, false>), dim3(grid), dim3(SPK_THREADS), lds, ctx->stream, D, (int)S, rr, kci.as<u32>(),
+                       minc.as<u32>(), cntc.as<CT>(), kri.as<u32>(), minr.as<u32>(), cntr.as<CT>(), counts, dims,
+                       slabs.as<double>(), slab_doubles, scores, status);
+    hipLaunchKernelGGL((k_sparse_big<CT, true>), dim3(grid), dim3(SPK_THREADS), lds, ctx->stream, D, (int)S, rr, kci.as<u32>(),
                        minc.as<u32>(), cntc.as<CT>(), kri.as<u32>(), minr.as<u32>(), cntr.as<CT>(), counts, dims,
                        slabs.as<double>(), slab_doubles, scores, status);
     hipError_t e = hipGetLastError();

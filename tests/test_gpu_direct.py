@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 SCORE_TOL = 1e-10
 OPTIONS = (("force_big", 0), ("big_by_keys", 0), ("lds_cap", 0), ("wide_cap", 0), ("direct_finish", 1), ("direct_all", 0),
-           ("direct_max_rows", 0))
+           ("direct_max_rows", 0), ("sort_three_launch", 0), ("eigen_block16", 0))
 
 
 @pytest.fixture(scope="module")
@@ -211,3 +211,42 @@ def test_direct_solver_bigger_sides_12_taxa(sp):
     got2, st2 = sp.score_splits(dev, splits, return_status=True)
     assert not np.any(st2 & 3) and np.abs(got2 - want).max() <= SCORE_TOL
     assert np.count_nonzero(st2 & 4) >= np.count_nonzero(st & 4)
+
+
+def test_radix_sort_direct(sp):
+    """csrc/radix_sort.h through its test entry: random 32- and 64-bit keys with values, one and many segments,
+    segment lengths around the 4096-key tile (4095 / 4096 / 4097, a single key, 3 tiles + 1), key widths that are no multiple
+    of the 8-bit digit (17, 33, 41 bits) - against numpy's stable argsort per segment; the one-sweep (decoupled look-back)
+    form and round 3's three-launch form must agree bit for bit."""
+    import ctypes as C
+
+    from splitp_amd import _lib
+
+    ctx = sp.get_context()
+    lib = ctx._lib
+    rng = np.random.default_rng(99)
+    cases = [(4, 1, 1, 9), (4, 4095, 1, 17), (4, 4096, 3, 17), (4, 4097, 5, 24), (4, 12289, 7, 32), (8, 4097, 3, 33),
+             (8, 100_000, 2, 41), (8, 5000, 64, 40), (4, 300_000, 1, 29), (4, 777, 257, 13)]
+    for key_bytes, seg_len, n_seg, bits in cases:
+        n = seg_len * n_seg
+        keys = rng.integers(0, 1 << bits, size=n, dtype=np.uint64)
+        if seg_len > 2000:
+            keys[: n // 3] &= np.uint64(0xFF)          # heavy duplicates: stability matters
+        vals = np.arange(n, dtype=np.uint32)
+        outs = []
+        for legacy in (0, 1):
+            ctx.set_option("sort_three_launch", legacy)
+            ko, vo = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint32)
+            _lib.check(lib.sp_debug_radix_sort(ctx.handle, _lib._ptr(keys, C.c_uint64), _lib._ptr(vals, C.c_uint32), key_bytes,
+                                               seg_len, n_seg, bits, _lib._ptr(ko, C.c_uint64), _lib._ptr(vo, C.c_uint32)))
+            outs.append((ko, vo))
+        ctx.set_option("sort_three_launch", 0)
+        want_v = np.concatenate([s * seg_len + np.argsort(keys[s * seg_len:(s + 1) * seg_len], kind="stable")
+                                 for s in range(n_seg)]).astype(np.uint32)
+        assert np.array_equal(outs[0][1], want_v), (key_bytes, seg_len, n_seg, bits)
+        assert np.array_equal(outs[0][0], keys[want_v]), (key_bytes, seg_len, n_seg, bits)
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        ko = np.zeros(n, dtype=np.uint64)                          # keys only
+        _lib.check(lib.sp_debug_radix_sort(ctx.handle, _lib._ptr(keys, C.c_uint64), None, key_bytes, seg_len, n_seg, bits,
+                                           _lib._ptr(ko, C.c_uint64), None))
+        assert np.array_equal(ko, keys[want_v])
