@@ -157,6 +157,7 @@ static long long* option_slot(sp_ctx* c, const char* name, int** as_int) {
     else if (!strcmp(name, "direct_all")) *as_int = &c->opt.direct_all;
     else if (!strcmp(name, "eigen_block16")) *as_int = &c->opt.eigen_block16;
     else if (!strcmp(name, "sort_three_launch")) *as_int = &c->opt.sort_three_launch;
+    else if (!strcmp(name, "sort_digit_bits")) *as_int = &c->opt.sort_digit_bits;
     else if (!strcmp(name, "lds_cap")) return &c->opt.lds_cap;
     return nullptr;
 }

@@ -139,6 +139,7 @@ struct CtxOptions {
     int direct_max_rows = 0;    // largest smaller side (compact rows) the direct solver takes (0 = 16384)
     int direct_all = 0;         // dense route / generic matrices: the direct solver instead of the block iteration (test switch)
     int sort_three_launch = 0;  // radix sorts (n > 12 histogram, big-table form) in round 3's three-launches-a-pass form instead of one-sweep
+    int sort_digit_bits = 0;    // one-sweep sorts: 9 = 9-bit digits (test switch; measured slower per pass than the pass they save), else 8
     int eigen_block16 = 0;      // dense route / generic matrices: rounds 1 - 3's 16-wide block pipeline (eigen.hip) instead of the
                                 // certified 4-wide kernel (eig4.hip) - kept as a cross-check
 };

@@ -35,7 +35,6 @@
 #define RS_WAVES (RS_THREADS / 64)
 #define RS_ITEMS 16
 #define RS_TILE (RS_THREADS * RS_ITEMS)
-#define RS_MAXPASS 8         // 64-bit keys
 #define RS_HTILES 1          // tiles per workgroup of the one-sweep histogram kernel (8: 31 workgroups for 1 M keys, 180 us)
 #define OS_LB 8              // predecessors whose look-back words a thread requests together
 #define OS_AGG 0x40000000u   // look-back word: flag in the two top bits (0 = not published yet), 30-bit count below
@@ -198,18 +197,25 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KT* __restrict_
 }
 
 // ---- one-sweep form -------------------------------------------------------------------------------------------------------
+// Digit width BITS = 8 (default) or 9 (option `sort_digit_bits`: one pass fewer on 17-, 33- and 41-bit keys, slower per pass -
+// see rs_sort_nine_bit_digits).  RADIX = 2^BITS; a thread owns RADIX / 256 digits.
+template <typename KT, int BITS>
+__device__ __forceinline__ u32 os_digit(KT key, int shift) { return (u32)((key >> shift) & (KT)((1u << BITS) - 1u)); }
+
 // ghist[(seg * n_pass + p) * RADIX + d] += keys of segment seg whose digit p is d.  Grid = n_seg * bph workgroups.
 // The upper digits of a site-pattern key take few values (33-bit keys: the last digit has two) - as one LDS atomic per key
 // and pass on a shared row the kernel spent 70 us on 1 M keys, 256 threads queueing on a handful of counters.  So the lanes
-// of a wave that hold the same digit are matched first (eight ballots, as in the pass kernel) and the first lane of each
+// of a wave that hold the same digit are matched first (BITS ballots, as in the pass kernel) and the first lane of each
 // group adds the group's size to a wave-private row: one atomic per distinct digit, wave and pass.
-template <typename KT>
+template <typename KT, int BITS>
 __global__ __launch_bounds__(RS_THREADS) void k_os_hist(const KT* __restrict__ keys, int64_t seg_len, int bph, int n_pass,
                                                         u32* __restrict__ ghist) {
-    __shared__ u32 cnt[RS_WAVES][RS_MAXPASS][RS_RADIX];   // 32 KB
+    constexpr int RADIX = 1 << BITS;
+    constexpr int MAXP = (int)(8 * sizeof(KT) + BITS - 1) / BITS;   // passes a key of this width can need
+    __shared__ u32 cnt[RS_WAVES][MAXP][RADIX];   // <= 64 KB
     const int seg = blockIdx.x / bph, blk = blockIdx.x % bph;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < RS_WAVES * RS_MAXPASS * RS_RADIX; i += RS_THREADS) (&cnt[0][0][0])[i] = 0;
+    for (int i = threadIdx.x; i < RS_WAVES * MAXP * RADIX; i += RS_THREADS) (&cnt[0][0][0])[i] = 0;
     __syncthreads();
     const int64_t base = (int64_t)seg * seg_len, lo = (int64_t)blk * RS_TILE * RS_HTILES;
     const int64_t hi = lo + (int64_t)RS_TILE * RS_HTILES < seg_len ? lo + (int64_t)RS_TILE * RS_HTILES : seg_len;
@@ -226,12 +232,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_hist(const KT* __restrict__ k
             const KT k = kk[j];
             const unsigned long long inm = __ballot(in);
 #pragma unroll
-            for (int p = 0; p < RS_MAXPASS; ++p) {
+            for (int p = 0; p < MAXP; ++p) {
                 if (p < n_pass) {
-                    const u32 d = rs_digit(k, p * RS_BITS);
+                    const u32 d = os_digit<KT, BITS>(k, p * BITS);
                     unsigned long long m = inm;
 #pragma unroll
-                    for (int b = 0; b < RS_BITS; ++b) {
+                    for (int b = 0; b < BITS; ++b) {
                         const unsigned long long bal = __ballot((d >> b) & 1u);
                         m &= ((d >> b) & 1u) ? bal : ~bal;
                     }
@@ -241,48 +247,48 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_hist(const KT* __restrict__ k
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n_pass * RS_RADIX; e += RS_THREADS) {
+    for (int e = threadIdx.x; e < n_pass * RADIX; e += RS_THREADS) {
         u32 c = 0;
 #pragma unroll
         for (int ww = 0; ww < RS_WAVES; ++ww) c += (&cnt[ww][0][0])[e];
-        if (c) atomicAdd(&ghist[(size_t)seg * n_pass * RS_RADIX + e], c);
+        if (c) atomicAdd(&ghist[(size_t)seg * n_pass * RADIX + e], c);
     }
 }
 
 // One pass.  lookback: (tiles of all segments) x RADIX words of THIS pass, all zero at launch; ticket: this pass's counter.
-// ITEMS keys per thread: 16 (the 4096-key tile of the other kernels) or 8 - a sort of ~1 M keys has only 245 tiles of 4096, one
-// per CU and each a chain of dependent steps (load, 128 ballots, LDS scan, look-back, scatter); tiles of 2048 give every CU two.
-template <typename KT, bool VALUES, int ITEMS>
+template <typename KT, bool VALUES, int BITS>
 __global__ __launch_bounds__(RS_THREADS) void k_os_pass(const KT* __restrict__ keys, const u32* __restrict__ vals,
                                                         int64_t seg_len, int bps, int shift, int pass, int n_pass,
                                                         const u32* __restrict__ ghist, u32* __restrict__ lookback,
                                                         u32* __restrict__ ticket, KT* __restrict__ out_keys,
                                                         u32* __restrict__ out_vals) {
-    __shared__ unsigned short segcnt[ITEMS * RS_WAVES][RS_RADIX];
-    __shared__ u32 dbase[RS_RADIX];
-    __shared__ u32 wsum[RS_WAVES];
+    constexpr int RADIX = 1 << BITS;
+    constexpr int NDIG = RADIX / RS_THREADS;   // digits a thread owns: d = threadIdx.x + q * RS_THREADS
+    __shared__ unsigned short segcnt[RS_ITEMS * RS_WAVES][RADIX];   // 32 / 64 KB
+    __shared__ u32 dbase[RADIX];
+    __shared__ u32 wsum[NDIG][RS_WAVES];
     __shared__ u32 s_tile;
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-    for (int i = threadIdx.x; i < ITEMS * RS_WAVES * RS_RADIX / 2; i += RS_THREADS) reinterpret_cast<u32*>(&segcnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < RS_ITEMS * RS_WAVES * RADIX / 2; i += RS_THREADS) reinterpret_cast<u32*>(&segcnt[0][0])[i] = 0;
     __syncthreads();
     const u32 tile = s_tile;
     const int seg = (int)(tile / (u32)bps), blk = (int)(tile % (u32)bps);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t base = (int64_t)seg * seg_len, lo = (int64_t)blk * (RS_THREADS * ITEMS);
-    KT key[ITEMS];
-    u32 val[ITEMS];
-    unsigned short rank[ITEMS];
-    unsigned short dig[ITEMS];
+    const int64_t base = (int64_t)seg * seg_len, lo = (int64_t)blk * RS_TILE;
+    KT key[RS_ITEMS];
+    u32 val[RS_ITEMS];
+    unsigned short rank[RS_ITEMS];
+    unsigned short dig[RS_ITEMS];
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
+    for (int j = 0; j < RS_ITEMS; ++j) {
         const int64_t i = lo + j * RS_THREADS + threadIdx.x;
         const bool in = i < seg_len;
         key[j] = in ? keys[base + i] : (KT)0;
         if (VALUES) val[j] = in ? vals[base + i] : 0u;
-        const u32 d = rs_digit(key[j], shift);
+        const u32 d = os_digit<KT, BITS>(key[j], shift);
         unsigned long long m = __ballot(in);   // lanes of this wave with the same digit (and inside the array)
 #pragma unroll
-        for (int b = 0; b < RS_BITS; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const unsigned long long bal = __ballot((d >> b) & 1u);
             m &= ((d >> b) & 1u) ? bal : ~bal;
         }
@@ -291,71 +297,83 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_pass(const KT* __restrict__ k
         if (in && rank[j] == 0) segcnt[j * RS_WAVES + w][d] = (unsigned short)__popcll(m);   // (the first lane of the group)
     }
     __syncthreads();
-    // thread d: exclusive prefix of digit d over the 64 pieces (tile order = item-major, then wave); its total = the tile's
-    // count of digit d
-    const int d = threadIdx.x;   // RS_THREADS == RS_RADIX
-    u32 mine = 0;
-    {
+    // per owned digit: exclusive prefix over the 64 pieces (tile order = item-major, then wave); its total = the tile's count
+    u32 mine[NDIG], tot_d[NDIG], x[NDIG];
+#pragma unroll
+    for (int q = 0; q < NDIG; ++q) {
+        const int d = threadIdx.x + q * RS_THREADS;
         unsigned int run = 0;
 #pragma unroll 8
-        for (int sgi = 0; sgi < ITEMS * RS_WAVES; ++sgi) {
+        for (int sgi = 0; sgi < RS_ITEMS * RS_WAVES; ++sgi) {
             const unsigned int c = segcnt[sgi][d];
             segcnt[sgi][d] = (unsigned short)run;
             run += c;
         }
-        mine = run;
-    }
-    // where digit d starts in the segment: keys of smaller digits (exclusive scan of this pass's totals over the digits)
-    const u32 tot_d = ghist[((size_t)seg * n_pass + pass) * RS_RADIX + d];
-    u32 x = tot_d;
+        mine[q] = run;
+        // where digit d starts in the segment: keys of smaller digits (exclusive scan of this pass's totals over the digits)
+        tot_d[q] = ghist[((size_t)seg * n_pass + pass) * RADIX + d];
+        u32 xx = tot_d[q];
 #pragma unroll
-    for (int k = 1; k < 64; k <<= 1) {
-        const u32 y = __shfl_up(x, k, 64);
-        if (lane >= k) x += y;
+        for (int k = 1; k < 64; k <<= 1) {
+            const u32 y = __shfl_up(xx, k, 64);
+            if (lane >= k) xx += y;
+        }
+        x[q] = xx;
+        if (lane == 63) wsum[q][w] = xx;
     }
-    if (lane == 63) wsum[w] = x;
     __syncthreads();
-    u32 below = x - tot_d;
-    for (int i = 0; i < w; ++i) below += wsum[i];
-    // decoupled look-back over the earlier tiles of this segment
-    u32* const lb = lookback + (size_t)tile * RS_RADIX + d;
-    u32 excl = 0;
-    if (blk == 0) {
-        __hip_atomic_store(lb, OS_PREF | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        __hip_atomic_store(lb, OS_AGG | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // OS_LB predecessors per round, their words requested together: when all tiles of a pass start at once no tile but
-        // the first holds a prefix yet and tile t walks back ~t / 2 words - one dependent L2 round trip each otherwise
-        const u32* p = lb - RS_RADIX;
-        bool done = false;
-        for (int back = 0; back < blk && !done; back += OS_LB, p -= OS_LB * RS_RADIX) {   // (ends at the segment's first tile)
-            u32 v[OS_LB];
+    u32 carry = 0;   // totals of the digit blocks before block q
 #pragma unroll
-            for (int u = 0; u < OS_LB; ++u)
-                v[u] = back + u < blk ? __hip_atomic_load(p - u * RS_RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : OS_PREF;
+    for (int q = 0; q < NDIG; ++q) {
+        const int d = threadIdx.x + q * RS_THREADS;
+        u32 below = carry + x[q] - tot_d[q];
+        u32 blocksum = 0;
 #pragma unroll
-            for (int u = 0; u < OS_LB; ++u) {
-                if (!done) {
-                    u32 x = v[u];
-                    int spins = 0;
-                    // the tile holds a smaller ticket: it is running and publishes its aggregate without waiting for anybody.
-                    // (The spin is bounded all the same - ~50 ms - so that a defect could only ever produce a wrong order,
-                    // which the tests catch, never a wave that does not finish.)
-                    while ((x >> 30) == 0u && ++spins < (1 << 20)) {
-                        __builtin_amdgcn_s_sleep(1);
-                        x = __hip_atomic_load(p - u * RS_RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < RS_WAVES; ++i) {
+            if (i < w) below += wsum[q][i];
+            blocksum += wsum[q][i];
+        }
+        carry += blocksum;
+        // decoupled look-back over the earlier tiles of this segment
+        u32* const lb = lookback + (size_t)tile * RADIX + d;
+        u32 excl = 0;
+        if (blk == 0) {
+            __hip_atomic_store(lb, OS_PREF | mine[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(lb, OS_AGG | mine[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // OS_LB predecessors per round, their words requested together: when all tiles of a pass start at once no tile
+            // but the first holds a prefix yet and tile t walks back ~t / 2 words - one dependent L2 round trip each otherwise
+            const u32* p = lb - RADIX;
+            bool done = false;
+            for (int back = 0; back < blk && !done; back += OS_LB, p -= OS_LB * RADIX) {   // (ends at the segment's first tile)
+                u32 v[OS_LB];
+#pragma unroll
+                for (int u = 0; u < OS_LB; ++u)
+                    v[u] = back + u < blk ? __hip_atomic_load(p - u * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : OS_PREF;
+#pragma unroll
+                for (int u = 0; u < OS_LB; ++u) {
+                    if (!done) {
+                        u32 xv = v[u];
+                        int spins = 0;
+                        // the tile holds a smaller ticket: it is running and publishes its aggregate without waiting for
+                        // anybody.  (The spin is bounded all the same - ~50 ms - so that a defect could only ever produce a
+                        // wrong order, which the tests catch, never a wave that does not finish.)
+                        while ((xv >> 30) == 0u && ++spins < (1 << 20)) {
+                            __builtin_amdgcn_s_sleep(1);
+                            xv = __hip_atomic_load(p - u * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        excl += xv & OS_MASK;
+                        if (xv & OS_PREF) done = true;
                     }
-                    excl += x & OS_MASK;
-                    if (x & OS_PREF) done = true;
                 }
             }
+            __hip_atomic_store(lb, OS_PREF | (excl + mine[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __hip_atomic_store(lb, OS_PREF | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dbase[d] = (u32)((int64_t)seg * seg_len) + below + excl;
     }
-    dbase[d] = (u32)((int64_t)seg * seg_len) + below + excl;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
+    for (int j = 0; j < RS_ITEMS; ++j) {
         const int64_t i = lo + j * RS_THREADS + threadIdx.x;
         if (i < seg_len) {
             const u32 dd = dig[j];
@@ -371,6 +389,67 @@ static int rs_sort_three_launch(sp_ctx* ctx, const KT* keys_in, KT* keys_a, KT* 
                                 int64_t seg_len, int64_t n_seg, unsigned end_bit, DevBuf& work, const KT** sorted_keys,
                                 const u32** sorted_vals);
 
+template <typename KT, int BITS>
+static int rs_sort_onesweep(sp_ctx* ctx, const KT* keys_in, KT* keys_a, KT* keys_b, const u32* vals_in, u32* vals_a, u32* vals_b,
+                            int64_t seg_len, int64_t n_seg, unsigned end_bit, DevBuf& work, const KT** sorted_keys,
+                            const u32** sorted_vals) {
+    constexpr int RADIX = 1 << BITS;
+    const int n_pass = (int)((end_bit + BITS - 1) / BITS);
+    // (tiles of 2048 keys for sorts with fewer than two 4096-key tiles per CU measured no faster: 25 against 23 us a pass at 1 M keys)
+    const int64_t bps = (seg_len + RS_TILE - 1) / RS_TILE;
+    const int64_t blocks = bps * n_seg;
+    SP_REQUIRE(blocks < ((int64_t)1 << 31) && seg_len * n_seg < ((int64_t)1 << 32) && seg_len < ((int64_t)1 << 30) &&
+                   end_bit <= 8 * sizeof(KT),
+               SP_ELIMIT, "radix sort: %lld keys in %lld segments, %u key bits (limits: 2^32 keys, 2^30 per segment, the key's width)",
+               (long long)(seg_len * n_seg), (long long)n_seg, end_bit);
+    const size_t n_tot = (size_t)n_seg * n_pass * RADIX, n_lb = (size_t)blocks * RADIX;
+    const size_t words = n_tot + 16 + (size_t)n_pass * n_lb;
+    SP_CHECK(work.ensure(words * 4));
+    u32* ghist = work.as<u32>();
+    u32* tickets = ghist + n_tot;
+    u32* lookback = tickets + 16;
+    SP_HIP(hipMemsetAsync(ghist, 0, words * 4, ctx->stream));
+    const int64_t bph = (seg_len + (int64_t)RS_TILE * RS_HTILES - 1) / ((int64_t)RS_TILE * RS_HTILES);
+    hipLaunchKernelGGL((k_os_hist<KT, BITS>), dim3((unsigned)(bph * n_seg)), dim3(RS_THREADS), 0, ctx->stream, keys_in, seg_len,
+                       (int)bph, n_pass, ghist);
+    const KT* src = keys_in;
+    const u32* vsrc = vals_in;
+    KT* dst = keys_a;
+    u32* vdst = vals_a;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        u32* lb = lookback + (size_t)pass * n_lb;
+        const dim3 grid((unsigned)blocks), blk(RS_THREADS);
+        if (vals_in)
+            hipLaunchKernelGGL((k_os_pass<KT, true, BITS>), grid, blk, 0, ctx->stream, src, vsrc, seg_len, (int)bps, pass * BITS,
+                               pass, n_pass, (const u32*)ghist, lb, tickets + pass, dst, vdst);
+        else
+            hipLaunchKernelGGL((k_os_pass<KT, false, BITS>), grid, blk, 0, ctx->stream, src, (const u32*)nullptr, seg_len, (int)bps,
+                               pass * BITS, pass, n_pass, (const u32*)ghist, lb, tickets + pass, dst, (u32*)nullptr);
+        SP_HIP(hipGetLastError());
+        src = dst;
+        vsrc = vdst;
+        dst = dst == keys_a ? keys_b : keys_a;
+        vdst = vdst == vals_a ? vals_b : vals_a;
+    }
+    *sorted_keys = src;
+    if (sorted_vals) *sorted_vals = vsrc;
+    return SP_OK;
+}
+
+// Number of passes rs_sort makes for keys of end_bit bits (callers that need the result in a particular one of the two work
+// arrays pick the first target by its parity): 9-bit digits where they save a pass, unless an option pins the width.
+// (Measured, round 4: 9-bit digits on the 17-bit compact ids of the big-table form - 2 passes instead of 3 - ran 1.20 ms a
+// pass against 0.69 ms: the 64 KB rank table halves the workgroups per CU and doubles the per-digit scan; 36 x 1.20 = 43 ms
+// against 54 x 0.69 = 37 ms per three calls.  8 bits stay the default; `sort_digit_bits` = 9 keeps the wider form under test.)
+static inline bool rs_sort_nine_bit_digits(const sp_ctx* ctx, unsigned end_bit) {
+    (void)end_bit;
+    return !ctx->opt.sort_three_launch && ctx->opt.sort_digit_bits == 9;
+}
+static inline unsigned rs_sort_passes(const sp_ctx* ctx, unsigned end_bit) {
+    const unsigned b = rs_sort_nine_bit_digits(ctx, end_bit) ? 9u : 8u;
+    return (end_bit + b - 1) / b;
+}
+
 // Stable sort of `n_seg` independent segments of `seg_len` keys each (n_seg = 1: one array) on the bits [0, end_bit).
 // keys_in (and vals_in, optional values carried with the keys) are only read; the passes ping-pong between the two work
 // arrays keys_a / keys_b (vals_a / vals_b), n = seg_len * n_seg elements each, and the result ends up in *sorted_keys
@@ -385,56 +464,11 @@ static int rs_sort(sp_ctx* ctx, const KT* keys_in, KT* keys_a, KT* keys_b, const
     *sorted_keys = keys_in;
     if (sorted_vals) *sorted_vals = vals_in;
     if (seg_len <= 0 || n_seg <= 0 || end_bit == 0) return SP_OK;
-    const int n_pass = (int)((end_bit + RS_BITS - 1) / RS_BITS);
-    // (tiles of 2048 keys for sorts with fewer than two 4096-key tiles per CU measured no faster: 25 against 23 us a pass at 1 M keys)
-    const bool small_tiles = false;
-    const int64_t tile = RS_TILE;
-    const int64_t bps = (seg_len + tile - 1) / tile;
-    const int64_t blocks = bps * n_seg;
-    SP_REQUIRE(blocks < ((int64_t)1 << 31) && seg_len * n_seg < ((int64_t)1 << 32) && seg_len < ((int64_t)1 << 30) &&
-                   n_pass <= RS_MAXPASS,
-               SP_ELIMIT, "radix sort: %lld keys in %lld segments, %u key bits (limits: 2^32 keys, 2^30 per segment, 64 bits)",
-               (long long)(seg_len * n_seg), (long long)n_seg, end_bit);
-    const size_t n_tot = (size_t)n_seg * n_pass * RS_RADIX, n_lb = (size_t)blocks * RS_RADIX;
-    const size_t words = n_tot + 16 + (size_t)n_pass * n_lb;
-    SP_CHECK(work.ensure(words * 4));
-    u32* ghist = work.as<u32>();
-    u32* tickets = ghist + n_tot;
-    u32* lookback = tickets + 16;
-    SP_HIP(hipMemsetAsync(ghist, 0, words * 4, ctx->stream));
-    const int64_t bph = (seg_len + (int64_t)RS_TILE * RS_HTILES - 1) / ((int64_t)RS_TILE * RS_HTILES);
-    hipLaunchKernelGGL(k_os_hist<KT>, dim3((unsigned)(bph * n_seg)), dim3(RS_THREADS), 0, ctx->stream, keys_in, seg_len, (int)bph,
-                       n_pass, ghist);
-    const KT* src = keys_in;
-    const u32* vsrc = vals_in;
-    KT* dst = keys_a;
-    u32* vdst = vals_a;
-    for (int pass = 0; pass < n_pass; ++pass) {
-        u32* lb = lookback + (size_t)pass * n_lb;
-        const dim3 grid((unsigned)blocks), blk(RS_THREADS);
-        const u32* nov = nullptr;
-        u32* nov_out = nullptr;
-        if (vals_in && small_tiles)
-            hipLaunchKernelGGL((k_os_pass<KT, true, RS_ITEMS / 2>), grid, blk, 0, ctx->stream, src, vsrc, seg_len, (int)bps,
-                               pass * RS_BITS, pass, n_pass, (const u32*)ghist, lb, tickets + pass, dst, vdst);
-        else if (vals_in)
-            hipLaunchKernelGGL((k_os_pass<KT, true, RS_ITEMS>), grid, blk, 0, ctx->stream, src, vsrc, seg_len, (int)bps,
-                               pass * RS_BITS, pass, n_pass, (const u32*)ghist, lb, tickets + pass, dst, vdst);
-        else if (small_tiles)
-            hipLaunchKernelGGL((k_os_pass<KT, false, RS_ITEMS / 2>), grid, blk, 0, ctx->stream, src, nov, seg_len, (int)bps,
-                               pass * RS_BITS, pass, n_pass, (const u32*)ghist, lb, tickets + pass, dst, nov_out);
-        else
-            hipLaunchKernelGGL((k_os_pass<KT, false, RS_ITEMS>), grid, blk, 0, ctx->stream, src, nov, seg_len, (int)bps,
-                               pass * RS_BITS, pass, n_pass, (const u32*)ghist, lb, tickets + pass, dst, nov_out);
-        SP_HIP(hipGetLastError());
-        src = dst;
-        vsrc = vdst;
-        dst = dst == keys_a ? keys_b : keys_a;
-        vdst = vdst == vals_a ? vals_b : vals_a;
-    }
-    *sorted_keys = src;
-    if (sorted_vals) *sorted_vals = vsrc;
-    return SP_OK;
+    if (rs_sort_nine_bit_digits(ctx, end_bit))
+        return rs_sort_onesweep<KT, 9>(ctx, keys_in, keys_a, keys_b, vals_in, vals_a, vals_b, seg_len, n_seg, end_bit, work, sorted_keys,
+                                       sorted_vals);
+    return rs_sort_onesweep<KT, 8>(ctx, keys_in, keys_a, keys_b, vals_in, vals_a, vals_b, seg_len, n_seg, end_bit, work, sorted_keys,
+                                   sorted_vals);
 }
 
 // The three-launch form of round 3 (cross-check of the one-sweep form: context option `sort_three_launch`).

@@ -466,7 +466,7 @@ int launch_sparse_big(sp_ctx* ctx, int64_t D, int64_t S, const u32* rr, const u3
     // buffer and a shared alternate; the first target is chosen so that the last pass lands in the named one.
     DevBuf &altk = ctx->big[12], &altv = ctx->big[13];
     if ((rc = altk.ensure(total * 4)) || (rc = altv.ensure(total * 4))) return fail(rc);
-    const unsigned passes = (bits + RS_BITS - 1) / RS_BITS;
+    const unsigned passes = rs_sort_passes(ctx, bits);
     auto sort_side = [&](const u32* ids, DevBuf& keyb, DevBuf& permb) -> int {
         const u32 *sk = nullptr, *sv = nullptr;
         u32 *ka = (passes & 1) ? keyb.as<u32>() : altk.as<u32>(), *kb = (passes & 1) ? altk.as<u32>() : keyb.as<u32>();
@@ -577,7 +577,7 @@ int launch_sparse_big_keys(sp_ctx* ctx, const u64* keys, int64_t D, int n, const
     // stable sort of every split's (raw side key, pattern index) pairs by key: S segments of D entries (radix_sort.h)
     DevBuf &altk = ctx->big[22], &altv = ctx->big[23];   // (slots of their own: 12 / 13 are d_taxa / d_a of this function)
     if ((rc = altk.ensure(total * 8)) || (rc = altv.ensure(total * 4))) return fail(rc);
-    const unsigned passes = (bits + RS_BITS - 1) / RS_BITS;
+    const unsigned passes = rs_sort_passes(ctx, bits);
     auto sort_side = [&](const u64* side_keys, DevBuf& permb) -> int {
         const u64* skp = nullptr;
         const u32* svp = nullptr;

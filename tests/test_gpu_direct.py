@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 SCORE_TOL = 1e-10
 OPTIONS = (("force_big", 0), ("big_by_keys", 0), ("lds_cap", 0), ("wide_cap", 0), ("direct_finish", 1), ("direct_all", 0),
-           ("direct_max_rows", 0), ("sort_three_launch", 0), ("eigen_block16", 0))
+           ("direct_max_rows", 0), ("sort_three_launch", 0), ("eigen_block16", 0), ("sort_digit_bits", 0))
 
 
 @pytest.fixture(scope="module")
@@ -234,13 +234,16 @@ def test_radix_sort_direct(sp):
             keys[: n // 3] &= np.uint64(0xFF)          # heavy duplicates: stability matters
         vals = np.arange(n, dtype=np.uint32)
         outs = []
-        for legacy in (0, 1):
+        for legacy, digit_bits in ((0, 8), (0, 9), (1, 0)):          # one-sweep with 8- / 9-bit digits, round 3's three-launch form
             ctx.set_option("sort_three_launch", legacy)
+            ctx.set_option("sort_digit_bits", digit_bits)
             ko, vo = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint32)
             _lib.check(lib.sp_debug_radix_sort(ctx.handle, _lib._ptr(keys, C.c_uint64), _lib._ptr(vals, C.c_uint32), key_bytes,
                                                seg_len, n_seg, bits, _lib._ptr(ko, C.c_uint64), _lib._ptr(vo, C.c_uint32)))
             outs.append((ko, vo))
         ctx.set_option("sort_three_launch", 0)
+        ctx.set_option("sort_digit_bits", 0)
+        assert np.array_equal(outs[0][0], outs[2][0]) and np.array_equal(outs[0][1], outs[2][1])
         want_v = np.concatenate([s * seg_len + np.argsort(keys[s * seg_len:(s + 1) * seg_len], kind="stable")
                                  for s in range(n_seg)]).astype(np.uint32)
         assert np.array_equal(outs[0][1], want_v), (key_bytes, seg_len, n_seg, bits)
