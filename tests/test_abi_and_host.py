@@ -242,3 +242,28 @@ def test_flattening_content_check_detects_edits():
     G._sp_check = _content_check(G)
     G /= G.sum()
     assert flattening_origin(G) is None
+
+
+def test_new_kernels_keep_nothing_in_scratch():
+    """The compiler's own resource remarks (tools/kernel_resources.py, no GPU): the round-4 kernels - the certified 4-wide eigen
+    kernel of the dense route and the direct solver - spill no vector register and use no scratch memory, and the committed
+    table of all kernels (profiles/r04_kernel_resources.json) says the same of the headline kernel."""
+    import json
+    import shutil
+    import sys
+
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+
+    for fn in ("eig4.hip", "finish.hip"):
+        table = kr.resources(os.path.join(ROOT, "splitp_amd", "csrc", fn))
+        assert table, fn
+        for name, res in table.items():
+            assert res.get("scratch_bytes_per_lane") == 0 and res.get("vgpr_spills") == 0, (fn, name, res)
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r04_kernel_resources.json")))
+    fast = committed["sparse.hip"]["k_sparse_score"]
+    assert fast["scratch_bytes_per_lane"] == 0 and fast["vgpr_spills"] == 0
+    big = [v for k, v in committed["sparse_big.hip"].items() if "k_sparse_big" in k and "false" in k]
+    assert big and all(v["vgpr_spills"] <= 32 for v in big)     # (round 3: 585; the wide fallback is a kernel of its own now)

@@ -22,7 +22,7 @@ FIELDS = {"VGPRs": "vgprs", "AGPRs": "agprs", "SGPRs": "sgprs", "ScratchSize [by
 
 
 def demangle(names):
-    filt = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    filt = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt" if os.path.exists("/opt/rocm/lib/llvm/bin/llvm-cxxfilt") else "/usr/bin/c++filt"
     if not names or not os.path.exists(filt):
         return {n: n for n in names}
     out = subprocess.run([filt] + list(names), capture_output=True, text=True).stdout.split("\n")
