@@ -267,3 +267,19 @@ def test_new_kernels_keep_nothing_in_scratch():
     assert fast["scratch_bytes_per_lane"] == 0 and fast["vgpr_spills"] == 0
     big = [v for k, v in committed["sparse_big.hip"].items() if "k_sparse_big" in k and "false" in k]
     assert big and all(v["vgpr_spills"] <= 32 for v in big)     # (round 3: 585; the wide fallback is a kernel of its own now)
+
+
+def test_hand_issued_scalar_loads_have_no_hazard():
+    """subflat.hip fetches its Sturm table with inline-asm s_load_dwordx8 into registers the hardware writes asynchronously
+    (ADVICE r3): on every control-flow path from such a load to its s_waitcnt lgkmcnt(0) no instruction may touch the
+    destination registers - checked on the device assembly of the current compiler (tools/check_sload_hazard.py)."""
+    import shutil
+    import sys
+
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_sload_hazard as chk
+
+    n, bad = chk.check(os.path.join(ROOT, "splitp_amd", "csrc", "subflat.hip"))
+    assert n >= 16 and not bad, bad[:5]
