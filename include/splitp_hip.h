@@ -290,6 +290,26 @@ int sp_score_plan_steps(sp_ctx* lane, sp_alignment* const* als, int n_al, sp_pla
 int sp_finish_flagged(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
                       double* scores_host, int32_t* status_host, int64_t* n_finished);
 
+/* ---------------------------------------------------------------- one process, all GPUs of the node (ABI 4) --- */
+/* SURVEY 8b / 8e, north_star: "partitioned across the 8 GPUs of one node by sharding the per-tree candidate-split set with an
+ * RCCL all-gather of scores over xGMI".  An sp_node owns one context per device and one RCCL communicator per device
+ * (ncclCommInitAll; librccl is loaded with dlopen on first use - the library itself links only the HIP runtime).
+ * sp_node_score_all_splits replicates the pattern table on every device (a few MB), lets device r enumerate and score the
+ * combinations r, r + P, ... of every size class (sp_score_all_splits_shard: an equal share of every cost class, no split
+ * list anywhere; one host thread per device), all-gathers the packed (scores, status) shards in ONE collective and returns
+ * all scores in the order of the reference's all_splits (splits.py:39-59).  keys / weights / counts / D / n_taxa / N as for
+ * sp_alignment_create, method / trivial / size / outputs / SP_ENOCONV as for sp_score_all_splits.  n_devices = 0: every
+ * visible device.  n_devices < 0 is a TEST MODE: |n_devices| ranks emulated on device 0, the collective replaced by device
+ * copies - the sharding, packing and un-permuting of P > 1 ranks run on a one-GPU box (no RCCL involved).  (bench.py and splitp_amd.batch drive the same partition with one PROCESS per GPU through
+ * torch.distributed, as the task's launch contract prescribes; this entry is for hosts that are not Python.) */
+typedef struct sp_node sp_node;
+int sp_node_create(int n_devices, sp_node** out);
+int sp_node_destroy(sp_node* node);
+int sp_node_info(const sp_node* node, int* n_devices);
+int sp_node_score_all_splits(sp_node* node, const uint64_t* keys, const double* weights, const int64_t* counts, int64_t D,
+                             int n_taxa, int64_t N, int method, int trivial, int size, int64_t* n_splits,
+                             double* scores_host, int32_t* status_host);
+
 /* ---------------------------------------------------------------- test entry --- */
 /* The library's stable segmented LSD radix sort (csrc/radix_sort.h: one-sweep, decoupled look-back) on host arrays, for
  * tests only: n_seg independent segments of seg_len keys each, sorted on the bits [0, end_bit); keys as 64-bit words

@@ -9,7 +9,7 @@ plus the device-resident batched form of the README loop:
 Host code is Python; all compute is hand-written HIP for gfx950 behind a ctypes C ABI
 (include/splitp_hip.h).  There is no CPU fallback."""
 from . import constants, constructions, enums, matrix, phylogenetics, simulation, splits  # noqa: F401
-from .batch import encode_all_splits, score_all_splits, score_splits  # noqa: F401
+from .batch import NodeScorer, encode_all_splits, score_all_splits, score_splits  # noqa: F401
 from .constructions import (flattening, sparse_flattening_with_banned_patterns,  # noqa: F401
                             subflattening)
 from .device import DeviceAlignment, get_context  # noqa: F401
@@ -21,4 +21,4 @@ from .simulation import generate_alignment  # noqa: F401
 from .splits import all_splits  # noqa: F401
 from ._lib import SplitPDeviceError  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.4.0"

@@ -38,6 +38,7 @@ SYMBOLS = (
     "sp_score_splits_multi_async", "sp_score_all_splits", "sp_score_all_splits_shard",
     "sp_plan_create", "sp_plan_retain", "sp_plan_release", "sp_plan_info", "sp_score_plan_async", "sp_score_plan_steps",
     "sp_finish_flagged", "sp_debug_radix_sort",
+    "sp_node_create", "sp_node_destroy", "sp_node_info", "sp_node_score_all_splits",
 )
 
 
@@ -133,6 +134,11 @@ def load():
         "sp_score_plan_steps": [vp, P(vp), i32, vp, i32, vp, i64, vp, i64],
         "sp_finish_flagged": [vp, P(C.c_int32), P(C.c_int32), i64, P(dbl), P(C.c_int32), P(i64)],
         "sp_debug_radix_sort": [vp, P(C.c_uint64), P(C.c_uint32), i32, i64, i64, C.c_uint, P(C.c_uint64), P(C.c_uint32)],
+        "sp_node_create": [i32, P(vp)],
+        "sp_node_destroy": [vp],
+        "sp_node_info": [vp, P(i32)],
+        "sp_node_score_all_splits": [vp, P(C.c_uint64), P(dbl), P(i64), i64, i32, i64, i32, i32, i32, P(i64), P(dbl),
+                                     P(C.c_int32)],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

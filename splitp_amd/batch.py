@@ -423,3 +423,51 @@ def score_splits(pattern_probabilities, splits, method=Method.flattening, distri
         out, status = gather_scores(loc, shards, len(splits), group=group, local_status=loc_st, return_status=True)
     warn_unconverged(status)
     return (out, status) if return_status else out
+
+
+class NodeScorer:
+    """One process, all GPUs of the node: the library's own multi-GPU partition (sp_node_*, csrc/node.hip) - the candidate
+    splits of an alignment sharded over `n_devices` GPUs (index mod P within every size class), one RCCL
+    all-gather of the scores over xGMI.  The counterpart for Python programs that run one process per GPU is
+    score_all_splits(distributed=True) on torch.distributed; this class drives every GPU from the calling process."""
+
+    def __init__(self, n_devices=0):
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        self.handle = C.c_void_p()
+        _lib.check(self._lib.sp_node_create(int(n_devices), C.byref(self.handle)))
+        n = C.c_int()
+        _lib.check(self._lib.sp_node_info(self.handle, C.byref(n)))
+        self.n_devices = int(n.value)
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self._lib.sp_node_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def score_all_splits(self, keys, n_taxa, counts=None, weights=None, n_sites=None, method=Method.flattening, route="auto",
+                         trivial=False, size=None, return_status=False):
+        """Scores of every split of the table's taxa in all_splits order.  keys: packed pattern keys (uint64, taxon 0 most
+        significant); counts (with n_sites) or weights: the table's values."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        cnt = None if counts is None else np.ascontiguousarray(counts, dtype=np.int64)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        if cnt is not None and n_sites is None:
+            n_sites = int(cnt.sum())
+        code = _method_code(method, route)
+        n = C.c_int64()
+        args = (self.handle, _lib._ptr(keys, C.c_uint64), _lib._ptr(w, C.c_double), _lib._ptr(cnt, C.c_int64), len(keys),
+                int(n_taxa), int(n_sites or 0), code, 1 if trivial else 0, int(size or 0))
+        _lib.check(self._lib.sp_node_score_all_splits(*args, C.byref(n), None, None))
+        scores = np.zeros(n.value, dtype=np.float64)
+        status = np.zeros(n.value, dtype=np.int32)
+        _lib.check(self._lib.sp_node_score_all_splits(*args, C.byref(n), _lib._ptr(scores, C.c_double),
+                                                      _lib._ptr(status, C.c_int32)), allow_noconv=True)
+        warn_unconverged(status)
+        return (scores, status) if return_status else scores

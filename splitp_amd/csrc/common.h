@@ -291,6 +291,14 @@ struct sp_plan {
     DevBuf launch_dev;   // SplitDev[S], launch order (heaviest first), each with its split index in `cls`
 };
 
+// hipFuncSetAttribute (dynamic LDS beyond 64 KB) is a per-DEVICE setting of a function: a process that drives several GPUs
+// (node.hip) must set it once on each - a process-wide `static bool` served the first device only.  Thread-safe.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    bool need(int device) const { return !((mask.load(std::memory_order_acquire) >> (device & 63)) & 1ull); }
+    void done(int device) { mask.fetch_or(1ull << (device & 63), std::memory_order_release); }
+};
+
 struct PhaseScope {
     sp_ctx* c;
     int phase;

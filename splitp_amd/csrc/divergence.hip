@@ -103,11 +103,11 @@ int launch_divergence(sp_ctx* ctx, bool exact, int64_t D, int64_t S, const u32* 
     PhaseScope ps(ctx, SP_PHASE_DIVERGENCE);
     if (exact && D <= 16384 && n_total < 4294967296.0 && !ctx->opt.divergence_global) {
         const size_t lds = (size_t)2 * D * 4;
-        static bool attr = false;
-        if (!attr) {
+        static PerDeviceOnce attr;
+        if (attr.need(ctx->device)) {
             SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_div_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        131072));
-            attr = true;
+            attr.done(ctx->device);
         }
         hipLaunchKernelGGL(k_div_fused, dim3((unsigned)S), dim3(256), lds, ctx->stream, D, rr, cc, counts, n_total, out);
         SP_HIP(hipGetLastError());

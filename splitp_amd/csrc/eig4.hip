@@ -207,11 +207,12 @@ int launch_eigen4(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<Spl
                "eigen kernel: the smaller side of a flattening has %d (padded) rows; one workgroup owns a split (a row per "
                "thread) and takes at most %d (n_taxa <= 11 on the dense route)", maxr, EIG_MAXR);
     const size_t lds = ((sizeof(SpkShared) + 15) & ~(size_t)15) + (size_t)maxr * 4 * sizeof(double);
-    static size_t attr = 0;
-    if (lds > attr) {
-        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eig4<int>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eig4<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
+    static PerDeviceOnce attr;   // (the largest block the kernel can be asked for: EIG_MAXR rows)
+    if (attr.need(ctx->device)) {
+        const int lds_max = (int)(((sizeof(SpkShared) + 15) & ~(size_t)15) + (size_t)EIG_MAXR * 4 * sizeof(double));
+        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eig4<int>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eig4<double>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        attr.done(ctx->device);
     }
     PhaseScope ps(ctx, SP_PHASE_EIGEN);
     if (g_i32)

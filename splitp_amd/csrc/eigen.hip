@@ -384,15 +384,16 @@ static int launch_eigen_t(sp_ctx* ctx, const SplitDev* splits_dev, const std::ve
     PhaseScope ps(ctx, SP_PHASE_EIGEN);
     const size_t lds_head = EIG_HEAD_BYTES;
     const size_t lds = lds_head + (size_t)maxr * EIG_VP * sizeof(double);
-    static size_t attr = 0;
-    if (lds > attr) {
+    static PerDeviceOnce attr;   // (per kernel type GT; the largest block: EIG_MAXR rows)
+    if (attr.need(ctx->device)) {
+        const size_t lds_max = lds_head + (size_t)EIG_MAXR * EIG_VP * sizeof(double);
         SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eig_init<GT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eig_rr), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
+                                   (int)lds_max));
         SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eig_finish<GT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        attr.done(ctx->device);
     }
     // One pipeline = init, EIG_NFAST x (G V product over all row blocks, per-split Rayleigh-Ritz), finisher.  Every kernel
     // touches only the states / blocks / scores of its own splits, so two disjoint sets of splits are two independent

@@ -159,11 +159,11 @@ int launch_reindex(sp_ctx* ctx, const u64* keys, int64_t D, int n_taxa, const Sp
     const size_t lds_bytes = (size_t)maxw * 12;
     const int S = (int)splits.size();
     if (lds_bytes <= 96 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PerDeviceOnce attr_set;
+        if (attr_set.need(ctx->device)) {
             SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reindex<true, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr_set = true;
+            attr_set.done(ctx->device);
         }
         hipLaunchKernelGGL((k_reindex<true, false>), dim3(S), dim3(RX_THREADS), lds_bytes, ctx->stream, keys, D, n_taxa,
                            splits_dev, bitmaps, prefixes, dims, rr, cc, maxw, nullptr, nullptr);

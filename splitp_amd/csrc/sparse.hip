@@ -1859,13 +1859,13 @@ int launch_sparse_chain(sp_ctx* ctx, const AlDesc* als_dev, const AlDesc& al0, i
     if (S == 0 || n_al == 0) return SP_OK;
     const int64_t n_items = S * n_al;
     SP_REQUIRE(n_items < ((int64_t)1 << 31), SP_ELIMIT, "sparse route: %lld items in one call (limit 2^31)", (long long)n_items);
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.need(ctx->device)) {
         SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_score),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_BYTES));
         SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sparse_slow),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_BYTES));
-        attr = true;
+        attr.done(ctx->device);
     }
     SpkSlow q{};
     q.slab_l = sparse_list_slab_bytes(d_max);

@@ -980,15 +980,15 @@ static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da,
         const void* kfn = m32 ? reinterpret_cast<const void*>(k_subscore_tri<true, true>)
                               : (al->exact ? reinterpret_cast<const void*>(k_subscore_tri<true, false>)
                                            : reinterpret_cast<const void*>(k_subscore_tri<false, false>));
-        static bool attr_t = false;
-        if (!attr_t) {
+        static PerDeviceOnce attr_t;
+        if (attr_t.need(ctx->device)) {
             SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_TOTAL));
             SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<true, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_TOTAL));
             SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_subscore_tri<false, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SPK_LDS_TOTAL));
-            attr_t = true;
+            attr_t.done(ctx->device);
         }
         // Workgroup shape: the eigenvalue steps are dependency chains, so what counts is the number of waves resident on a
         // CU, and that is set by the LDS (one staged matrix per workgroup + one work area per wave).  Take the shape that

@@ -253,3 +253,49 @@ def test_radix_sort_direct(sp):
         _lib.check(lib.sp_debug_radix_sort(ctx.handle, _lib._ptr(keys, C.c_uint64), None, key_bytes, seg_len, n_seg, bits,
                                            _lib._ptr(ko, C.c_uint64), None))
         assert np.array_equal(ko, keys[want_v])
+
+
+def test_node_api_one_device(sp, golden):
+    """sp_node_* (csrc/node.hip: one process drives the node's GPUs, RCCL loaded on first use): on the one-GPU box the node has
+    one device - the whole path runs (ncclCommInitAll, shard = everything, ncclAllGather with one rank, un-permute) and must
+    return the single-GPU call's results bit for bit, for the flattening and the subflattening route; asking for more
+    devices than are visible is answered with an error, not a crash."""
+    import ctypes as C
+
+    from splitp_amd import _lib
+
+    g = golden("n10_L100k")
+    keys = np.asarray(g["keys"], dtype=np.uint64)
+    probs = np.asarray(g["probs"], dtype=np.float64)
+    counts = np.rint(probs * 100_000).astype(np.int64)
+    node = sp.NodeScorer(1)
+    assert node.n_devices == 1
+    try:
+        got, st = node.score_all_splits(keys, 10, counts=counts, n_sites=100_000, return_status=True)
+        assert got.shape == (501,) and not np.any(st & 3)
+        assert np.abs(got - g["scores"]).max() <= SCORE_TOL
+        dev = sp.DeviceAlignment.from_arrays(keys, None, 10, counts=counts, n_sites=100_000, taxa=taxa_names(10))
+        assert np.array_equal(got, sp.score_all_splits(dev))
+        sub = node.score_all_splits(keys, 10, counts=counts, n_sites=100_000, method=sp.Method.subflattening)
+        assert np.array_equal(sub, sp.score_all_splits(dev, method=sp.Method.subflattening))
+        triv = node.score_all_splits(keys, 10, counts=counts, n_sites=100_000, method=sp.Method.subflattening, trivial=True, size=None)
+        assert np.array_equal(triv, sp.score_all_splits(dev, method=sp.Method.subflattening, trivial=True))
+        w = node.score_all_splits(keys, 10, weights=probs, method=sp.Method.subflattening)        # float-weight table
+        assert np.abs(w - sub).max() <= 1e-12
+    finally:
+        node.close()
+    # P = 2, 3, 8 ranks emulated on this one device (test mode: shards, packing and un-permuting of a real multi-rank run)
+    for ranks in (2, 3, 8):
+        em = sp.NodeScorer(-ranks)
+        assert em.n_devices == ranks
+        try:
+            assert np.array_equal(em.score_all_splits(keys, 10, counts=counts, n_sites=100_000), got)
+            assert np.array_equal(em.score_all_splits(keys, 10, counts=counts, n_sites=100_000, method=sp.Method.subflattening), sub)
+            assert np.array_equal(em.score_all_splits(keys, 10, counts=counts, n_sites=100_000, method=sp.Method.subflattening,
+                                                      size=5), sp.score_all_splits(dev, method=sp.Method.subflattening, size=5))
+        finally:
+            em.close()
+    h = C.c_void_p()
+    lib = _lib.load()
+    assert lib.sp_node_create(_lib.device_count() + 1, C.byref(h)) == _lib.SP_EINVAL
+    assert b"visible" in lib.sp_last_error()
