@@ -22,3 +22,19 @@ from .splits import all_splits  # noqa: F401
 from ._lib import SplitPDeviceError  # noqa: F401
 
 __version__ = "0.4.0"
+
+
+def install_as_splitp(force=False):
+    """Make `import splitp` (and splitp.constructions / .phylogenetics / .matrix / .enums / .constants / .splits) resolve to
+    this package: the literal drop-in for code written against the reference (splitp/__init__.py:15-18 names the surface).
+    Refuses to shadow an already imported reference package unless force=True.  Returns the module registered."""
+    import sys
+
+    me = sys.modules[__name__]
+    have = sys.modules.get("splitp")
+    if have is not None and have is not me and not force:
+        raise ImportError("a module named 'splitp' is already imported; pass force=True to replace it")
+    sys.modules["splitp"] = me
+    for sub in ("constructions", "phylogenetics", "matrix", "enums", "constants", "splits", "simulation"):
+        sys.modules["splitp." + sub] = sys.modules[__name__ + "." + sub]
+    return me

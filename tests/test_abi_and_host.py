@@ -283,3 +283,25 @@ def test_hand_issued_scalar_loads_have_no_hazard():
 
     n, bad = chk.check(os.path.join(ROOT, "splitp_amd", "csrc", "subflat.hip"))
     assert n >= 16 and not bad, bad[:5]
+
+
+def test_install_as_splitp_alias():
+    """`import splitp` after splitp_amd.install_as_splitp(): the reference's import lines work unchanged."""
+    import importlib
+    import sys
+
+    saved = {k: v for k, v in sys.modules.items() if k == "splitp" or k.startswith("splitp.")}
+    try:
+        for k in saved:
+            del sys.modules[k]
+        sp.install_as_splitp()
+        import splitp                                    # noqa: F401
+        from splitp.constructions import flattening      # noqa: F401
+        from splitp.phylogenetics import split_score     # noqa: F401
+        from splitp import FlatFormat, all_splits        # noqa: F401
+        assert splitp is sp and flattening is sp.flattening and split_score is sp.split_score
+        assert importlib.import_module("splitp.enums").FlatFormat is sp.FlatFormat
+    finally:
+        for k in [k for k in sys.modules if k == "splitp" or k.startswith("splitp.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
