@@ -73,6 +73,39 @@ __global__ __launch_bounds__(SPK_THREADS) void k_eig4(const SplitDev* __restrict
         }
         return;
     }
+    if (R <= EIG_B) {
+        // The whole Gram matrix fits the one-wave 16 x 16 Jacobi (eig_small.h): eigenvalues directly, each to its own relative
+        // accuracy, and the score from the sum of the eigenvalues BEHIND the fourth - no 1 - top4 / trace cancellation.  (The
+        // iteration's sum is good to ~4e-15 of the trace; on a 6 x 5 table of numerical rank 4 that is 3e-14 in score^2 -
+        // scores of 8e-6 came back 2e-9 off in the soak of round 4's first build.)
+        EigShared& esh = *reinterpret_cast<EigShared*>(V);
+        if (threadIdx.x < EIG_B * EIG_B) {
+            const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+            esh.H[r * EIG_VP + c] = (r < R && c < R) ? (double)G[(int64_t)r * gp + c] : 0.0;
+        }
+        __syncthreads();
+        jacobi_nb<EIG_B>(esh);
+        if (threadIdx.x < 64) {
+            const double th = lane < EIG_B ? fmax(esh.theta[lane], 0.0) : -1.0;
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < EIG_B; ++j) {
+                const double o = __shfl(th, j, 64);
+                rank += (o > th || (o == th && j < lane)) ? 1 : 0;
+            }
+            double top = (lane < EIG_B && rank < 4) ? th : 0.0, rest = (lane < EIG_B && rank >= 4) ? th : 0.0;
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) {
+                top += __shfl_xor(top, d, 64);
+                rest += __shfl_xor(rest, d, 64);
+            }
+            if (lane == 0) {
+                scores[sid] = sqrt(rest / (top + rest));
+                status[sid] = 1 << 8;
+            }
+        }
+        return;
+    }
     // the 4 rows with the largest diagonal (for count matrices the dominant singular vectors sit on the rows of the few very
     // frequent patterns): candidates = (value bits, low 10 bits replaced by 1023 - row), extracted in descending order
     unsigned long long bound = ~0ull;
@@ -206,10 +239,10 @@ int launch_eigen4(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<Spl
     SP_REQUIRE(maxr <= EIG_MAXR, SP_ELIMIT,
                "eigen kernel: the smaller side of a flattening has %d (padded) rows; one workgroup owns a split (a row per "
                "thread) and takes at most %d (n_taxa <= 11 on the dense route)", maxr, EIG_MAXR);
-    const size_t lds = ((sizeof(SpkShared) + 15) & ~(size_t)15) + (size_t)maxr * 4 * sizeof(double);
+    const size_t lds = ((sizeof(SpkShared) + 15) & ~(size_t)15) + std::max((size_t)maxr * 4 * sizeof(double), sizeof(EigShared));
     static PerDeviceOnce attr;   // (the largest block the kernel can be asked for: EIG_MAXR rows)
     if (attr.need(ctx->device)) {
-        const int lds_max = (int)(((sizeof(SpkShared) + 15) & ~(size_t)15) + (size_t)EIG_MAXR * 4 * sizeof(double));
+        const int lds_max = (int)(((sizeof(SpkShared) + 15) & ~(size_t)15) + std::max((size_t)EIG_MAXR * 4 * sizeof(double), sizeof(EigShared)));
         SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eig4<int>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eig4<double>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         attr.done(ctx->device);
