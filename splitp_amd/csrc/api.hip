@@ -995,7 +995,7 @@ static int cached_sparse_plan(sp_ctx* ctx, int n, const int32_t* split_taxa, con
 // by the direct solver (finish.hip): compact matrix of the split -> fp64 Gram over its smaller side -> Householder
 // tridiagonalisation + Sturm multisection.  Host-driven (2 m launches, dims fetched once per chunk); the chunks keep the
 // compact matrices + Gram matrices of one batch under ~24 GB.  Splits whose smaller side has more compact rows than
-// `direct_max_rows` (default 16384: 2 GB of G, ~23 TB of traffic - about 10 s) or a side of more than 14 taxa (bitmap
+// `direct_max_rows` (default 16384: 2 GB of G, ~23 TB of traffic - about 25 s) or a side of more than 14 taxa (bitmap
 // compaction) keep their flagged estimate.  scores_dev / status_dev: the S-entry device arrays to patch; st: their
 // host copy (patched too).  Returns the number of splits finished in *n_done.
 static int finish_flagged(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S, std::vector<int>& st,
