@@ -33,6 +33,54 @@ __device__ __forceinline__ double e4_load<double>(__amdgpu_buffer_rsrc_t rsrc, u
     return __hiloint2double((int)w.y, (int)w.x);
 }
 
+// Gram matrices of at most 16 rows: the one-wave 16 x 16 Jacobi (eig_small.h) gives every eigenvalue to its own relative
+// accuracy, and the score is taken from the sum of the eigenvalues BEHIND the fourth - no 1 - top4 / trace cancellation.  (The
+// iteration's sum is good to ~4e-15 of the trace; on a 6 x 5 table of numerical rank 4 that is 3e-14 in score^2 - scores of
+// 8e-6 came back 2e-9 off in the first soak of round 4.)  A kernel of its own, one wave per split, launched before k_eig4 (which
+// skips these splits): inlined into k_eig4 the Jacobi cost it 28 bytes of scratch per lane.
+template <typename GT>
+__global__ __launch_bounds__(64) void k_eig4_small(const SplitDev* __restrict__ splits, const int2* __restrict__ dims,
+                                                   const GT* __restrict__ grams, double* __restrict__ scores,
+                                                   int* __restrict__ status) {
+    __shared__ EigShared esh;
+    const int sid = blockIdx.x;
+    const SplitDev& sp = splits[sid];
+    const int R = min(dims[sid].x, sp.rcap);
+    if (R <= 4 || R > EIG_B) return;   // (R <= 4 and the all-zero matrix: k_eig4)
+    const GT* __restrict__ G = grams + sp.g_off;
+    const int64_t gp = sp.g_pitch;
+    const int lane = threadIdx.x;
+    double tr = 0;
+    for (int e = lane; e < EIG_B * EIG_B; e += 64) {
+        const int r = e >> 4, c = e & 15;
+        const double g = (r < R && c < R) ? (double)G[(int64_t)r * gp + c] : 0.0;
+        esh.H[r * EIG_VP + c] = g;
+        if (r == c) tr += g;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tr += __shfl_xor(tr, d, 64);
+    if (!(tr > 0)) return;             // all-zero: k_eig4 writes the nan
+    __syncthreads();
+    jacobi_nb<EIG_B>(esh);
+    const double th = lane < EIG_B ? fmax(esh.theta[lane], 0.0) : -1.0;
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < EIG_B; ++j) {
+        const double o = __shfl(th, j, 64);
+        rank += (o > th || (o == th && j < lane)) ? 1 : 0;
+    }
+    double top = (lane < EIG_B && rank < 4) ? th : 0.0, rest = (lane < EIG_B && rank >= 4) ? th : 0.0;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+        top += __shfl_xor(top, d, 64);
+        rest += __shfl_xor(rest, d, 64);
+    }
+    if (lane == 0) {
+        scores[sid] = sqrt(rest / (top + rest));
+        status[sid] = 1 << 8;
+    }
+}
+
 template <typename GT>
 __global__ __launch_bounds__(SPK_THREADS) void k_eig4(const SplitDev* __restrict__ splits, const int2* __restrict__ dims,
                                                       const GT* __restrict__ grams, double* __restrict__ scores,
@@ -73,39 +121,7 @@ __global__ __launch_bounds__(SPK_THREADS) void k_eig4(const SplitDev* __restrict
         }
         return;
     }
-    if (R <= EIG_B) {
-        // The whole Gram matrix fits the one-wave 16 x 16 Jacobi (eig_small.h): eigenvalues directly, each to its own relative
-        // accuracy, and the score from the sum of the eigenvalues BEHIND the fourth - no 1 - top4 / trace cancellation.  (The
-        // iteration's sum is good to ~4e-15 of the trace; on a 6 x 5 table of numerical rank 4 that is 3e-14 in score^2 -
-        // scores of 8e-6 came back 2e-9 off in the soak of round 4's first build.)
-        EigShared& esh = *reinterpret_cast<EigShared*>(V);
-        if (threadIdx.x < EIG_B * EIG_B) {
-            const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
-            esh.H[r * EIG_VP + c] = (r < R && c < R) ? (double)G[(int64_t)r * gp + c] : 0.0;
-        }
-        __syncthreads();
-        jacobi_nb<EIG_B>(esh);
-        if (threadIdx.x < 64) {
-            const double th = lane < EIG_B ? fmax(esh.theta[lane], 0.0) : -1.0;
-            int rank = 0;
-#pragma unroll
-            for (int j = 0; j < EIG_B; ++j) {
-                const double o = __shfl(th, j, 64);
-                rank += (o > th || (o == th && j < lane)) ? 1 : 0;
-            }
-            double top = (lane < EIG_B && rank < 4) ? th : 0.0, rest = (lane < EIG_B && rank >= 4) ? th : 0.0;
-#pragma unroll
-            for (int d = 8; d >= 1; d >>= 1) {
-                top += __shfl_xor(top, d, 64);
-                rest += __shfl_xor(rest, d, 64);
-            }
-            if (lane == 0) {
-                scores[sid] = sqrt(rest / (top + rest));
-                status[sid] = 1 << 8;
-            }
-        }
-        return;
-    }
+    if (R <= EIG_B) return;   // (k_eig4_small, launched just before, has scored it)
     // the 4 rows with the largest diagonal (for count matrices the dominant singular vectors sit on the rows of the few very
     // frequent patterns): candidates = (value bits, low 10 bits replaced by 1023 - row), extracted in descending order
     unsigned long long bound = ~0ull;
@@ -239,15 +255,25 @@ int launch_eigen4(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<Spl
     SP_REQUIRE(maxr <= EIG_MAXR, SP_ELIMIT,
                "eigen kernel: the smaller side of a flattening has %d (padded) rows; one workgroup owns a split (a row per "
                "thread) and takes at most %d (n_taxa <= 11 on the dense route)", maxr, EIG_MAXR);
-    const size_t lds = ((sizeof(SpkShared) + 15) & ~(size_t)15) + std::max((size_t)maxr * 4 * sizeof(double), sizeof(EigShared));
+    const size_t lds = ((sizeof(SpkShared) + 15) & ~(size_t)15) + (size_t)maxr * 4 * sizeof(double);
     static PerDeviceOnce attr;   // (the largest block the kernel can be asked for: EIG_MAXR rows)
     if (attr.need(ctx->device)) {
-        const int lds_max = (int)(((sizeof(SpkShared) + 15) & ~(size_t)15) + std::max((size_t)EIG_MAXR * 4 * sizeof(double), sizeof(EigShared)));
+        const int lds_max = (int)(((sizeof(SpkShared) + 15) & ~(size_t)15) + (size_t)EIG_MAXR * 4 * sizeof(double));
         SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eig4<int>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         SP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_eig4<double>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         attr.done(ctx->device);
     }
     PhaseScope ps(ctx, SP_PHASE_EIGEN);
+    int minr = EIG_MAXR;
+    for (const auto& sp : splits) minr = std::min(minr, (int)sp.rcap);
+    if (minr <= 64) {   // (a side of <= 16 compact rows has rcap = 64: only then can the small kernel have anything to do)
+        if (g_i32)
+            hipLaunchKernelGGL(k_eig4_small<int>, dim3((unsigned)splits.size()), dim3(64), 0, ctx->stream, splits_dev, dims,
+                               (const int*)grams, scores, status);
+        else
+            hipLaunchKernelGGL(k_eig4_small<double>, dim3((unsigned)splits.size()), dim3(64), 0, ctx->stream, splits_dev, dims,
+                               (const double*)grams, scores, status);
+    }
     if (g_i32)
         hipLaunchKernelGGL(k_eig4<int>, dim3((unsigned)splits.size()), dim3(SPK_THREADS), lds, ctx->stream, splits_dev, dims,
                            (const int*)grams, scores, status, order_dev);
