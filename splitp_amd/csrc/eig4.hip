@@ -36,8 +36,10 @@ __device__ __forceinline__ double e4_load<double>(__amdgpu_buffer_rsrc_t rsrc, u
 // Gram matrices of at most 16 rows: the one-wave 16 x 16 Jacobi (eig_small.h) gives every eigenvalue to its own relative
 // accuracy, and the score is taken from the sum of the eigenvalues BEHIND the fourth - no 1 - top4 / trace cancellation.  (The
 // iteration's sum is good to ~4e-15 of the trace; on a 6 x 5 table of numerical rank 4 that is 3e-14 in score^2 - scores of
-// 8e-6 came back 2e-9 off in the first soak of round 4.)  A kernel of its own, one wave per split, launched before k_eig4 (which
-// skips these splits): inlined into k_eig4 the Jacobi cost it 28 bytes of scratch per lane.
+// 8e-6 came back 2e-9 off in the first soak of round 4.)  A kernel of its own, one wave per split, launched BEHIND k_eig4 and
+// only for the splits that need it - a score below 1e-3 (where the floor of the sum shows) or no certificate: inlined into
+// k_eig4 the Jacobi cost that kernel 28 bytes of scratch per lane, and run for every short side ahead of it (one wave's
+// Jacobi is 60 us of latency) it cost the north-star pipeline 0.06 ms.
 template <typename GT>
 __global__ __launch_bounds__(64) void k_eig4_small(const SplitDev* __restrict__ splits, const int2* __restrict__ dims,
                                                    const GT* __restrict__ grams, double* __restrict__ scores,
@@ -47,6 +49,7 @@ __global__ __launch_bounds__(64) void k_eig4_small(const SplitDev* __restrict__ 
     const SplitDev& sp = splits[sid];
     const int R = min(dims[sid].x, sp.rcap);
     if (R <= 4 || R > EIG_B) return;   // (R <= 4 and the all-zero matrix: k_eig4)
+    if (!(status[sid] & 3) && !(scores[sid] <= 1e-3)) return;   // certified and far above the floor of the iteration's sum
     const GT* __restrict__ G = grams + sp.g_off;
     const int64_t gp = sp.g_pitch;
     const int lane = threadIdx.x;
@@ -121,7 +124,6 @@ __global__ __launch_bounds__(SPK_THREADS) void k_eig4(const SplitDev* __restrict
         }
         return;
     }
-    if (R <= EIG_B) return;   // (k_eig4_small, launched just before, has scored it)
     // the 4 rows with the largest diagonal (for count matrices the dominant singular vectors sit on the rows of the few very
     // frequent patterns): candidates = (value bits, low 10 bits replaced by 1023 - row), extracted in descending order
     unsigned long long bound = ~0ull;
@@ -264,6 +266,12 @@ int launch_eigen4(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<Spl
         attr.done(ctx->device);
     }
     PhaseScope ps(ctx, SP_PHASE_EIGEN);
+    if (g_i32)
+        hipLaunchKernelGGL(k_eig4<int>, dim3((unsigned)splits.size()), dim3(SPK_THREADS), lds, ctx->stream, splits_dev, dims,
+                           (const int*)grams, scores, status, order_dev);
+    else
+        hipLaunchKernelGGL(k_eig4<double>, dim3((unsigned)splits.size()), dim3(SPK_THREADS), lds, ctx->stream, splits_dev, dims,
+                           (const double*)grams, scores, status, order_dev);
     int minr = EIG_MAXR;
     for (const auto& sp : splits) minr = std::min(minr, (int)sp.rcap);
     if (minr <= 64) {   // (a side of <= 16 compact rows has rcap = 64: only then can the small kernel have anything to do)
@@ -274,12 +282,6 @@ int launch_eigen4(sp_ctx* ctx, const SplitDev* splits_dev, const std::vector<Spl
             hipLaunchKernelGGL(k_eig4_small<double>, dim3((unsigned)splits.size()), dim3(64), 0, ctx->stream, splits_dev, dims,
                                (const double*)grams, scores, status);
     }
-    if (g_i32)
-        hipLaunchKernelGGL(k_eig4<int>, dim3((unsigned)splits.size()), dim3(SPK_THREADS), lds, ctx->stream, splits_dev, dims,
-                           (const int*)grams, scores, status, order_dev);
-    else
-        hipLaunchKernelGGL(k_eig4<double>, dim3((unsigned)splits.size()), dim3(SPK_THREADS), lds, ctx->stream, splits_dev, dims,
-                           (const double*)grams, scores, status, order_dev);
     SP_HIP(hipGetLastError());
     return SP_OK;
 }

@@ -67,8 +67,8 @@ def test_pmc_records_are_hash_and_shape_checked(tmp_path, monkeypatch):
     # time: a stale record makes `frac` null with a reason, it does not break anything)
     monkeypatch.setattr(bench, "ROOT", ROOT)
     import glob
-    mine = glob.glob(os.path.join(ROOT, "profiles", "r03_pmc_binding_*.json"))
-    assert len(mine) >= 5
+    mine = glob.glob(os.path.join(ROOT, "profiles", "r03_pmc_binding_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r04_pmc_binding_*.json"))
+    assert len(mine) >= 10      # five workloads a round
     for f in mine:
         prov = json.load(open(f))["_provenance"]
         assert len(prov["source_hash"]) == 16 and int(prov["source_hash"], 16) >= 0
