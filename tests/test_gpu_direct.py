@@ -299,3 +299,31 @@ def test_node_api_one_device(sp, golden):
     lib = _lib.load()
     assert lib.sp_node_create(_lib.device_count() + 1, C.byref(h)) == _lib.SP_EINVAL
     assert b"visible" in lib.sp_last_error()
+
+
+def test_float_weight_table_12_taxa_ends_in_direct_solver(sp):
+    """A 12-taxon table with real-valued weights (not count / N: the big-table form's float path) and no gap behind the 4th
+    singular value: the 4-wide and 8-wide blocks certify next to nothing, the flagged splits are finished by the direct
+    solver on the fp64 Gram matrix of the WEIGHTS - every score within 1e-10 of the oracle, nothing flagged, no warning."""
+    import warnings
+
+    from tests.test_gpu_parity import _copy_mutate_table
+
+    rng = np.random.default_rng(12)
+    n = 12
+    keys, counts = _copy_mutate_table(rng, n, 20000, 3)
+    names = taxa_names(n)
+    w = counts / float(counts.sum()) * (1.0 + 1e-3 * rng.random(len(counts)))
+    dev = sp.DeviceAlignment.from_arrays(keys, w, n, taxa=names, exact=False)
+    splits = []
+    for k in (2, 3, 4, 5, 6, 6, 5, 4, 3, 6):
+        left = sorted(rng.choice(n, size=k, replace=False).tolist())
+        splits.append((tuple(names[t] for t in left), tuple(names[t] for t in range(n) if t not in left)))
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got, st = sp.score_splits(dev, splits, return_status=True)
+    assert not any(issubclass(c.category, RuntimeWarning) for c in caught)
+    want = np.array([O.dense_split_score(O.reduced_flattening_packed(keys, w, n, [names.index(t) for t in s[0]],
+                                                                     [names.index(t) for t in s[1]])[0]) for s in splits])
+    assert not np.any(st & 3) and np.count_nonzero(st & 4) >= 5
+    assert np.abs(got - want).max() <= SCORE_TOL
