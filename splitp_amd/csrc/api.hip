@@ -127,6 +127,7 @@ extern "C" int sp_ctx_create(int device, void* stream, sp_ctx** out) {
     c->opt.big_by_keys = env_flag("SPLITP_BIG_BY_KEYS");
     c->opt.subscore_jacobi = env_flag("SPLITP_SUBSCORE_JACOBI");
     if (const char* sw = getenv("SPLITP_SUBSCORE_WAVES")) c->opt.subscore_waves = atoi(sw);
+    if (const char* sp = getenv("SPLITP_SUBSCORE_PAIR")) c->opt.subscore_pair = atoi(sp);
     c->opt.divergence_global = env_flag("SPLITP_DIVERGENCE_GLOBAL");
     c->opt.gram_tile64 = env_flag("SPLITP_GRAM_TILE64");
     c->opt.eigen_one_stream = env_flag("SPLITP_EIGEN_ONE_STREAM");
@@ -147,6 +148,7 @@ static long long* option_slot(sp_ctx* c, const char* name, int** as_int) {
     else if (!strcmp(name, "big_by_keys")) *as_int = &c->opt.big_by_keys;
     else if (!strcmp(name, "subscore_jacobi")) *as_int = &c->opt.subscore_jacobi;
     else if (!strcmp(name, "subscore_waves")) *as_int = &c->opt.subscore_waves;
+    else if (!strcmp(name, "subscore_pair")) *as_int = &c->opt.subscore_pair;
     else if (!strcmp(name, "divergence_global")) *as_int = &c->opt.divergence_global;
     else if (!strcmp(name, "hist_sort")) *as_int = &c->opt.hist_sort;
     else if (!strcmp(name, "wide_cap")) *as_int = &c->opt.wide_cap;
@@ -200,7 +202,7 @@ extern "C" int sp_ctx_destroy(sp_ctx* c) {
     for (auto e : c->timer.pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->splits, &c->bitmaps, &c->coords, &c->dims, &c->mats,  &c->grams,  &c->eigws,
                       &c->scores, &c->status,  &c->misc,   &c->misc2, &c->gram_items, &c->aldescs, &c->slabs, &c->chain,
-                      &c->splits_launch, &c->hist_bins, &c->hist_blk, &c->hist_off, &c->enum_buf};
+                      &c->splits_launch, &c->hist_bins, &c->hist_blk, &c->hist_off, &c->enum_buf, &c->pair_dev};
     if (c->cache && c->cache->sparse) (void)sp_plan_release(c->cache->sparse);
     delete c->cache;
     for (auto* b : bufs) b->release();

@@ -128,6 +128,7 @@ struct CtxOptions {
     int force_big = 0;          // every flattening score on the big-table form
     int big_by_keys = 0;        // ... with its sort-based compaction
     int subscore_jacobi = 0;    // Jacobi kernel for the batched subflattening score
+    int subscore_pair = 1;      // two splits a wave (subflat_pair.hip) where the batch's classes are known; 0 = one split a wave
     int subscore_waves = 0;     // waves per workgroup of the fast subflattening score kernel (0 = the shape that fills the CU)
     int divergence_global = 0;  // global-memory form of the mutual-information score
     int hist_sort = -1;         // -1 auto, 0 direct bins, 1 sort + run-length encode
@@ -142,6 +143,16 @@ struct CtxOptions {
     int sort_digit_bits = 0;    // one-sweep sorts: 9 = 9-bit digits (test switch; measured slower per pass than the pass they save), else 8
     int eigen_block16 = 0;      // dense route / generic matrices: rounds 1 - 3's 16-wide block pipeline (eigen.hip) instead of the
                                 // certified 4-wide kernel (eig4.hip) - kept as a cross-check
+};
+
+// the size classes of one batch (at most 16); the kernel reads a copy in device memory.  Positions are indices into `order` (or, without one, into
+// the split list itself).
+struct PairClasses {
+    int nclass;
+    int rows[16];            // 3 * (smaller side) + 1
+    long long start[16];     // first position of the class
+    long long count[16];     // its splits
+    long long poff[17];      // pairs before the class: a class of c splits makes (c + 1) / 2 pairs
 };
 
 struct sp_ctx {
@@ -186,6 +197,10 @@ struct sp_ctx {
     DevBuf enum_buf;
     long long enum_key[6] = {0, 0, 0, 0, 0, 0};
     bool enum_valid = false;
+    // size classes of the last paired subflattening batch (subflat_pair.hip), host copy and the device copy the kernel reads
+    PairClasses pair_host = {};
+    DevBuf pair_dev;
+    bool pair_valid = false;
 };
 
 struct sp_alignment {

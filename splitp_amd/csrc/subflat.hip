@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "subflat_common.h"
 
 #define MOM_THREADS 256
 #define MOM_CHUNK 256
@@ -129,10 +130,6 @@ extern "C" int sp_moment_matrix(sp_alignment* al, int64_t* out_i64, double* out_
     });
 }
 
-// idx(S) + [3n] for one split half
-__device__ __forceinline__ int sub_index(const int8_t* taxa, int cnt, int n, int i) {
-    return i < 3 * cnt ? 3 * taxa[i / 3] + (i % 3) : 3 * n;
-}
 
 template <bool EXACT>
 __global__ void k_subflatten_gather(const void* __restrict__ Mv, int n, double N, const SplitDev* __restrict__ sp_,
@@ -196,11 +193,6 @@ extern "C" int sp_subflatten(sp_alignment* al, const int32_t* oa, int a, const i
 // diagonalised by parallel-order cyclic Jacobi; score = sqrt(max(0, 1 - top4 / trace)).
 #define SUB_WAVES 4
 
-__device__ __forceinline__ void wave_sync_lds2() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 template <bool EXACT>
 __global__ __launch_bounds__(SUB_WAVES * 64) void k_subscore(const void* __restrict__ Mv, int n,
@@ -359,25 +351,13 @@ __global__ __launch_bounds__(SUB_WAVES * 64) void k_subscore(const void* __restr
 // shifts a pass, 13 passes (17^13 = 9.9e15 > 2^53: the bracket ends below eps * span; a 14th pass only moved noise).  Both steps are backward stable: eigenvalues good to a few eps * lambda_1,
 // which is what 1 - top4 / trace needs.  No iteration that could fail to converge.
 #define SUBT_MAXWAVES 16  // waves of a workgroup: chosen per launch so that the CU holds as many waves as its LDS allows
-#define SUBT_MMAX 61
 #ifndef SUBT_PASSES
 #define SUBT_PASSES 13
 #endif
-#define SPK_LDS_TOTAL 163840   // LDS of a CU
 
 // Sums over lanes of a wave, returned to all of them (subt_row0_sum, subt_half_sum below): two quad steps and two row shifts
 // on the DPP path (no LDS crossbar), a row_bcast step where two DPP rows are summed, the total through scalar registers.
 // Fixed order.
-template <int CTRL, int ROWS = 0xF>
-__device__ __forceinline__ double subt_dpp(double x) {   // (rows outside the mask ROWS receive 0)
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWS, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWS, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double subt_readlane(double x, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
-}
 // Per-wave LDS: de (32 pairs {d_i, e2_(i-1)}: diagonal and squared sub-diagonal of the tridiagonal matrix, one 16-byte
 // read per step of the Sturm recurrence), G (rmax rows of pitch P = rmax | 1 doubles: an odd pitch keeps a column walk off
 // one bank), v, w (32 doubles each), urow (32 x u16: row offset u * m into the staged matrix, < 61 * 61) and vcol
@@ -385,36 +365,6 @@ __device__ __forceinline__ double subt_readlane(double x, int l) {
 // instead of 9.6.
 __host__ __device__ __forceinline__ size_t subt_wave_bytes(int rmax) {
     return ((size_t)rmax * (rmax | 1) * 8 + 4 * 32 * 8 + 32 * 2 + 64 + 15) & ~(size_t)15;
-}
-// max(|a|, |b|) as one instruction (fmax(fabs(a), fabs(b)) adds a canonicalising v_max_f64 x, x per operand)
-__device__ __forceinline__ double subt_max_abs(double a, double b) {
-    double r;
-    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-typedef double subt_d2 __attribute__((ext_vector_type(2)));
-// Steps I, I + 1, ... r - 1 of the minor recurrence (k_subscore_tri), written out by recursion: constant LDS offsets, the
-// pair (P_(i-1), P_i) changes registers instead of being moved, one scalar test a step (`#pragma unroll` leaves this loop
-// rolled).  de[i] = {d_i, e2_(i-1)}, v = de[I]; the sign of every new minor is shifted into `mask`.
-template <int I>
-__device__ __forceinline__ void subt_minor_steps(int r, const subt_d2* de, double sigma, double pp, double pc, subt_d2 v,
-                                                 unsigned& mask) {
-    if constexpr (I < 31) {
-        if (I < r) {
-            // the next step's pair is requested before this step's arithmetic (nothing is scheduled across the barrier), or
-            // the compiler moves the read down to its use and every step waits out an LDS round trip (de has 32 pairs)
-            const subt_d2 vn = de[I + 1];
-            __builtin_amdgcn_sched_barrier(0);
-            double pn = fma(v.x - sigma, pc, -(v.y * pp));
-            mask = __builtin_amdgcn_alignbit(mask, (unsigned)__double2hiint(pn), 31);   // (mask << 1) | sign
-            if ((I & 7) == 0) {
-                const int ex = __builtin_amdgcn_frexp_exp(subt_max_abs(pn, pc));
-                pn = ldexp(pn, -ex);
-                pc = ldexp(pc, -ex);
-            }
-            subt_minor_steps<I + 1>(r, de, sigma, pc, pn, vn, mask);
-        }
-    }
 }
 // The same recurrence with the table read through the SCALAR cache: every lane of the wave needs the same pair {d_i,
 // e2_(i-1)} at step i, and as a broadcast LDS read that is 1 KB of LDS bandwidth a step - with 13 passes a third of the
@@ -773,8 +723,11 @@ __global__ __launch_bounds__(SUBT_MAXWAVES * 64) void k_subscore_tri(const void*
 
 // Scores of S splits whose taxon lists (int8, split-major) and first-side sizes already sit on the device.
 // scores_out / status_out: device buffers of the caller (NULL = the context's own, ctx->scores / ctx->status).
+// pc / order (optional): the batch's size classes and, for a list that is not sorted by class, the positions' split indices
+// - what the two-splits-a-wave kernel (subflat_pair.hip) needs; without them the one-split-a-wave kernel runs.
 static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da, int64_t S, int kmax,
-                           double* scores_out = nullptr, int* status_out = nullptr);
+                           double* scores_out = nullptr, int* status_out = nullptr, const PairClasses* pc = nullptr,
+                           const int* order = nullptr);
 
 int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t S) {
     sp_ctx* ctx = al->ctx;
@@ -794,13 +747,35 @@ int run_subflat_route(sp_alignment* al, const int32_t* split_taxa, const int32_t
         }
         kmax = std::max(kmax, std::min(a, n - a));
     }
-    SP_CHECK(ctx->coords.ensure(taxa8.size() + (size_t)S * 4 + 64));
+    // positions sorted by size class (stable): the two-splits-a-wave kernel pairs neighbours of one class
+    PairClasses pc;
+    memset(&pc, 0, sizeof(pc));   // (padding too: the table is compared bytewise with the context's copy)
+    std::vector<int> order((size_t)S);
+    {
+        std::vector<long long> per(n / 2 + 2, 0);
+        for (int64_t s = 0; s < S; ++s) ++per[std::min(split_a[s], n - split_a[s])];
+        std::vector<long long> at(n / 2 + 2, 0);
+        for (int b = 1; b <= n / 2; ++b) {
+            if (!per[b] || pc.nclass >= 16) continue;
+            const int c = pc.nclass++;
+            pc.rows[c] = 3 * b + 1;
+            pc.start[c] = c ? pc.start[c - 1] + pc.count[c - 1] : 0;
+            pc.count[c] = per[b];
+            pc.poff[c + 1] = pc.poff[c] + (per[b] + 1) / 2;
+            at[b] = pc.start[c];
+        }
+        for (int64_t s = 0; s < S; ++s) order[(size_t)at[std::min(split_a[s], n - split_a[s])]++] = (int)s;
+    }
+    const size_t taxa_bytes = (taxa8.size() + 15) & ~(size_t)15;
+    SP_CHECK(ctx->coords.ensure(taxa_bytes + (size_t)S * 8 + 64));
     int8_t* dtaxa = ctx->coords.as<int8_t>();
-    int* da = reinterpret_cast<int*>(dtaxa + ((taxa8.size() + 15) & ~(size_t)15));
+    int* da = reinterpret_cast<int*>(dtaxa + taxa_bytes);
+    int* dorder = da + S;
     SP_HIP(hipMemcpyAsync(dtaxa, taxa8.data(), taxa8.size(), hipMemcpyHostToDevice, ctx->stream));
     SP_HIP(hipMemcpyAsync(da, split_a, (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
-    SP_HIP(hipStreamSynchronize(ctx->stream));  // taxa8 is a host temporary
-    return launch_subscore(al, dtaxa, da, S, kmax);
+    SP_HIP(hipMemcpyAsync(dorder, order.data(), (size_t)S * 4, hipMemcpyHostToDevice, ctx->stream));
+    SP_HIP(hipStreamSynchronize(ctx->stream));  // taxa8 and order are host temporaries
+    return launch_subscore(al, dtaxa, da, S, kmax, nullptr, nullptr, n / 2 <= 16 ? &pc : nullptr, dorder);
 }
 
 // ---- every split of the taxa, enumerated on the device ----------------------------------------------------------------
@@ -951,13 +926,22 @@ int run_subflat_all_splits(sp_alignment* al, int trivial, int size, int shard_ra
     if (n_out) *n_out = total;
     if (!score || total == 0) return SP_OK;
     int kmax = 0;
-    for (size_t q = 0; q < sizes.size(); ++q)
-        if (counts[q]) kmax = std::max(kmax, sizes[q]);
-    return launch_subscore(al, dtaxa, da, total, kmax, scores_out, status_out);
+    PairClasses pc;
+    memset(&pc, 0, sizeof(pc));   // (padding too: the table is compared bytewise with the context's copy)
+    for (size_t q = 0; q < sizes.size(); ++q) {
+        if (!counts[q]) continue;
+        kmax = std::max(kmax, sizes[q]);
+        const int c = pc.nclass++;
+        pc.rows[c] = 3 * sizes[q] + 1;
+        pc.start[c] = c ? pc.start[c - 1] + pc.count[c - 1] : 0;   // (classes without splits take no positions)
+        pc.count[c] = (long long)counts[q];
+        pc.poff[c + 1] = pc.poff[c] + (pc.count[c] + 1) / 2;
+    }
+    return launch_subscore(al, dtaxa, da, total, kmax, scores_out, status_out, &pc);
 }
 
 static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da, int64_t S, int kmax, double* scores_out,
-                           int* status_out) {
+                           int* status_out, const PairClasses* pc, const int* order) {
     sp_ctx* ctx = al->ctx;
     const int n = al->n_taxa;
     SP_CHECK(ensure_moments(al));
@@ -975,6 +959,7 @@ static int launch_subscore(sp_alignment* al, const int8_t* dtaxa, const int* da,
     if (mdim <= SUBT_MMAX && rmax <= 32 && !ctx->opt.subscore_jacobi) {   // fast form (the option keeps the Jacobi kernel testable)
         const bool m32 = al->exact && al->N < ((int64_t)1 << 31);
         const int rt = 3 * kmax + 1;   // longest row side of the batch
+        if (pc && ctx->opt.subscore_pair) return launch_subscore_pair(al, dtaxa, da, order, *pc, rt, scores_out, status_out);
         const size_t ms_bytes = ((size_t)mdim * mdim * (m32 ? 4 : 8) + 15) & ~(size_t)15;
         const int dev_cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
         const void* kfn = m32 ? reinterpret_cast<const void*>(k_subscore_tri<true, true>)

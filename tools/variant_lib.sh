@@ -10,7 +10,7 @@ csrc=$root/splitp_amd/csrc
 obj=/tmp/variant_$(basename $src .hip)_$$.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-function "$@" -c $csrc/$src -o $obj
 others=""
-for f in api flatten gram gram_i8 eigen sparse sparse_big subflat hist divergence finish eig4 node; do
+for f in api flatten gram gram_i8 eigen sparse sparse_big subflat subflat_pair hist divergence finish eig4 node; do
   if [ "$f.hip" = "$src" ]; then others="$others $obj"; else others="$others $csrc/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out $others
