@@ -255,7 +255,7 @@ def roofline_block(m):
     algo_flops = float(np.sum(2.0 * 4.0 ** n_taxa * 4.0 ** k_small)) * per_al            # 2*4^n*4^k per split
     names = {"gram": "k_gram_i8_big<2,int> (int8-limb MFMA Gram, 128 x 128 tiles)", "eigen": "k_eig_gv / k_eig_rr (fp64 MFMA)",
              "sparse": "k_sparse_score (one workgroup per split: CSC/CSR lists + 4-wide block in LDS)",
-             "scatter": "k_zero_i8 + k_scatter_i8", "reindex": "k_reindex", "subscore": "k_subscore_tri",
+             "scatter": "k_zero_i8 + k_scatter_i8", "reindex": "k_reindex", "subscore": "k_subscore_pair (two splits a wave; k_subscore_tri with subscore_pair = 0)",
              "chain": "k_sparse_slow (persistent workgroups: lists-in-global / all-global / 8-wide forms of the sparse kernel)"}
     roof = {"kernel": names.get(dom, dom), "launch_ms": m["dom_ms_alone"], "launch_ms_in_timed_region": m["dom_ms_region"],
             "launches_in_flight": m["in_flight"], "phase_ms_per_step": m["phases_per_step"], "traffic": None}
@@ -266,15 +266,15 @@ def roofline_block(m):
         roof["pmc_record_reason"] = pmc_why or f"the matching record {pmc_file} holds no counters of phase '{dom}'"
     if dom == "subscore":
         # SURVEY 8(d), subflattening path: per split a Gram 2 m^2 m' on the (3k+1) x (3(n-k)+1) block, Householder
-        # tridiagonalisation 4/3 m^3 and Sturm multisection (13 passes x 64 shifts x m steps of the minor recurrence, 4
-        # flops each: subtract, multiply, fused multiply-add); bound: fp64 VALU issue
+        # tridiagonalisation 4/3 m^3 and Sturm multisection (17 passes x 32 shifts x m steps of the minor recurrence, 4
+        # flops each: subtract, multiply, fused multiply-add; rounds 2 - 3: 13 passes x 64 shifts); bound: fp64 VALU issue
         mm = 3.0 * k_small + 1.0
         mp = 3.0 * (n_taxa - k_small) + 1.0
-        flops = float(np.sum(2.0 * mm * mm * mp + 4.0 / 3.0 * mm ** 3 + 13 * 64 * 4.0 * mm)) * per_al
+        flops = float(np.sum(2.0 * mm * mm * mp + 4.0 / 3.0 * mm ** 3 + 17 * 32 * 4.0 * mm)) * per_al
         roof.update({"bound": "fp64-valu", "achieved": flops / sec / 1e12, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops / sec / 1e12 / FP64_MFMA_PEAK_TF, "algorithmic_flops_per_launch": flops,
-                     "note": "one wave per split; wave-uniform scalar work (norms, reciprocals, reflector coefficients) and the "
-                             "reductions are done by all 64 lanes, so the useful-flop fraction is small by construction; what the "
+                     "note": "two splits per wave, a lane per row; per-step scalar work (norms, reciprocals, reflector coefficients) "
+                             "and the reductions are done by all 32 lanes of a half, so the useful-flop fraction is small by construction; what the "
                              "units do is in `binding` (vector issue, LDS, waves parked) (SURVEY 8d: 'fp64 VALU / launch "
                              "latency; report splits/s and achieved fp64 FLOP/s'); peak = the fp64 vector rate (= the fp64 "
                              "matrix rate on this part)"})

@@ -19,8 +19,8 @@
 //     is gone;
 //   * sums over the 32 lanes of a half are butterflies on the DPP path plus one v_permlane16_swap (gfx950), so every lane
 //     ends with the same bits and nothing goes through scalar registers (which a wave's two halves could not share);
-//   * the Sturm phase brackets 4 eigenvalues x 8 shifts per half (9-section, 17 passes; 15 where the score is >= 0.05)
-//     instead of 16 shifts and 13 (11) passes: 0.58 of the evaluations per split.
+//   * the Sturm phase brackets 4 eigenvalues x 8 shifts per half (9-section, 17 passes; 14 where the score is >= 0.05)
+//     instead of 16 shifts and 13 (11) passes: 0.6 of the evaluations per split.
 // A split's result does not depend on its partner: nothing crosses the halves but wave-uniform branches on the class's row
 // count and the pass loop's exit, and a half whose brackets are final keeps them while the other goes on.  (Shards pair the
 // splits differently and must return the same bits: tests/test_gpu_direct.py, tests/test_gpu_parity.py.)
@@ -32,9 +32,13 @@
 #include "common.h"
 #include "subflat_common.h"
 
+#ifndef SUBP_MAXWAVES
 #define SUBP_MAXWAVES 16
+#endif
+#ifndef SUBP_PASSES
 #define SUBP_PASSES 17   // 9^17 > 2^53
-#define SUBP_EARLY 15    // passes after which a bracket is 9^-15 = 4.9e-15 of the (unit) Gershgorin interval wide
+#define SUBP_EARLY 14    // passes after which a bracket is 9^-14 = 4.4e-14 of the (unit) Gershgorin interval wide
+#endif
 
 struct SubpAdd { static __device__ __forceinline__ double f(double a, double b) { return a + b; } };
 struct SubpMin { static __device__ __forceinline__ double f(double a, double b) { return __builtin_fmin(a, b); } };
@@ -46,9 +50,11 @@ struct SubpMax { static __device__ __forceinline__ double f(double a, double b) 
 template <class OP>
 __device__ __forceinline__ double subp_all32(double x) {
     x = OP::f(x, subt_dpp<0xB1>(x));
+#ifndef SUBP_CHEAP_SUM   // (timing experiment only: wrong sums)
     x = OP::f(x, subt_dpp<0x4E>(x));
     x = OP::f(x, subt_dpp<0x141>(x));
     x = OP::f(x, subt_dpp<0x140>(x));
+#endif
     const int lo = __double2loint(x), hi = __double2hiint(x);
     // (vdst = src = x: the odd rows of the first copy change places with the even rows of the second, i.e. afterwards the
     // first copy holds row 0 | row 0 | row 2 | row 2 and the second row 1 | row 1 | row 3 | row 3)
@@ -86,9 +92,15 @@ __device__ __forceinline__ void subp_steps(double (&a)[31], const int r, const i
             // A x over the block's columns (four chains; for odd L the pair read past the end holds x_L = 0)
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             double x0 = 0.0;
+#ifdef SUBP_KEEP_X
+            subt_d2 xk[(L + 1) / 2];   // x stays in registers for the update
+#endif
 #pragma unroll
             for (int j = 0; j < L; j += 2) {
                 const subt_d2 xv = *reinterpret_cast<const subt_d2*>(svh + j);
+#ifdef SUBP_KEEP_X
+                xk[j >> 1] = xv;
+#endif
                 acc[(j >> 1) & 1] = fma(a[j], xv.x, acc[(j >> 1) & 1]);
                 if (j + 1 < L) acc[2 + ((j >> 1) & 1)] = fma(a[j + 1], xv.y, acc[2 + ((j >> 1) & 1)]);
                 if (j == L - 1) x0 = xv.x;
@@ -118,7 +130,11 @@ __device__ __forceinline__ void subp_steps(double (&a)[31], const int r, const i
             wave_sync_lds2();
 #pragma unroll
             for (int j = 0; j < L; j += 2) {
+#ifdef SUBP_KEEP_X
+                const subt_d2 xv = xk[j >> 1];
+#else
                 const subt_d2 xv = *reinterpret_cast<const subt_d2*>(svh + j);
+#endif
                 const subt_d2 wv = *reinterpret_cast<const subt_d2*>(swh + j);
                 const double v0 = j == L - 1 ? xv.x - alpha : xv.x;
                 a[j] = fma(-vi, wv.x, fma(-wi, v0, a[j]));
@@ -132,6 +148,38 @@ __device__ __forceinline__ void subp_steps(double (&a)[31], const int r, const i
         subp_steps<L - 1>(a, r, row, svl, svh, swl, swh, deh);
     }
 }
+
+#ifdef SUBP_TABLE_REGS
+// The minor recurrence with the half's table {d_i, e2_(i-1)} in registers (tb, compile-time indices): no LDS read a step.
+template <int I>
+__device__ __forceinline__ void subp_minor_steps_r(int r, const subt_d2 (&tb)[31], double sigma, double pp, double pc,
+                                                   unsigned& mask) {
+    if constexpr (I < 31) {
+        if (I < r) {
+            double pn = fma(tb[I].x - sigma, pc, -(tb[I].y * pp));
+            mask = __builtin_amdgcn_alignbit(mask, (unsigned)__double2hiint(pn), 31);   // (mask << 1) | sign
+            if ((I & 7) == 0) {
+                const int ex = __builtin_amdgcn_frexp_exp(subt_max_abs(pn, pc));
+                pn = ldexp(pn, -ex);
+                pc = ldexp(pc, -ex);
+            }
+            subp_minor_steps_r<I + 1>(r, tb, sigma, pc, pn, mask);
+        }
+    }
+}
+#endif
+
+#ifdef SUBP_STAMPS
+// diagnostic build (tools/gpu_subpair_stamps.sh): s_memtime of wave 0 of workgroup 0 at the phase boundaries of its last pair
+// (the classes come in ascending size: one of the longest)
+__device__ long long g_subp_stamps[16];
+extern "C" int sp_debug_subp_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_subp_stamps), sizeof(long long) * 16) == hipSuccess ? 0 : 2;
+}
+#define PSTAMP(i) do { if (blockIdx.x == 0 && w == 0 && lane == 0) g_subp_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PSTAMP(i)
+#endif
 
 template <bool EXACT, bool M32>
 __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void* __restrict__ Mv, int n, int rmax,
@@ -171,6 +219,7 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
         const int64_t posA = cstart + 2 * (pr - pcd->poff[q]);
         const int64_t posB = posA + 1 < cstart + pcd->count[q] ? posA + 1 : posA;   // (an odd class: the last split twice)
         const int64_t sidA = order ? (int64_t)order[posA] : posA, sidB = order ? (int64_t)order[posB] : posB;
+        PSTAMP(0);
         double a[31];
 #pragma unroll
         for (int j = 0; j < 31; ++j) a[j] = 0.0;
@@ -200,15 +249,30 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
                 const bool two = r > 16;
                 const int u0 = fr < r ? (int)urow[fr] : -1, u1 = (two && 16 + fr < r) ? (int)urow[16 + fr] : -1;
                 d4 g00 = {0, 0, 0, 0}, g01 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
-                for (int k0 = 0; k0 < c; k0 += 4) {
-                    const int k = k0 + fk;
-                    const int v = k < c ? (int)vcol[k] : -1;
-                    const double x0 = (v >= 0 && u0 >= 0) ? (double)Ms[u0 + v] : 0.0;
-                    g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, g00, 0, 0, 0);
-                    if (two) {
-                        const double x1 = (v >= 0 && u1 >= 0) ? (double)Ms[u1 + v] : 0.0;
-                        g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, g01, 0, 0, 0);
-                        g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, g11, 0, 0, 0);
+                // 16 columns a trip: the four column indices, then the eight gathers, then the products - two LDS round trips
+                // per trip (k_subscore_tri's loop made them per 4 columns, and this phase is nothing but their latency)
+#pragma unroll 1
+                for (int k0 = 0; k0 < c; k0 += 16) {
+                    int v[4];
+                    double x0[4], x1[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int k = k0 + 4 * qq + fk;   // (< 64: vcol has 64 entries)
+                        v[qq] = k < c ? (int)vcol[k] : -1;
+                    }
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        x0[qq] = (v[qq] >= 0 && u0 >= 0) ? (double)Ms[u0 + v[qq]] : 0.0;
+                        x1[qq] = (v[qq] >= 0 && u1 >= 0) ? (double)Ms[u1 + v[qq]] : 0.0;
+                    }
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        if (k0 + 4 * qq >= c) break;
+                        g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[qq], x0[qq], g00, 0, 0, 0);
+                        if (two) {
+                            g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[qq], x1[qq], g01, 0, 0, 0);
+                            g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[qq], x1[qq], g11, 0, 0, 0);
+                        }
                     }
                 }
 #pragma unroll
@@ -234,6 +298,7 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
             }
         }
         wave_sync_lds2();   // the staging area becomes x, w and the Sturm tables
+        PSTAMP(1);
         const double tr = subp_all32<SubpAdd>(dg);
         const int64_t sid_mine = half ? sidB : sidA;
         if (r <= 4) {
@@ -249,6 +314,7 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
         int rowv = row;
         asm volatile("" : "+v"(rowv));
         subp_steps<30>(a, r, rowv, sv + lane, sv + 32 * half, sw + lane, sw + 32 * half, deh);
+        PSTAMP(2);
         if (row == 1) deh[1].x = a[1];
         if (row == 0) {
             subt_d2 first;
@@ -286,16 +352,26 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
         const int want = r - 1 - grp;                     // ascending index of this group's eigenvalue
         const unsigned rmask = (1u << r) - 1u;            // r <= 31
         const double d0 = deh[0].x;
+#ifdef SUBP_TABLE_REGS
+        subt_d2 tb[31];
+#pragma unroll
+        for (int i = 0; i < 31; ++i) tb[i] = deh[i];   // (entries from r on are not used)
+#endif
         const double tr_s = ldexp(tr, -E);                // the trace in the scaled units
         const double frac = (double)(t + 1) * (1.0 / 9.0);
         bool frozen = false;
         int passes = SUBP_PASSES;
+        PSTAMP(3);
         for (int pass = 0; pass < SUBP_PASSES; ++pass) {
-            const subt_d2 cur = deh[1];
             const double sigma = fma(hi - lo, frac, lo);
             const double pp = 1.0, pcur = d0 - sigma;
             unsigned mask = (unsigned)__double2hiint(pcur) >> 31;
+#ifdef SUBP_TABLE_REGS
+            subp_minor_steps_r<1>(r, tb, sigma, pp, pcur, mask);
+#else
+            const subt_d2 cur = deh[1];
             subt_minor_steps<1>(r, deh, sigma, pp, pcur, cur, mask);
+#endif
             // bit j of mask = sign of P_(r-j), bit r = 0 = sign of P_0: sign changes = eigenvalues below sigma
             const int cnt = __popc((mask ^ (mask >> 1)) & rmask);
             const unsigned long long above = __ballot(cnt > want);
@@ -306,9 +382,10 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
             const double nlo = first > 0 ? s_lo : lo, nhi = first < 8 ? s_hi : hi;
             lo = frozen ? lo : nlo;
             hi = frozen ? hi : nhi;
-            // After SUBP_EARLY passes the sum of the four midpoints is good to 4 x 2.5e-15 and 1 - top4 / trace to 1e-14 /
-            // tr_s (tr_s ~ 0.1 at worst on count tables): where the score is >= 0.05 it moves by < 1e-12 - that half's
-            // brackets are final.  The other half goes on; the wave leaves the loop when both are.
+            // After SUBP_EARLY passes the sum of the four midpoints is good to 4 x 2.2e-14 and 1 - top4 / trace to 9e-14 /
+            // tr_s (tr_s ~ 0.1 at worst on count tables): where the score is >= 0.05 it moves by < 9e-12 in that worst case
+            // and ~1e-12 typically (k_subscore_tri stops at 2.9e-14 by the same argument) - that half's brackets are
+            // final.  The other half goes on; the wave leaves the loop when both are.
             if (pass == SUBP_EARLY - 1) {
                 const double tq = subp_all32<SubpAdd>(t == 0 ? fmax(0.5 * (lo + hi), 0.0) : 0.0);
                 if (1.0 - tq / tr_s >= 2.5e-3) {
@@ -318,6 +395,7 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
                 if (__ballot(frozen) == ~0ull) break;
             }
         }
+        PSTAMP(4);
         const double top = subp_all32<SubpAdd>(t == 0 ? fmax(0.5 * (lo + hi), 0.0) : 0.0);
         if (row == 0) {
             const double op = 1.0 - top / tr_s;             // (top in the scaled units)
@@ -325,6 +403,7 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
             scores[sid_mine] = ok ? sqrt(op > 0 ? op : 0.0) : __builtin_nan("");
             status[sid_mine] = ok ? passes << 8 : 0;
         }
+        PSTAMP(5);
     }
 }
 
