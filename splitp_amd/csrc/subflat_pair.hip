@@ -1,5 +1,5 @@
-// Subflattening scores, TWO splits per wave (round 4; replaces splitp/constructions.py:108-163 + phylogenetics.py:280-312
-// for every split of a batch, like subflat.hip's k_subscore_tri, whose numerical method this keeps: exact Gram matrix of the
+// Subflattening scores, TWO splits per wave (round 4; replaces splitp/constructions.py:108-163 + phylogenetics.py:280-312 for
+// every split of a batch, like subflat.hip's k_subscore_tri, whose numerical method this keeps: exact Gram matrix of the
 // <= 31-row block on the fp64 matrix cores, Householder tridiagonalisation, the four largest eigenvalues by multisection on
 // the Sturm count).
 //
@@ -21,6 +21,8 @@
 //     ends with the same bits and nothing goes through scalar registers (which a wave's two halves could not share);
 //   * the Sturm phase brackets 4 eigenvalues x 8 shifts per half (9-section, 17 passes; 14 where the score is >= 0.05)
 //     instead of 16 shifts and 13 (11) passes: 0.6 of the evaluations per split.
+// Measured and dropped on the way (tools/experiments/README.md): x kept in registers, the Sturm table in registers, shifts
+// placed around a secant guess, the Sturm phases of two pairs run together.
 // A split's result does not depend on its partner: nothing crosses the halves but wave-uniform branches on the class's row
 // count and the pass loop's exit, and a half whose brackets are final keeps them while the other goes on.  (Shards pair the
 // splits differently and must return the same bits: tests/test_gpu_direct.py, tests/test_gpu_parity.py.)
@@ -50,11 +52,9 @@ struct SubpMax { static __device__ __forceinline__ double f(double a, double b) 
 template <class OP>
 __device__ __forceinline__ double subp_all32(double x) {
     x = OP::f(x, subt_dpp<0xB1>(x));
-#ifndef SUBP_CHEAP_SUM   // (timing experiment only: wrong sums)
     x = OP::f(x, subt_dpp<0x4E>(x));
     x = OP::f(x, subt_dpp<0x141>(x));
     x = OP::f(x, subt_dpp<0x140>(x));
-#endif
     const int lo = __double2loint(x), hi = __double2hiint(x);
     // (vdst = src = x: the odd rows of the first copy change places with the even rows of the second, i.e. afterwards the
     // first copy holds row 0 | row 0 | row 2 | row 2 and the second row 1 | row 1 | row 3 | row 3)
@@ -92,15 +92,9 @@ __device__ __forceinline__ void subp_steps(double (&a)[31], const int r, const i
             // A x over the block's columns (four chains; for odd L the pair read past the end holds x_L = 0)
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             double x0 = 0.0;
-#ifdef SUBP_KEEP_X
-            subt_d2 xk[(L + 1) / 2];   // x stays in registers for the update
-#endif
 #pragma unroll
             for (int j = 0; j < L; j += 2) {
                 const subt_d2 xv = *reinterpret_cast<const subt_d2*>(svh + j);
-#ifdef SUBP_KEEP_X
-                xk[j >> 1] = xv;
-#endif
                 acc[(j >> 1) & 1] = fma(a[j], xv.x, acc[(j >> 1) & 1]);
                 if (j + 1 < L) acc[2 + ((j >> 1) & 1)] = fma(a[j + 1], xv.y, acc[2 + ((j >> 1) & 1)]);
                 if (j == L - 1) x0 = xv.x;
@@ -130,11 +124,7 @@ __device__ __forceinline__ void subp_steps(double (&a)[31], const int r, const i
             wave_sync_lds2();
 #pragma unroll
             for (int j = 0; j < L; j += 2) {
-#ifdef SUBP_KEEP_X
-                const subt_d2 xv = xk[j >> 1];
-#else
                 const subt_d2 xv = *reinterpret_cast<const subt_d2*>(svh + j);
-#endif
                 const subt_d2 wv = *reinterpret_cast<const subt_d2*>(swh + j);
                 const double v0 = j == L - 1 ? xv.x - alpha : xv.x;
                 a[j] = fma(-vi, wv.x, fma(-wi, v0, a[j]));
@@ -149,25 +139,6 @@ __device__ __forceinline__ void subp_steps(double (&a)[31], const int r, const i
     }
 }
 
-#ifdef SUBP_TABLE_REGS
-// The minor recurrence with the half's table {d_i, e2_(i-1)} in registers (tb, compile-time indices): no LDS read a step.
-template <int I>
-__device__ __forceinline__ void subp_minor_steps_r(int r, const subt_d2 (&tb)[31], double sigma, double pp, double pc,
-                                                   unsigned& mask) {
-    if constexpr (I < 31) {
-        if (I < r) {
-            double pn = fma(tb[I].x - sigma, pc, -(tb[I].y * pp));
-            mask = __builtin_amdgcn_alignbit(mask, (unsigned)__double2hiint(pn), 31);   // (mask << 1) | sign
-            if ((I & 7) == 0) {
-                const int ex = __builtin_amdgcn_frexp_exp(subt_max_abs(pn, pc));
-                pn = ldexp(pn, -ex);
-                pc = ldexp(pc, -ex);
-            }
-            subp_minor_steps_r<I + 1>(r, tb, sigma, pc, pn, mask);
-        }
-    }
-}
-#endif
 
 #ifdef SUBP_STAMPS
 // diagnostic build (tools/gpu_subpair_stamps.sh): s_memtime of wave 0 of workgroup 0 at the phase boundaries of its last pair
@@ -352,11 +323,6 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
         const int want = r - 1 - grp;                     // ascending index of this group's eigenvalue
         const unsigned rmask = (1u << r) - 1u;            // r <= 31
         const double d0 = deh[0].x;
-#ifdef SUBP_TABLE_REGS
-        subt_d2 tb[31];
-#pragma unroll
-        for (int i = 0; i < 31; ++i) tb[i] = deh[i];   // (entries from r on are not used)
-#endif
         const double tr_s = ldexp(tr, -E);                // the trace in the scaled units
         const double frac = (double)(t + 1) * (1.0 / 9.0);
         bool frozen = false;
@@ -366,12 +332,8 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
             const double sigma = fma(hi - lo, frac, lo);
             const double pp = 1.0, pcur = d0 - sigma;
             unsigned mask = (unsigned)__double2hiint(pcur) >> 31;
-#ifdef SUBP_TABLE_REGS
-            subp_minor_steps_r<1>(r, tb, sigma, pp, pcur, mask);
-#else
             const subt_d2 cur = deh[1];
             subt_minor_steps<1>(r, deh, sigma, pp, pcur, cur, mask);
-#endif
             // bit j of mask = sign of P_(r-j), bit r = 0 = sign of P_0: sign changes = eigenvalues below sigma
             const int cnt = __popc((mask ^ (mask >> 1)) & rmask);
             const unsigned long long above = __ballot(cnt > want);

@@ -24,15 +24,21 @@ for n, length, seed in ((6, 5000, 1), (8, 20_000, 2), (10, 50_000, 3), (12, 80_0
             res = {}
             for pair in (1, 0):
                 ctx.set_option("subscore_pair", pair)
-                res[pair] = sp.score_all_splits(dev, method=sp.Method.subflattening, trivial=trivial)
+                res[pair], st = sp.score_all_splits(dev, method=sp.Method.subflattening, trivial=trivial, return_status=True)
+                if pair == 1:
+                    flagged = int(np.count_nonzero(st & 3))
+                    ps = (st >> 8)[st != 0]
+                    passes = "passes mean %.2f max %d" % (ps.mean(), ps.max()) if ps.size else "passes -"
             ctx.set_option("subscore_pair", 1)
             a, b = res[1], res[0]
             nan = np.isnan(a) & np.isnan(b)
             d = np.where(nan, 0.0, np.abs(a - b))
             d2 = np.where(nan, 0.0, np.abs(a * a - b * b))
             bad = ~((d <= 1e-11) | (d2 <= 1e-13)) | (np.isnan(a) != np.isnan(b))
-            print(f"n {n:2d} {label:10s} trivial {int(trivial)}: {a.size:7d} splits  max |d| {np.nanmax(d):.2e}  max |d2| {np.nanmax(d2):.2e}  bad {int(bad.sum())}")
+            print(f"n {n:2d} {label:10s} trivial {int(trivial)}: {a.size:7d} splits  max |d| {np.nanmax(d):.2e}  max |d2| {np.nanmax(d2):.2e}  bad {int(bad.sum())}  {passes}  flagged {flagged}")
             worst = max(worst, float(np.nanmax(np.minimum(d, d2 * 100))))
+            if flagged:
+                sys.exit(1)
             if bad.any():
                 i = int(np.nonzero(bad)[0][0])
                 print("   first bad", i, a[i], b[i])
