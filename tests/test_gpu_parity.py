@@ -33,7 +33,7 @@ def _reset_context_options(sp):
     ctx = sp.get_context()
     for name, val in (("force_big", 0), ("big_by_keys", 0), ("subscore_jacobi", 0), ("divergence_global", 0),
                       ("hist_sort", -1), ("lds_cap", 0), ("wide_cap", 0), ("direct_finish", 1), ("direct_all", 0),
-                      ("direct_max_rows", 0)):
+                      ("direct_max_rows", 0), ("subscore_pair", 1), ("subscore_waves", 0)):
         ctx.set_option(name, val)
 
 
@@ -1433,6 +1433,49 @@ def test_subflattening_score_kernels_agree(sp, monkeypatch):
         err = np.where(both_nan, 0.0, np.abs(fast - slow))
         err2 = np.where(both_nan, 0.0, np.abs(fast ** 2 - slow ** 2))
         assert np.all((err <= 1e-11) | (err2 <= 1e-13)), (float(np.nanmax(err)), float(np.nanmax(err2)))
+
+
+def test_subflattening_pair_and_single_kernels_agree(sp):
+    """The default subflattening score kernel takes two splits of one size class per wave (csrc/subflat_pair.hip); option
+    `subscore_pair` = 0 selects round 3's one-split-a-wave kernel.  Same Gram matrices, two implementations of Householder +
+    Sturm: scores within 1e-11 (or 1e-13 in score^2) of each other for every split of 6 - 14 taxon tables (count, float-weight,
+    degenerate; with and without the trivial splits: classes of 4 rows, odd and even class sizes), none flagged.  A split's
+    score must not depend on its partner in the wave: a shuffled list (other pairs) returns the bits of the enumeration."""
+    from splitp_amd import synthetic as syn
+
+    ctx = sp.get_context()
+    for n, length, seed in ((6, 5000, 1), (9, 30_000, 2), (12, 80_000, 3), (14, 100_000, 4)):
+        sites = syn.simulate_sites(n + (n & 1), length, 0.05, seed=seed)[:, :n]   # (balanced trees need an even leaf count)
+        keys, counts = syn.pattern_table(sites)
+        names = syn.taxa_names(n)
+        tables = [sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=length, taxa=names),
+                  sp.DeviceAlignment.from_arrays(keys, counts / float(length), n, taxa=names, exact=False),
+                  sp.DeviceAlignment.from_arrays(keys[:3], None, n, counts=counts[:3], n_sites=int(counts[:3].sum()), taxa=names)]
+        for ti, dev in enumerate(tables):
+            for trivial in (False, True):
+                res = {}
+                for pair in (1, 0):
+                    ctx.set_option("subscore_pair", pair)
+                    res[pair], st = sp.score_all_splits(dev, method=sp.Method.subflattening, trivial=trivial, return_status=True)
+                    assert not np.any(st & 3), (n, ti, pair)
+                ctx.set_option("subscore_pair", 1)
+                a, b = res[1], res[0]
+                assert np.array_equal(np.isnan(a), np.isnan(b))
+                nan = np.isnan(a)
+                d = np.where(nan, 0.0, np.abs(a - b))
+                d2 = np.where(nan, 0.0, np.abs(a * a - b * b))
+                assert np.all((d <= 1e-11) | (d2 <= 1e-13)), (n, ti, trivial, float(d.max()), float(d2.max()))
+        dev = tables[0]
+        allsp = list(sp.all_splits(names))
+        full = dict(zip(allsp, sp.score_all_splits(dev, method=sp.Method.subflattening)))
+        rng = np.random.default_rng(seed)
+        pick = [allsp[i] for i in rng.permutation(len(allsp))[:777]]
+        got = sp.score_splits(dev, pick, method=sp.Method.subflattening)
+        assert np.array_equal(got, np.array([full[s] for s in pick])), n
+        # one split alone (its own partner) and a list of one class with an odd count
+        assert sp.score_splits(dev, pick[:1], method=sp.Method.subflattening)[0] == full[pick[0]]
+        odd = [s for s in allsp if min(len(s[0]), len(s[1])) == n // 2][:5]
+        assert np.array_equal(sp.score_splits(dev, odd, method=sp.Method.subflattening), np.array([full[s] for s in odd]))
 
 
 def test_device_simulator_20_taxa(sp):
