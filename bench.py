@@ -22,7 +22,9 @@ with batch.shard_indices, one all-gather of the packed scores + status per group
 the default invocation measures BOTH (`value` = the alignment-sharded whole-node rate on config 2, the split-sharded
 runs on config 2 and config 4 beside it under `partitions`).
 Other workloads: config5 (batch of 32 simulated 12-taxon alignments x 2035 splits, one device pass per step; the
-batch is dealt to the ranks), config3 / config4 (16 / 20 taxa, 1 M bp, all splits, subflattening route).
+batch is dealt to the ranks), config3 / config4 (16 / 20 taxa, 1 M bp, all splits, subflattening route: the kernels run in
+the alignment's own context on one compute stream; two lanes there = two sets of result buffers and copy streams, so
+that step i's scores and status words travel to the host beside the kernel of step i + 1).
 `--mode dropin` additionally times the literal README loop (README.md:37-41) on the drop-in functions.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the dominant kernel - counter-based
@@ -447,7 +449,11 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
     # (more lanes with RCCL: the all-gather adds latency to every group, not work)
     n_lanes = lanes_arg if lanes_arg > 0 else ((5 if dist is not None else 3) if use_plan and workload == "config2" else 1)
     if not use_plan:
-        n_lanes = 1      # the dense / subflattening routes run in the alignment's own context: one stream, ordered
+        # The dense / subflattening routes run in the alignment's own context - ONE compute stream, kernels in order.  Two
+        # lanes there are two sets of result buffers and two copy streams: the copy of step i's scores and status words
+        # to the host (6.3 MB at config 4: 0.35 ms next to a 3.9 ms kernel) runs beside the kernel of step i + 1.
+        n_lanes = lanes_arg if lanes_arg > 0 else (2 if enum_on_device else 1)
+    compute_stream = torch.cuda.Stream(device=dev_t) if not use_plan else None
     # (steps per host call: at one rank the GPU step - 0.1 ms - hides the 25 us of host work per step and deeper queues
     # measured 1 % slower, 0.1019 against 0.1011 ms; next to RCCL four steps share one all-gather and one host call)
     group = group_arg if group_arg > 0 else (4 if use_plan and workload == "config2" and dist is not None else 1)
@@ -470,6 +476,7 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
             self.host = torch.zeros(world * group * width, dtype=torch.float64).pin_memory()
             self.host_np = self.host.numpy()
             self.done = torch.cuda.Event()
+            self.kdone = torch.cuda.Event()   # (shared compute stream: the lane's kernels are done, its copy may start)
             self.busy = 0            # steps in flight on this lane
             base = self.send.data_ptr()
             self.packed = n_al_rank == 1 or not use_plan
@@ -487,7 +494,7 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
 
     def launch(lane, g):
         t_h = time.perf_counter()
-        with torch.cuda.stream(lane.stream):
+        with torch.cuda.stream(lane.stream if use_plan else compute_stream):
             if use_plan:
                 if lane.packed:
                     for a in range(n_al_rank):
@@ -511,10 +518,16 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
                                                          C.c_void_p(lane.st_p[a])))
             if dist is not None:
                 dist.all_gather_into_tensor(lane.recv, lane.send)      # one collective per group of steps
-                lane.host.copy_(lane.recv, non_blocking=True)
+            if use_plan:
+                lane.host.copy_(lane.recv if dist is not None else lane.send, non_blocking=True)
+                lane.done.record()
             else:
-                lane.host.copy_(lane.send, non_blocking=True)
-            lane.done.record()
+                lane.kdone.record()
+        if not use_plan:
+            with torch.cuda.stream(lane.stream):                       # the lane's copy stream
+                lane.stream.wait_event(lane.kdone)
+                lane.host.copy_(lane.recv if dist is not None else lane.send, non_blocking=True)
+                lane.done.record()
         lane.busy = g
         host_s[0] += time.perf_counter() - t_h
 
