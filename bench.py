@@ -452,7 +452,7 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
         # The dense / subflattening routes run in the alignment's own context - ONE compute stream, kernels in order.  Two
         # lanes there are two sets of result buffers and two copy streams: the copy of step i's scores and status words
         # to the host (6.3 MB at config 4: 0.35 ms next to a 3.9 ms kernel) runs beside the kernel of step i + 1.
-        n_lanes = lanes_arg if lanes_arg > 0 else (2 if enum_on_device else 1)
+        n_lanes = lanes_arg if lanes_arg > 0 else 2
     compute_stream = torch.cuda.Stream(device=dev_t) if not use_plan else None
     # (steps per host call: at one rank the GPU step - 0.1 ms - hides the 25 us of host work per step and deeper queues
     # measured 1 % slower, 0.1019 against 0.1011 ms; next to RCCL four steps share one all-gather and one host call)
@@ -543,6 +543,7 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
         return sc, st
 
     unresolved = [0]
+    finished = [0]
 
     def retire(lane):
         """Wait until the lane's scores are on the host (the unit of work is complete) and check the status words of this
@@ -551,7 +552,12 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
             return
         lane.done.synchronize()
         for s in range(lane.busy):
-            _, st = lane_results(lane, s=s)
+            sc, st = lane_results(lane, s=s)
+            if not use_plan and not enum_on_device and (st & 3).any():
+                # dense route: a split its eigen kernel could not certify goes to the library's direct solver here, on
+                # the host side of the pipeline (never on the benchmark tables: counted in `direct_finished`)
+                for a, al in enumerate(aligns):
+                    finished[0] += batch.finish_async(al, taxa_arr, a_arr, sc[a], st[a])
             if (st & 2).any():
                 raise SystemExit("bench.py: a split came back unhandled (status bit 1) - the device chain must be complete")
             unresolved[0] += int(np.count_nonzero(st & 1))
@@ -650,7 +656,7 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
         "elapsed": elapsed, "steps": steps, "value": total_items / elapsed, "ms_per_step": elapsed / steps * 1e3,
         "scaling": "strong" if (shard_splits or (wl_aligns > 1 and alignments_arg == 0)) else "weak",
         "host_us_per_step": host_us, "group": group, "n_lanes": n_lanes, "n_al_rank": n_al_rank, "n_mine": n_mine,
-        "n_splits_total": n_splits_total, "n_patterns": n_patterns, "parallelism": par, "unresolved": unresolved[0],
+        "n_splits_total": n_splits_total, "n_patterns": n_patterns, "parallelism": par, "unresolved": unresolved[0], "finished": finished[0],
         "scores": scores, "status": status, "tables": tables, "names": names,
         "dom": dom, "dom_ms_alone": dom_ms_alone,
         "dom_ms_region": (ph[dom][0] / ph[dom][1]) if dom else None,
@@ -665,7 +671,8 @@ def config_block(m):
     return {"workload": WL_TEXT[m["workload"]], "workload_key": m["workload"], "route": m["route"],
             "alignments_per_rank_per_step": m["n_al_rank"], "lanes": m["n_lanes"], "steps_per_host_call": m["group"],
             "splits_per_alignment": m["n_splits_total"], "splits_this_rank": m["n_mine"], "patterns": m["n_patterns"],
-            "parallelism": m["parallelism"], "unconverged_splits_in_timed_region": m["unresolved"]}
+            "parallelism": m["parallelism"], "unconverged_splits_in_timed_region": m["unresolved"],
+            "splits_finished_by_the_direct_solver": m["finished"]}
 
 
 def north_star_pipeline(env, main_scores):

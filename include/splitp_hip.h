@@ -232,7 +232,8 @@ int sp_score_all_splits_shard(sp_alignment* al, int method, int trivial, int siz
  *   scores_dev[n_splits] (double) and status_dev[n_splits] (int32) are device buffers written by the kernels.
  * With SP_METHOD_FLATTENING / _SPARSE on a table the sparse route takes, this is sp_score_plan_async on an internally
  * cached plan: the hand-back chain runs on the device and every score is final (status as described there).  Other
- * methods and tables run their synchronous route with device outputs. */
+ * methods and tables run the route of sp_score_splits with device outputs and without its result step: nothing is
+ * fetched, and a split the dense route's eigen kernel flags (status bit 0 / 1) is left to sp_finish_flagged. */
 int sp_score_splits_async(sp_alignment* al, const int32_t* split_taxa, const int32_t* split_a, int64_t n_splits,
                           int method, void* scores_dev, void* status_dev);
 

@@ -191,7 +191,8 @@ def score_plan_steps(lane_ctx, als, plan, n_steps, scores_dev_ptr, scores_step_b
 
 def score_encoded_async(al, split_taxa, split_a, method_code, scores_dev_ptr, status_dev_ptr):
     """Enqueue only (no host synchronisation): scores and status land in the given device buffers.  On the sparse
-    route the hand-back chain runs on the device, so the results are final once the stream has run."""
+    route the hand-back chain runs on the device; on every flattening route a split whose eigen-solver found no
+    certificate comes back flagged (status bit 0 / 1) - finish_async re-scores those with the direct solver."""
     split_taxa = np.ascontiguousarray(split_taxa, dtype=np.int32)
     split_a = np.ascontiguousarray(split_a, dtype=np.int32)
     _lib.check(al.ctx._lib.sp_score_splits_async(
@@ -421,6 +422,10 @@ def score_splits(pattern_probabilities, splits, method=Method.flattening, distri
         else:
             loc, loc_st = np.zeros(0), np.zeros(0, dtype=np.int32)
         out, status = gather_scores(loc, shards, len(splits), group=group, local_status=loc_st, return_status=True)
+    if code in (_lib.SP_METHOD_FLATTENING, _lib.SP_METHOD_FLATTENING_DENSE, _lib.SP_METHOD_FLATTENING_SPARSE) and np.any(status & 3):
+        # the asynchronous entry leaves splits without a certificate flagged: every rank finishes them on its own copy of
+        # the gathered results (the direct solver is deterministic; none on tree-like tables)
+        finish_async(al, taxa_arr, a_arr, out, status)
     warn_unconverged(status)
     return (out, status) if return_status else out
 

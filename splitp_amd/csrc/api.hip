@@ -1340,7 +1340,7 @@ extern "C" int sp_score_splits(sp_alignment* al, const int32_t* split_taxa, cons
     // a status word is flagged (bit 0 / 1: an iterative flattening route found no certificate) does the direct solver run
     // (status bit 2 afterwards) and the patched results are copied again.
     const bool flat_method = method == SP_METHOD_FLATTENING || method == SP_METHOD_FLATTENING_DENSE || method == SP_METHOD_FLATTENING_SPARSE;
-    const bool may_finish = flat_method && ctx->opt.direct_finish != 0;
+    const bool may_finish = flat_method && ctx->opt.direct_finish != 0 && !ctx->async_results;
     std::vector<int32_t> st_tmp;
     int32_t* st_out = status_host;
     if ((scores_host || may_finish) && !status_host) {   // the return code reports unconverged splits either way
@@ -1644,7 +1644,16 @@ extern "C" int sp_score_splits_async(sp_alignment* al, const int32_t* split_taxa
         SP_CHECK(cached_sparse_plan(ctx, al->n_taxa, split_taxa, split_a, n_splits, &plan));
         return enqueue_sparse_plan(ctx, &al, 1, plan, (double*)scores_dev, (int*)status_dev, true);
     }
-    // other methods: the synchronous entry point with device outputs, then the status (same stream: ordered)
+    // Other methods and routes: the synchronous entry point's route with device outputs and WITHOUT its result step - no
+    // status fetch, no host synchronisation behind the kernels: a flagged split (status bit 0 / 1: the dense route's 4-wide
+    // block found no certificate) stays flagged for the caller's sp_finish_flagged, as on the sparse route.  (Until round 4
+    // this fetched the status words to look for flagged splits: one stream synchronisation per call, i.e. the steps of a
+    // pipeline over the dense route could not overlap.)
+    struct AsyncScope {
+        sp_ctx* c;
+        explicit AsyncScope(sp_ctx* c_) : c(c_) { c->async_results = true; }
+        ~AsyncScope() { c->async_results = false; }
+    } scope(ctx);
     int rc = sp_score_splits(al, split_taxa, split_a, n_splits, method, nullptr, scores_dev, nullptr);
     if (rc != SP_OK && rc != SP_ENOCONV) return rc;
     SP_HIP(hipMemcpyAsync(status_dev, ctx->status.p, (size_t)n_splits * 4, hipMemcpyDeviceToDevice, ctx->stream));

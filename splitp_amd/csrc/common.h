@@ -197,6 +197,9 @@ struct sp_ctx {
     DevBuf enum_buf;
     long long enum_key[6] = {0, 0, 0, 0, 0, 0};
     bool enum_valid = false;
+    // set by sp_score_splits_async around its call of the synchronous entry: results stay on the device, no status fetch,
+    // flagged splits are left to the caller's sp_finish_flagged (api.hip)
+    bool async_results = false;
     // size classes of the last paired subflattening batch (subflat_pair.hip), host copy and the device copy the kernel reads
     PairClasses pair_host = {};
     DevBuf pair_dev;

@@ -176,6 +176,19 @@ def test_finish_flagged_abi_and_async(sp):
     assert np.abs(s_h - want).max() <= SCORE_TOL
     got, st2 = sp.score_splits(flat, splits, return_status=True)          # the synchronous entry point: finished inside
     assert not np.any(st2 & 3) and np.abs(got - want).max() <= SCORE_TOL
+    # the dense route behind the asynchronous entry: no status fetch, no synchronisation in the call - what its 4-wide eigen
+    # kernel cannot certify on this table comes back flagged (bit 1: handed back) and is finished by the same host step
+    scd = torch.zeros(len(sub_a), dtype=torch.float64, device="cuda")
+    std = torch.zeros(len(sub_a), dtype=torch.int32, device="cuda")
+    batch.score_encoded_async(flat, sub_t, sub_a, _lib.SP_METHOD_FLATTENING_DENSE, scd.data_ptr(), std.data_ptr())
+    torch.cuda.synchronize()
+    sd_h, td_h = scd.cpu().numpy(), std.cpu().numpy()
+    flagged_d = (td_h & 3) != 0
+    assert flagged_d.sum() > 0 and np.all(np.abs(sd_h - want)[~flagged_d] <= SCORE_TOL)
+    assert batch.finish_async(flat, sub_t, sub_a, sd_h, td_h) == int(flagged_d.sum())
+    assert not np.any(td_h & 3) and np.abs(sd_h - want).max() <= SCORE_TOL
+    got_d, st_d = sp.score_splits(flat, splits, route="dense", return_status=True)   # synchronous: finished inside
+    assert not np.any(st_d & 3) and np.abs(got_d - want).max() <= SCORE_TOL
     ctx = sp.get_context()
     ctx.set_option("direct_max_rows", 100)                                # the 4|6 and 5|5 splits exceed it
     with warnings.catch_warnings(record=True) as caught:
