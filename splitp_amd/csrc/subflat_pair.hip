@@ -210,6 +210,7 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
             if (lane < r) urow[lane] = (unsigned short)(sub_index(rt, nr, n, lane) * m);
             if (lane < c) vcol[lane] = (unsigned char)sub_index(ct, nc, n, lane);
             wave_sync_lds2();
+            PSTAMP(6 + 3 * h);
             // G = B B^T on the matrix cores, B[i][k] = M[urow_i + vcol_k] gathered from the staged moment matrix.
             // v_mfma_f64_16x16x4: lane (fr = lane & 15, fk = lane >> 4) supplies B[16 I + fr][4 s + fk] as A and
             // B[16 J + fr][4 s + fk] as B operand of tile (I, J); accumulator q holds G[16 I + fk + 4 q][16 J + fr].
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
                 }
             }
             wave_sync_lds2();
+            PSTAMP(7 + 3 * h);
             if (half == h && row < r) {
                 const double* const grow = G + row * P;
 #pragma unroll
@@ -267,6 +269,7 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
                     if (j < r) a[j] = grow[j];
                 dg = grow[row];
             }
+            PSTAMP(8 + 3 * h);
         }
         wave_sync_lds2();   // the staging area becomes x, w and the Sturm tables
         PSTAMP(1);

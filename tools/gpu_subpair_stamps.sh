@@ -22,6 +22,9 @@ for n in (16, 20):
         torch.cuda.synchronize()
     out = (C.c_longlong * 16)()
     lib.sp_debug_subp_stamps(out)
+    g = np.array(out[6:12], dtype=np.int64)
+    print(f"   Gram phase of the pair, split A: index tables (global loads of the split) {g[0]-out[0]}  products + stores {g[1]-g[0]}  row loads {g[2]-g[1]};"
+          f"  split B: {g[3]-g[2]} / {g[4]-g[3]} / {g[5]-g[4]}")
     o = np.array(out[:6], dtype=np.int64)
     d = np.diff(o)
     print(f"{n} taxa, {n_got.value} splits: two Gram matrices + rows into registers {d[0]}  tridiagonalisation {d[1]}  table + scaling {d[2]}  Sturm passes {d[3]}  score {d[4]}  total {o[5]-o[0]} cycles of one pair (s_memtime)")
