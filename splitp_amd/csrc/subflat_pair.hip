@@ -217,9 +217,17 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
             // (count tables: every term and sum is an integer below 2^53, so the result does not depend on the order)
             {
                 typedef double d4 __attribute__((ext_vector_type(4)));
-                const int fr = lane & 15, fk = lane >> 4;
+                // (the lane number made opaque once more: the 16 store addresses below are invariants of the pair loop - the
+                // compiler computed them ahead of it, spilled them, and every store then waited for a scratch load)
+                int lane_o = lane;
+                asm volatile("" : "+v"(lane_o));
+                const int fr = lane_o & 15, fk = lane_o >> 4;
                 const bool two = r > 16;
-                const int u0 = fr < r ? (int)urow[fr] : -1, u1 = (two && 16 + fr < r) ? (int)urow[16 + fr] : -1;
+                // (every LDS read below is unconditional and its result selected afterwards: written as `cond ? table[i] : 0`
+                // each gather became a branch around one read with its own s_waitcnt - eight LDS round trips in sequence
+                // per trip, 7 of the phase's 10 k ticks a split)
+                const int ur0 = (int)urow[fr], ur1 = (int)urow[16 + fr];   // (32 entries: in bounds; stale beyond r)
+                const int u0 = fr < r ? ur0 : -1, u1 = (two && 16 + fr < r) ? ur1 : -1;
                 d4 g00 = {0, 0, 0, 0}, g01 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
                 // 16 columns a trip: the four column indices, then the eight gathers, then the products - two LDS round trips
                 // per trip (k_subscore_tri's loop made them per 4 columns, and this phase is nothing but their latency)
@@ -230,12 +238,20 @@ __global__ __launch_bounds__(SUBP_MAXWAVES * 64) void k_subscore_pair(const void
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
                         const int k = k0 + 4 * qq + fk;   // (< 64: vcol has 64 entries)
-                        v[qq] = k < c ? (int)vcol[k] : -1;
+                        const int vc = (int)vcol[k];
+                        v[qq] = k < c ? vc : -1;
+                    }
+                    MsT m0[4], m1[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const bool ok0 = v[qq] >= 0 && u0 >= 0, ok1 = v[qq] >= 0 && u1 >= 0;
+                        m0[qq] = Ms[ok0 ? u0 + v[qq] : 0];
+                        m1[qq] = Ms[ok1 ? u1 + v[qq] : 0];
                     }
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
-                        x0[qq] = (v[qq] >= 0 && u0 >= 0) ? (double)Ms[u0 + v[qq]] : 0.0;
-                        x1[qq] = (v[qq] >= 0 && u1 >= 0) ? (double)Ms[u1 + v[qq]] : 0.0;
+                        x0[qq] = (v[qq] >= 0 && u0 >= 0) ? (double)m0[qq] : 0.0;
+                        x1[qq] = (v[qq] >= 0 && u1 >= 0) ? (double)m1[qq] : 0.0;
                     }
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
