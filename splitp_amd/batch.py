@@ -416,16 +416,16 @@ def score_splits(pattern_probabilities, splits, method=Method.flattening, distri
             score_encoded_async(al, taxa_arr[mine], a_arr[mine], code, send.data_ptr(), send.data_ptr() + per * 8)
         al.ctx.synchronize()          # the collective runs on torch's stream, the kernels on the context's (see _send_buffer)
         out, status = gather_scores(None, shards, len(splits), group=group, device_tensor=send, return_status=True)
+        if code in (_lib.SP_METHOD_FLATTENING, _lib.SP_METHOD_FLATTENING_DENSE, _lib.SP_METHOD_FLATTENING_SPARSE) and np.any(status & 3):
+            # the asynchronous entry leaves splits without a certificate flagged: every rank finishes them on its own copy
+            # of the gathered results (the direct solver is deterministic; none on tree-like tables)
+            finish_async(al, taxa_arr, a_arr, out, status)
     else:
         if len(mine):
             loc, loc_st = score_encoded(al, taxa_arr[mine], a_arr[mine], code)
         else:
             loc, loc_st = np.zeros(0), np.zeros(0, dtype=np.int32)
         out, status = gather_scores(loc, shards, len(splits), group=group, local_status=loc_st, return_status=True)
-    if code in (_lib.SP_METHOD_FLATTENING, _lib.SP_METHOD_FLATTENING_DENSE, _lib.SP_METHOD_FLATTENING_SPARSE) and np.any(status & 3):
-        # the asynchronous entry leaves splits without a certificate flagged: every rank finishes them on its own copy of
-        # the gathered results (the direct solver is deterministic; none on tree-like tables)
-        finish_async(al, taxa_arr, a_arr, out, status)
     warn_unconverged(status)
     return (out, status) if return_status else out
 
