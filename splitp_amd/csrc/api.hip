@@ -149,6 +149,7 @@ static long long* option_slot(sp_ctx* c, const char* name, int** as_int) {
     else if (!strcmp(name, "subscore_jacobi")) *as_int = &c->opt.subscore_jacobi;
     else if (!strcmp(name, "subscore_waves")) *as_int = &c->opt.subscore_waves;
     else if (!strcmp(name, "subscore_pair")) *as_int = &c->opt.subscore_pair;
+    else if (!strcmp(name, "moments_valu")) *as_int = &c->opt.moments_valu;
     else if (!strcmp(name, "divergence_global")) *as_int = &c->opt.divergence_global;
     else if (!strcmp(name, "hist_sort")) *as_int = &c->opt.hist_sort;
     else if (!strcmp(name, "wide_cap")) *as_int = &c->opt.wide_cap;

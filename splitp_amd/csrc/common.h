@@ -128,6 +128,7 @@ struct CtxOptions {
     int force_big = 0;          // every flattening score on the big-table form
     int big_by_keys = 0;        // ... with its sort-based compaction
     int subscore_jacobi = 0;    // Jacobi kernel for the batched subflattening score
+    int moments_valu = 0;       // the round-1 moment kernels (vector units, int64 partial sums) instead of the matrix-core form
     int subscore_pair = 1;      // two splits a wave (subflat_pair.hip) where the batch's classes are known; 0 = one split a wave
     int subscore_waves = 0;     // waves per workgroup of the fast subflattening score kernel (0 = the shape that fills the CU)
     int divergence_global = 0;  // global-memory form of the mutual-information score

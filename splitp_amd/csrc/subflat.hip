@@ -86,10 +86,122 @@ __global__ void k_moments_reduce(const ACC* __restrict__ partial, int parts, int
     M[e] = s;
 }
 
+// ---- the same matrix on the fp64 matrix cores (round 4; up to 21 taxa: m <= 64) ------------------------------------------
+// M = S^T diag(w) S with S[p][u] = +-1 is a (64 x D) x (D x 64) product.  One wave per chunk of 64 patterns, grid-stride:
+// every lane turns ONE pattern into its sign word (sign_bits) and stages {signs, weight} in LDS; 16 steps of
+// v_mfma_f64_16x16x4 then take 4 patterns each - lane (fr = lane & 15, fk = lane >> 4) supplies w_p s_p[16 I + fr] as A and
+// s_p[16 J + fr] as B operand of tile (I, J), p = 4 step + fk - into the 10 tiles on and above the diagonal, which stay in
+// registers over the wave's whole share of the table.  Count tables: every term and every partial sum is an integer below
+// 2^53 (at most the number of sites), so the fp64 sums are exact and do not depend on the order; k_moments_reduce64 adds the
+// waves' tiles in a fixed order, mirrors them and writes int64 (or double for weighted tables).
+// 20 taxa x 1 M sites (259 k patterns): 0.44 + 0.35 ms for k_moments + k_moments_reduce, which spent 8 instructions per
+// (pattern, entry) and summed 1024 partial matrices with one thread an entry.
+#define MOM64_WAVES 4
+template <typename W>
+__global__ __launch_bounds__(MOM64_WAVES * 64) void k_moments_mfma(const u64* __restrict__ keys, const W* __restrict__ wts,
+                                                                   int64_t D, int n, double* __restrict__ partial) {
+    __shared__ u64 s_sig[MOM64_WAVES][64];
+    __shared__ double s_wt[MOM64_WAVES][64];
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int fr = lane & 15, fk = lane >> 4;
+    const int64_t gw = (int64_t)blockIdx.x * MOM64_WAVES + w, nw = (int64_t)gridDim.x * MOM64_WAVES;
+    d4 acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = d4{0, 0, 0, 0};
+    for (int64_t base = gw * 64; base < D; base += nw * 64) {
+        const int64_t p = base + lane;
+        u64 lo = 0, hi = 0;
+        double wt = 0.0;   // (patterns past the end: weight 0)
+        if (p < D) {
+            sign_bits(keys[p], n, lo, hi);
+            wt = (double)wts[p];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the previous chunk's reads are done
+        s_sig[w][lane] = lo;
+        s_wt[w][lane] = wt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+        for (int step = 0; step < 16; ++step) {
+            const u64 sg = s_sig[w][4 * step + fk];
+            const double wp = s_wt[w][4 * step + fk];
+            double b[4], a[4];
+#pragma unroll
+            for (int I = 0; I < 4; ++I) {
+                b[I] = ((sg >> (16 * I + fr)) & 1ull) ? -1.0 : 1.0;
+                a[I] = b[I] * wp;
+            }
+            int t = 0;
+#pragma unroll
+            for (int I = 0; I < 4; ++I)
+#pragma unroll
+                for (int J = I; J < 4; ++J, ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], b[J], acc[t], 0, 0, 0);
+        }
+    }
+    // the wave's tiles: accumulator q of lane (fr, fk) is entry (16 I + fk + 4 q, 16 J + fr)
+    double* out = partial + gw * 4096;
+    int t = 0;
+#pragma unroll
+    for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int J = I; J < 4; ++J, ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[(16 * I + fk + 4 * q) * 64 + 16 * J + fr] = acc[t][q];
+}
+
+// M[u][v] = sum over the waves' tiles, in wave order (fixed: reproducible); tiles below the diagonal are the mirror images.
+// 16 entries a workgroup, 16 lanes an entry: every lane adds its 16th of the partial matrices, lane 0 of the entry adds the
+// 16 sums in order.
+template <typename ACC>
+__global__ __launch_bounds__(256) void k_moments_reduce64(const double* __restrict__ partial, int parts, int m,
+                                                          ACC* __restrict__ M) {
+    __shared__ double s_part[16][17];
+    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;   // entry of the 64 x 64 layout
+    const int u = e >> 6, v = e & 63;
+    const int src = (u >> 4) <= (v >> 4) ? e : v * 64 + u;
+    double sum = 0.0;
+    for (int g = slice; g < parts; g += 16) sum += partial[(int64_t)g * 4096 + src];
+    s_part[el][slice] = sum;
+    __syncthreads();
+    if (slice == 0 && u < m && v < m) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += s_part[el][k];
+        M[u * m + v] = (ACC)tot;
+    }
+}
+
 static int ensure_moments(sp_alignment* al) {
     if (al->moments_ready) return SP_OK;
     sp_ctx* ctx = al->ctx;
     const int m = 3 * al->n_taxa + 1, mm = m * m;
+    if (m <= 64 && !ctx->opt.moments_valu) {
+        const int dev_cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
+        const int64_t chunks = (al->D + 63) / 64;
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(dev_cus, (chunks + MOM64_WAVES - 1) / MOM64_WAVES));
+        const int parts = blocks * MOM64_WAVES;
+        SP_CHECK(al->moments.ensure((size_t)mm * 8));
+        SP_CHECK(ctx->misc.ensure((size_t)parts * 4096 * 8));
+        PhaseScope ps(ctx, SP_PHASE_MOMENT);
+        if (al->exact) {
+            hipLaunchKernelGGL(k_moments_mfma<u32>, dim3(blocks), dim3(MOM64_WAVES * 64), 0, ctx->stream, al->keys.as<u64>(),
+                               al->counts.as<u32>(), al->D, al->n_taxa, ctx->misc.as<double>());
+            hipLaunchKernelGGL(k_moments_reduce64<long long>, dim3(256), dim3(256), 0, ctx->stream, ctx->misc.as<double>(), parts,
+                               m, al->moments.as<long long>());
+        } else {
+            hipLaunchKernelGGL(k_moments_mfma<double>, dim3(blocks), dim3(MOM64_WAVES * 64), 0, ctx->stream, al->keys.as<u64>(),
+                               al->weights.as<double>(), al->D, al->n_taxa, ctx->misc.as<double>());
+            hipLaunchKernelGGL(k_moments_reduce64<double>, dim3(256), dim3(256), 0, ctx->stream, ctx->misc.as<double>(), parts, m,
+                               al->moments.as<double>());
+        }
+        SP_HIP(hipGetLastError());
+        al->moments_ready = true;
+        return SP_OK;
+    }
     const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (al->D + MOM_CHUNK - 1) / MOM_CHUNK));
     SP_CHECK(al->moments.ensure((size_t)mm * 8));
     SP_CHECK(ctx->misc.ensure((size_t)parts * mm * 8));

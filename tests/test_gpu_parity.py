@@ -33,7 +33,7 @@ def _reset_context_options(sp):
     ctx = sp.get_context()
     for name, val in (("force_big", 0), ("big_by_keys", 0), ("subscore_jacobi", 0), ("divergence_global", 0),
                       ("hist_sort", -1), ("lds_cap", 0), ("wide_cap", 0), ("direct_finish", 1), ("direct_all", 0),
-                      ("direct_max_rows", 0), ("subscore_pair", 1), ("subscore_waves", 0)):
+                      ("direct_max_rows", 0), ("subscore_pair", 1), ("subscore_waves", 0), ("moments_valu", 0)):
         ctx.set_option(name, val)
 
 
@@ -1433,6 +1433,48 @@ def test_subflattening_score_kernels_agree(sp, monkeypatch):
         err = np.where(both_nan, 0.0, np.abs(fast - slow))
         err2 = np.where(both_nan, 0.0, np.abs(fast ** 2 - slow ** 2))
         assert np.all((err <= 1e-11) | (err2 <= 1e-13)), (float(np.nanmax(err)), float(np.nanmax(err2)))
+
+
+def test_moment_matrix_kernels_agree(sp):
+    """The signed second-moment matrix behind every subflattening by its two kernels - S^T diag(w) S on the
+    fp64 matrix cores (default up to 21 taxa) and round 1's vector kernels with int64 partial sums (option moments_valu) -
+    against the oracle: count tables EXACT (integers), float-weight tables to 1e-13, 4 - 21 taxa, run-to-run identical."""
+    import ctypes as C
+
+    from splitp_amd import _lib
+    from splitp_amd import synthetic as syn
+
+    ctx = sp.get_context()
+    lib = ctx._lib
+
+    def moments(keys, counts, n, length, exact, valu):
+        ctx.set_option("moments_valu", valu)
+        names = syn.taxa_names(n)
+        dev = (sp.DeviceAlignment.from_arrays(keys, None, n, counts=counts, n_sites=length, taxa=names) if exact else
+               sp.DeviceAlignment.from_arrays(keys, counts / float(length), n, taxa=names, exact=False))
+        m = 3 * n + 1
+        out_i, out_f = np.zeros(m * m, dtype=np.int64), np.zeros(m * m, dtype=np.float64)
+        _lib.check(lib.sp_moment_matrix(dev.handle, _lib._ptr(out_i, C.c_int64) if exact else None,
+                                        None if exact else _lib._ptr(out_f, C.c_double)))
+        ctx.set_option("moments_valu", 0)
+        return (out_i if exact else out_f).reshape(m, m)
+
+    for n, length, seed in ((4, 300, 1), (7, 5_000, 2), (12, 100_000, 3), (17, 200_000, 4), (20, 300_000, 5), (21, 20_000, 6)):
+        sites = syn.simulate_sites(n + (n & 1), length, 0.05, seed=seed)[:, :n]
+        keys, counts = syn.pattern_table(sites)
+        want = O.moment_matrix(keys, counts, n)
+        new = moments(keys, counts, n, length, True, 0)
+        assert np.array_equal(new, want), n
+        assert np.array_equal(moments(keys, counts, n, length, True, 1), want), n
+        assert np.array_equal(moments(keys, counts, n, length, True, 0), new), n
+        # counts near 2^32 (one pattern carries most sites): products and partial sums stay below 2^53
+        big = counts.astype(np.int64).copy()
+        big[0] = 4_000_000_000
+        assert np.array_equal(moments(keys, big, n, int(big.sum()), True, 0), O.moment_matrix(keys, big, n)), n
+        ref = want / float(length)
+        newf = moments(keys, counts, n, length, False, 0)
+        assert np.abs(newf - ref).max() <= 1e-13 and np.abs(moments(keys, counts, n, length, False, 1) - ref).max() <= 1e-13
+        assert np.array_equal(moments(keys, counts, n, length, False, 0), newf)
 
 
 def test_subflattening_pair_and_single_kernels_agree(sp):

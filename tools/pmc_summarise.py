@@ -19,7 +19,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PHASE_OF = {"k_sparse_score": "sparse", "k_sparse_slow": "chain", "k_gram_i8": "gram", "k_gram_i8_big": "gram", "k_eig_gv": "eigen",
             "k_eig_rr": "eigen_rr", "k_zero_i8": "zero", "k_scatter_i8": "scatter", "k_eig_init": "eigen_init", "k_reindex": "reindex",
-            "k_subscore_pair": "subscore", "k_subscore_tri": "subscore", "k_subscore": "subscore_jacobi", "k_moments": "moment", "k_enumerate_splits": "enumerate",
+            "k_subscore_pair": "subscore", "k_subscore_tri": "subscore", "k_subscore": "subscore_jacobi", "k_moments": "moment", "k_moments_mfma": "moment", "k_moments_reduce64": "moment_reduce", "k_enumerate_splits": "enumerate",
             "k_eig_cv": "eigen", "k_eig_ctv": "eigen_ctv", "k_eig4": "eig4", "k_fin_apply": "direct_apply", "k_fin_vec": "direct_vec",
             "k_fin_sturm": "direct_sturm"}
 
