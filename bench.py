@@ -544,6 +544,7 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
 
     unresolved = [0]
     finished = [0]
+    trace = [None]      # SPLITP_BENCH_TRACE=1: host time of every retire inside the timed region (diagnostic)
 
     def retire(lane):
         """Wait until the lane's scores are on the host (the unit of work is complete) and check the status words of this
@@ -551,6 +552,8 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
         if not lane.busy:
             return
         lane.done.synchronize()
+        if trace[0] is not None:
+            trace[0].append(time.perf_counter())
         for s in range(lane.busy):
             sc, st = lane_results(lane, s=s)
             if not use_plan and not enum_on_device and (st & 3).any():
@@ -578,6 +581,16 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
         for lane in lanes:
             retire(lane)
 
+    # The phase timers' event pools (1024 hipEventCreate per lane context) are filled HERE, ahead of every untimed launch:
+    # created where timing is switched on - between the warmup steps and the timed region - they leave the GPU idle for
+    # milliseconds right before the clock starts, and a 20-step region (2 ms: the driver's command) then begins on a
+    # device that has dropped out of its boost state.  SPLITP_BENCH_LATE_EVENTS=1 restores the old order (A/B diagnostic).
+    late_events = os.environ.get("SPLITP_BENCH_LATE_EVENTS", "0") == "1"
+    if timing and not late_events:
+        for ctx_ in ({id(l.ctx): l.ctx for l in lanes}).values():
+            ctx_.enable_timing(True)
+            ctx_.enable_timing(False)
+
     # untimed spin-up: a fresh box needs a few hundred ms of load before clocks, queues and the RCCL channel settle;
     # then the W warmup steps the contract asks for.  (The number of spin-up batches is agreed between the ranks.)
     t_spin = time.perf_counter()
@@ -600,12 +613,16 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    if os.environ.get("SPLITP_BENCH_TRACE", "0") == "1":
+        trace[0] = []
     t0 = time.perf_counter()
     run(steps)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    retire_ms = [round((t - t0) * 1e3, 4) for t in trace[0]] if trace[0] is not None else None
+    trace[0] = None
     host_us = host_s[0] / max(steps, 1) * 1e6
     # per-phase device time inside the timed region, summed over the lanes (HIP events on each lane's own stream)
     phases = {}
@@ -655,7 +672,7 @@ def measure(env, workload, shard, route, steps, warmup, spinup, lanes_arg, group
         "workload": workload, "route": route, "shard": shard, "n_taxa": n_taxa, "n_sites": n_sites, "a_arr": a_arr, "mine": mine,
         "elapsed": elapsed, "steps": steps, "value": total_items / elapsed, "ms_per_step": elapsed / steps * 1e3,
         "scaling": "strong" if (shard_splits or (wl_aligns > 1 and alignments_arg == 0)) else "weak",
-        "host_us_per_step": host_us, "group": group, "n_lanes": n_lanes, "n_al_rank": n_al_rank, "n_mine": n_mine,
+        "host_us_per_step": host_us, "retire_ms": retire_ms, "group": group, "n_lanes": n_lanes, "n_al_rank": n_al_rank, "n_mine": n_mine,
         "n_splits_total": n_splits_total, "n_patterns": n_patterns, "parallelism": par, "unresolved": unresolved[0], "finished": finished[0],
         "scores": scores, "status": status, "tables": tables, "names": names,
         "dom": dom, "dom_ms_alone": dom_ms_alone,
@@ -823,6 +840,8 @@ def main():
             "roofline": roofline_block(m) if m["dom"] else None,
         }
         out.update(extra)
+        if m.get("retire_ms") is not None:
+            out["retire_ms"] = m["retire_ms"][:64]
         if cpu is not None:
             out["cpu_baseline"] = {k: v for k, v in cpu.items() if k != "scores"}
             # end-to-end sanity outside the timed region: the GPU scores of three splits equal the CPU leg's
