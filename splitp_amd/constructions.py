@@ -68,10 +68,12 @@ class Flattening(np.ndarray):
 
     _sp_origin = None
     _sp_check = None
+    _sp_pending = None
 
     def __array_finalize__(self, obj):
         self._sp_origin = None
         self._sp_check = None
+        self._sp_pending = None
 
     def __reduce__(self):      # pickling / copy.deepcopy: a plain array
         return np.asarray(self).__reduce__()
@@ -100,7 +102,93 @@ def flattening_origin(matrix):
         if _content_check(matrix) == matrix._sp_check:
             return matrix._sp_origin
         matrix._sp_origin = None        # edited in place: from now on an ordinary matrix
+        matrix._sp_pending = None
     return None
+
+
+# ---- the README loop's score, prefetched (tools/gpu_dropin_profile.py, round 4: 0.74 -> 0.55 ms a split) ----
+# `split_score(flattening(split, table, FlatFormat.reduced))` asks for the score of a split the library has just been told
+# about: once a caller has shown that pattern (split_score consumed an untouched Flattening of this table), the next
+# flattening() enqueues the score of ITS split behind the fetch - sp_score_splits_async, the same kernels as the
+# synchronous call - and the GPU works on it while the host checksums the matrix.  split_score(F) then only waits for the
+# context's stream.  The score still comes from the resident table and still only when F's contents are untouched
+# (flattening_origin); a caller who stops scoring costs two unused launches before the credit runs out.
+# (Measured beside it and dropped: the matrix fetched into pinned host memory from torch's caching host allocator -
+# +14 % on one box, -5 % on the next, `profiles/r04_dropin_profile.txt`; pageable numpy memory stays.)
+PREFETCH_SCORES = True                 # module switch (tests compare both ways)
+_PREFETCH_SLOTS = 64
+_prefetchers = {}
+
+
+class _ScorePrefetch:
+    """Per-device ring of (score, status) slots: 16 bytes in HBM the asynchronous entry writes, and a pinned word pair the
+    slot is read through.  Ordering is the context's own stream (a context created under torch's default stream runs on
+    a private non-blocking stream - nothing torch enqueues is ordered with it): collect() synchronises THAT stream."""
+
+    def __init__(self, device):
+        import torch
+
+        self.dev = torch.zeros((_PREFETCH_SLOTS, 2), dtype=torch.float64, device=torch.device("cuda", device))
+        self.host = torch.zeros(2, dtype=torch.float64).pin_memory()
+        self.host_np = self.host.numpy()
+        self.ticket = [-1] * _PREFETCH_SLOTS
+        self.issued = 0
+
+    def issue(self, al, oa, ob):
+        from .batch import score_encoded_async
+
+        t = self.issued
+        slot = t % _PREFETCH_SLOTS
+        taxa = np.ascontiguousarray(np.concatenate([oa, ob])[None, :], dtype=np.int32)
+        a = np.array([len(oa)], dtype=np.int32)
+        base = self.dev.data_ptr() + slot * 16
+        self.ticket[slot] = -1
+        score_encoded_async(al, taxa, a, _lib.SP_METHOD_FLATTENING, base, base + 8)
+        self.issued = t + 1
+        self.ticket[slot] = t
+        return (self, t, taxa, a)
+
+    def collect(self, al, pending):
+        """np.float64 score, or None when the slot has been reused since (the caller scores synchronously)."""
+        from .batch import finish_async, warn_unconverged
+
+        _, t, taxa, a = pending
+        slot = t % _PREFETCH_SLOTS
+        if self.ticket[slot] != t:
+            return None
+        al.ctx.synchronize()                        # the kernels behind the fetch are done (usually long ago)
+        self.host.copy_(self.dev[slot])             # 16 bytes, blocking
+        sc = self.host_np[0:1].copy()
+        st = self.host_np[1:2].view(np.int32)[0:1].copy()
+        if st[0] & 3:                       # no certificate on the device: the library's direct solver answers (batch.finish_async)
+            finish_async(al, taxa, a, sc, st)
+        warn_unconverged(st, stacklevel=4)
+        return np.float64(sc[0])
+
+
+def _prefetch_score(al, oa, ob):
+    if not PREFETCH_SCORES or getattr(al, "_sp_prefetch_credit", 0) <= 0:
+        return None
+    al._sp_prefetch_credit -= 1
+    try:
+        pf = _prefetchers.get(al.ctx.device)
+        if pf is None:
+            pf = _prefetchers[al.ctx.device] = _ScorePrefetch(al.ctx.device)
+        return pf.issue(al, oa, ob)
+    except Exception:       # a prefetch that cannot be enqueued is no error: split_score(F) makes the call itself and reports
+        al._sp_prefetch_credit = 0
+        return None
+
+
+def take_prefetched_score(matrix, al):
+    """The score flattening() enqueued for this untouched Flattening, if any (called by split_score after the origin
+    check).  Also records that this table's flattenings are being scored: the next one is prefetched."""
+    al._sp_prefetch_credit = 2
+    pending = matrix._sp_pending
+    matrix._sp_pending = None
+    if pending is None:
+        return None
+    return pending[0].collect(al, pending)
 
 
 def _reduced(al, oa, ob):
@@ -109,10 +197,14 @@ def _reduced(al, oa, ob):
     lib = al.ctx._lib
     _lib.check(lib.sp_flatten_reduced_prepare(al.handle, _lib._ptr(oa, C.c_int32), len(oa), _lib._ptr(ob, C.c_int32),
                                               len(ob), C.byref(r), C.byref(c)))
-    out = np.zeros((r.value, c.value), dtype=np.float64)
+    # (the fetch overwrites every cell of a non-empty matrix; an empty one has no cells)
+    out = np.empty((r.value, c.value), dtype=np.float64)
     _lib.check(lib.sp_flatten_reduced_fetch(al.handle, _lib._ptr(out, C.c_double), None, None))
+    oa32, ob32 = np.array(oa, dtype=np.int32), np.array(ob, dtype=np.int32)
+    pending = _prefetch_score(al, oa32, ob32)      # the GPU scores the split while the host checksums the matrix
     out = out.view(Flattening)
-    out._sp_origin = (al, np.array(oa, dtype=np.int32), np.array(ob, dtype=np.int32))
+    out._sp_origin = (al, oa32, ob32)
+    out._sp_pending = pending
     out._sp_check = _content_check(out)
     return out
 

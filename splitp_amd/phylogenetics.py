@@ -28,8 +28,12 @@ def split_score(matrix, return_singular_values=False, force_frob_norm_on_dense=F
     if origin is not None:
         # an untouched flattening(..., FlatFormat.reduced) of a resident table: score the split where the table lives
         from .batch import score_encoded
+        from .constructions import take_prefetched_score
 
         al, oa, ob = origin
+        ready = take_prefetched_score(matrix, al)      # enqueued by flattening() behind the fetch (constructions.py)
+        if ready is not None:
+            return ready
         al.ctx.sync_stream_with_torch()
         taxa_arr = np.ascontiguousarray(np.concatenate([oa, ob])[None, :], dtype=np.int32)
         scores, _ = score_encoded(al, taxa_arr, np.array([len(oa)], dtype=np.int32), _lib.SP_METHOD_FLATTENING)

@@ -943,6 +943,96 @@ def scipy_is_dok(m):
     return isinstance(m, dok_matrix)
 
 
+def test_dropin_loop_prefetched_scores(sp, golden):
+    """Round 4 (re-entry): once split_score has consumed an untouched Flattening of a table, the next flattening() of that
+    table enqueues the score of its split behind the fetch (constructions._ScorePrefetch).  Same kernels on the same resident table: the scores equal the batched call's bit for bit, with the prefetch on,
+    off, overtaken (more matrices alive than ring slots) and dropped (matrix edited in place); oracle on top."""
+    from splitp_amd import constructions as K, device
+    from splitp_amd.constructions import Flattening, flattening_origin
+
+    g = golden("n10_L10k")
+    names = taxa_names(10)
+    table = O.unpack_table(g["keys"], g["probs"], 10)
+    splits = [mask_to_split(int(m), 10, names) for m in g["masks"]]
+    pick = list(range(0, 501, 7))
+    batched = sp.score_splits(table, [splits[i] for i in pick])
+    assert np.max(np.abs(batched - g["scores"][pick])) <= SCORE_TOL
+    device.clear_table_cache()
+    al = device.as_device_alignment(table)
+    assert K.PREFETCH_SCORES
+
+    def loop():
+        out, used = [], 0
+        for i in pick:
+            F = sp.flattening(splits[i], table, sp.FlatFormat.reduced)
+            assert type(F) is Flattening and F.flags.writeable and F.flags.c_contiguous and F.dtype == np.float64
+            used += F._sp_pending is not None
+            s = sp.split_score(F)
+            assert isinstance(s, np.float64) and F._sp_pending is None
+            assert sp.split_score(F) == s                      # asked again: the synchronous call, the same kernels
+            out.append(s)
+        return np.array(out), used
+
+    before = K._prefetchers[al.ctx.device].issued if al.ctx.device in K._prefetchers else 0
+    got, used = loop()
+    assert np.array_equal(got, batched)
+    assert used == len(pick) - 1, used                          # every flattening after the first scored one was prefetched
+    pf = K._prefetchers[al.ctx.device]
+    assert pf.issued - before == used
+    for fid in g["full_ids"]:                                   # np.empty + fetch: the reference's matrix, bit for bit
+        F = sp.flattening(splits[int(fid)], table, sp.FlatFormat.reduced)
+        assert np.array_equal(np.asarray(F), g[f"reduced_{int(fid)}"])
+    # a caller who only takes flattenings: the credit of two runs out, nothing further is enqueued
+    n0 = pf.issued
+    keep = [sp.flattening(splits[i], table, sp.FlatFormat.reduced) for i in pick[:6]]
+    assert pf.issued - n0 <= 2 and sum(F._sp_pending is not None for F in keep) == pf.issued - n0
+    assert np.array_equal(np.array([sp.split_score(F) for F in keep]), batched[:6])
+    # more prefetched matrices alive than ring slots: the overtaken ones are scored by the synchronous call
+    many = []
+    for j in range(K._PREFETCH_SLOTS + 8):
+        al._sp_prefetch_credit = 2
+        many.append(sp.flattening(splits[pick[j % len(pick)]], table, sp.FlatFormat.reduced))
+    assert all(F._sp_pending is not None for F in many)
+    sc = np.array([sp.split_score(F) for F in many])
+    assert np.array_equal(sc, batched[[j % len(pick) for j in range(len(many))]])
+    # edited in place after the prefetch: the pending score is dropped with the origin, the matrix is scored as it now is
+    al._sp_prefetch_credit = 2
+    F = sp.flattening(splits[pick[40]], table, sp.FlatFormat.reduced)
+    assert F._sp_pending is not None
+    F[0, 0] += 0.5
+    edited = sp.split_score(F)
+    assert flattening_origin(F) is None and F._sp_pending is None
+    assert abs(edited - O.dense_split_score(np.asarray(F))) <= SCORE_TOL and abs(edited - batched[40]) > 1e-6
+    # switched off: the round-3 behaviour, the same numbers
+    K.PREFETCH_SCORES = False
+    try:
+        n0 = pf.issued
+        got2, used2 = loop()
+        assert used2 == 0 and pf.issued == n0 and np.array_equal(got2, batched)
+    finally:
+        K.PREFETCH_SCORES = True
+    # a float-weight table (no integer counts behind the values: the dense route's asynchronous entry) - prefetched and
+    # synchronous scores agree bit for bit, and with the oracle
+    rng = np.random.default_rng(77)
+    wtable = {k: float(v) * float(rng.uniform(0.5, 1.5)) for k, v in table.items()}
+    few = pick[::9]
+    res = {}
+    for on in (True, False):
+        K.PREFETCH_SCORES = on
+        device.clear_table_cache()
+        out, used = [], 0
+        for i in few:
+            F = sp.flattening(splits[i], wtable, sp.FlatFormat.reduced)
+            used += F._sp_pending is not None
+            keepF = np.array(F)
+            out.append(sp.split_score(F))
+            assert abs(out[-1] - O.dense_split_score(keepF)) <= SCORE_TOL
+        assert used == (len(few) - 1 if on else 0)
+        res[on] = np.array(out)
+    K.PREFETCH_SCORES = True
+    assert np.array_equal(res[True], res[False])
+
+
 def test_dropin_loop_stays_on_the_device(sp, golden):
     """The unchanged README loop (README.md:37-41) on a plain dict: the table is uploaded once (content-checked cache),
     flattening(..., reduced) returns the reference's ndarray (bit-exact) that remembers its origin, and split_score(F)
