@@ -244,6 +244,53 @@ def test_flattening_content_check_detects_edits():
     assert flattening_origin(G) is None
 
 
+def test_score_prefetch_credit_logic(monkeypatch):
+    """Host logic of the drop-in loop's score prefetch (constructions._prefetch_score / take_prefetched_score), no GPU: a
+    table's flattenings are prefetched only after split_score has consumed one, a caller who stops scoring costs two
+    launches, a prefetch that cannot be enqueued is not an error, an overtaken slot sends the caller to the synchronous call."""
+    from types import SimpleNamespace
+
+    from splitp_amd import constructions as K
+    from splitp_amd.constructions import Flattening
+
+    issued = []
+
+    class FakePrefetch:
+        def __init__(self, device):
+            self.device = device
+            self.fail = False
+
+        def issue(self, al, oa, ob):
+            if self.fail:
+                raise RuntimeError("cannot enqueue")
+            issued.append((tuple(oa), tuple(ob)))
+            return (self, len(issued) - 1, None, None)
+
+        def collect(self, al, pending):
+            return None if pending[1] == 0 else np.float64(pending[1])
+
+    monkeypatch.setattr(K, "_ScorePrefetch", FakePrefetch)
+    monkeypatch.setattr(K, "_prefetchers", {})
+    al = SimpleNamespace(ctx=SimpleNamespace(device=3))
+    oa, ob = np.array([0, 1], dtype=np.int32), np.array([2, 3], dtype=np.int32)
+    assert K._prefetch_score(al, oa, ob) is None and not issued            # nobody has scored a flattening of this table yet
+    F = np.zeros((2, 2)).view(Flattening)
+    assert K.take_prefetched_score(F, al) is None and al._sp_prefetch_credit == 2
+    p0 = K._prefetch_score(al, oa, ob)
+    p1 = K._prefetch_score(al, oa, ob)
+    assert p0 is not None and p1 is not None and len(issued) == 2
+    assert K._prefetch_score(al, oa, ob) is None and len(issued) == 2       # credit used up: two unused launches, no more
+    F._sp_pending = p1
+    assert K.take_prefetched_score(F, al) == 1.0 and F._sp_pending is None and al._sp_prefetch_credit == 2
+    F._sp_pending = p0                                                      # (the fake's slot 0 counts as overtaken)
+    assert K.take_prefetched_score(F, al) is None and F._sp_pending is None
+    K._prefetchers[3].fail = True
+    assert K._prefetch_score(al, oa, ob) is None and al._sp_prefetch_credit == 0
+    monkeypatch.setattr(K, "PREFETCH_SCORES", False)
+    al._sp_prefetch_credit = 2
+    assert K._prefetch_score(al, oa, ob) is None and al._sp_prefetch_credit == 2
+
+
 def test_new_kernels_keep_nothing_in_scratch():
     """The compiler's own resource remarks (tools/kernel_resources.py, no GPU): the round-4 kernels - the certified 4-wide eigen
     kernel of the dense route and the direct solver - spill no vector register and use no scratch memory, and the committed
