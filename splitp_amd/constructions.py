@@ -10,6 +10,7 @@ reference returns (scipy dok_matrix / numpy ndarray, float64)."""
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 from scipy.sparse import coo_matrix, dok_matrix
@@ -133,18 +134,20 @@ class _ScorePrefetch:
         self.host_np = self.host.numpy()
         self.ticket = [-1] * _PREFETCH_SLOTS
         self.issued = 0
+        self._lock = threading.Lock()
 
     def issue(self, al, oa, ob):
         from .batch import score_encoded_async
 
-        t = self.issued
+        with self._lock:        # (ctypes calls release the GIL: two threads must never draw the same ticket / slot)
+            t = self.issued
+            self.issued = t + 1
         slot = t % _PREFETCH_SLOTS
         taxa = np.ascontiguousarray(np.concatenate([oa, ob])[None, :], dtype=np.int32)
         a = np.array([len(oa)], dtype=np.int32)
         base = self.dev.data_ptr() + slot * 16
         self.ticket[slot] = -1
         score_encoded_async(al, taxa, a, _lib.SP_METHOD_FLATTENING, base, base + 8)
-        self.issued = t + 1
         self.ticket[slot] = t
         return (self, t, taxa, a)
 
