@@ -6,7 +6,8 @@
 // Cholesky + stop rule 1.9 k, orth 0.7 k), four iterations a split, 165 of 501 splits.
 // Measured (profiles/r04_gram_iter_probe.txt): R = 16: 2.1 k ticks per iteration (a third of today's 6.3 k); R = 64: 7.9 k -
 // no gain: 64 k-steps of (one b64 + two broadcast b128 LDS reads + 4 FMA) cost ~94 ticks each in a single wave, LDS latency
-// with nothing to hide it; there the block-wide product (3.3 k) has to stay and only the 4.7 k of sum + Gram + Cholesky +
+// with nothing to hide it - and still 67 with the loads of 8 or 16 steps in flight (6.2 k per iteration: a broadcast b128
+// read occupies the LDS as long as a scattered one); there the block-wide product (3.3 k) has to stay and only the 4.7 k of sum + Gram + Cholesky +
 // orth behind it can move into one wave (~1.8 k by the R = 16 figure).  Worth 45 x 17 k + 120 x 8 k = 1.7 M of the launch's
 // 61 M CU-cycles (2.8 %: 0.0954 -> ~0.093 ms) - not the 0.090 target on its own.
 //   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/gram_iter_probe.hip -o /tmp/gram_iter_probe && /tmp/gram_iter_probe
@@ -46,7 +47,7 @@ __device__ __forceinline__ double all_sum(double x) {
     return lane_value(x, 15);                   // R = 16: the rows live in lanes 0..15 (lanes 16..63 hold replicas)
 }
 
-template <int R>
+template <int R, int BATCH>
 __global__ __launch_bounds__(1024) void k_probe(const double* __restrict__ Gin, double* __restrict__ sums, long long* __restrict__ cyc,
                                                 int iters) {
     __shared__ double G[R * R];        // symmetric: G[k * R + i] = G[i][k], consecutive lanes read consecutive words
@@ -65,15 +66,38 @@ __global__ __launch_bounds__(1024) void k_probe(const double* __restrict__ Gin, 
         const long long t0 = __builtin_amdgcn_s_memtime();
         for (int it = 0; it < iters; ++it) {
             double y[4] = {0, 0, 0, 0};
+            if (BATCH > 1 && R == 64) {
+                // all loads of BATCH k-steps in flight before the first FMA (the plain loop above leaves two k-steps in
+                // flight and pays an LDS round trip for every pair: 94 ticks a step)
+#pragma unroll 1
+                for (int k0 = 0; k0 < 64; k0 += BATCH) {
+                    double g[BATCH];
+                    double2 lo[BATCH], hi[BATCH];
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u) {
+                        g[u] = G[(k0 + u) * R + row];
+                        lo[u] = *reinterpret_cast<const double2*>(&V[(k0 + u) * 4]);
+                        hi[u] = *reinterpret_cast<const double2*>(&V[(k0 + u) * 4 + 2]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u) {
+                        y[0] = fma(g[u], lo[u].x, y[0]);
+                        y[1] = fma(g[u], lo[u].y, y[1]);
+                        y[2] = fma(g[u], hi[u].x, y[2]);
+                        y[3] = fma(g[u], hi[u].y, y[3]);
+                    }
+                }
+            } else {
 #pragma unroll 8
-            for (int kk = 0; kk < KQ; ++kk) {
-                const int k = q * KQ + kk;
-                const double g = G[k * R + row];
-                const double2 lo = *reinterpret_cast<const double2*>(&V[k * 4]), hi = *reinterpret_cast<const double2*>(&V[k * 4 + 2]);
-                y[0] = fma(g, lo.x, y[0]);
-                y[1] = fma(g, lo.y, y[1]);
-                y[2] = fma(g, hi.x, y[2]);
-                y[3] = fma(g, hi.y, y[3]);
+                for (int kk = 0; kk < KQ; ++kk) {
+                    const int k = q * KQ + kk;
+                    const double g = G[k * R + row];
+                    const double2 lo = *reinterpret_cast<const double2*>(&V[k * 4]), hi = *reinterpret_cast<const double2*>(&V[k * 4 + 2]);
+                    y[0] = fma(g, lo.x, y[0]);
+                    y[1] = fma(g, lo.y, y[1]);
+                    y[2] = fma(g, hi.x, y[2]);
+                    y[3] = fma(g, hi.y, y[3]);
+                }
             }
             if (R == 16) {
 #pragma unroll
@@ -130,7 +154,7 @@ __global__ __launch_bounds__(1024) void k_probe(const double* __restrict__ Gin, 
     __syncthreads();        // the one barrier the other 15 waves wait at
 }
 
-template <int R>
+template <int R, int BATCH>
 static void run(const char* what) {
     // G = C C^T with a decaying spectrum (a flattening's row Gram matrix looks like this: a few large, many small)
     const int K = 300;
@@ -195,9 +219,9 @@ static void run(const char* what) {
     long long c4 = 0, c8 = 0;
     std::vector<double> got(iters_max);
     for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL(k_probe<R>, dim3(1), dim3(1024), 0, 0, dG, dS, dC, 4);
+        hipLaunchKernelGGL((k_probe<R, BATCH>), dim3(1), dim3(1024), 0, 0, dG, dS, dC, 4);
         hipMemcpy(&c4, dC, 8, hipMemcpyDeviceToHost);
-        hipLaunchKernelGGL(k_probe<R>, dim3(1), dim3(1024), 0, 0, dG, dS, dC, 8);
+        hipLaunchKernelGGL((k_probe<R, BATCH>), dim3(1), dim3(1024), 0, 0, dG, dS, dC, 8);
         hipMemcpy(&c8, dC, 8, hipMemcpyDeviceToHost);
     }
     hipMemcpy(got.data(), dS, iters_max * 8, hipMemcpyDeviceToHost);
@@ -212,7 +236,9 @@ static void run(const char* what) {
 }
 
 int main() {
-    run<16>("R = 16 (2-taxon row side; block-wide today: ~6.3 k cycles per iteration)");
-    run<64>("R = 64 (3-taxon row side; block-wide today: ~8.1 k cycles per iteration)");
+    run<16, 1>("R = 16 (2-taxon row side; block-wide today: ~6.3 k cycles per iteration)");
+    run<64, 1>("R = 64 (3-taxon row side; block-wide today: ~8.1 k cycles per iteration), plain loop");
+    run<64, 8>("R = 64, loads of 8 k-steps in flight");
+    run<64, 16>("R = 64, loads of 16 k-steps in flight");
     return 0;
 }
